@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- fp64 CSR SpMV (y = alpha*A*x + beta*y, alpha = beta = 1) on MI355X through the C ABI.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one SpMV over one synthetic matrix resident in HBM.  N = 1 runs BASELINE.json configs[1]
+(Hardesty3-sized stand-in, 8,217,820 x 7,591,564, 40,451,632 nnz, adaptive strategy).  N > 1 is launched by
+torch.distributed.run, one rank per GPU: every rank owns one such matrix as its row range of an
+(N*m) x n global matrix (weak scaling), x is replicated, and each step ends with the RCCL allgather of the
+y sub-vectors.  Rank 0 prints ONE JSON line.
+
+value       = 2 * nnz_total * K / wall_seconds / 1e9  [GFLOP/s], wall-clock over exactly K steps bracketed by
+              barrier + torch.cuda.synchronize() on both sides, max over ranks.
+roofline    = algorithmic bytes (12*nnz + 4*(m+1) + 8*n + 16*m) / mean per-launch duration,
+              measured with hipEvents recorded by the library on the stream the kernels are launched on.
+cpu_baseline= the oracle (CPU restatement of cli/verification.cpp:56-66) on the host cores, same matrix.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--workload", default="hardesty3",
+                   help="hardesty3 | banded | rmat | one of the large-set names (boneS10, Bump_2911, ...)")
+    p.add_argument("--strategy", default=None, help="KERNEL_STRATEGY name (default: adaptive; banded/rmat per BASELINE)")
+    p.add_argument("--scale", type=float, default=1.0, help="shrink the workload (for rehearsals only)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--no-overlap", action="store_true", help="N>1: wait for each allgather before the next SpMV")
+    return p.parse_args()
+
+
+def build_workload(args, torch, device, rank):
+    from spmv_acc_amd import synth
+
+    w = args.workload
+    if w == "hardesty3":
+        m, n, nnz, rp, ci, v = synth.hardesty3_like_torch(device=device, seed=0xC2 + rank, scale=args.scale)
+        return dict(name="Hardesty3-like (SuiteSparse Hardesty3 dims, synthetic stand-in)", m=m, n=n, nnz=nnz, rp=rp,
+                    ci=ci, v=v, strategy=args.strategy or "adaptive")
+    if w == "banded":
+        rows = int(32_000_000 * args.scale)
+        world = max(args.gpus, 1)
+        rp, ci, v = synth.banded_torch(rows, first_row=rank * rows, total_rows=world * rows, device=device)
+        return dict(name="banded offsets -4..+3 (BASELINE configs[4] shard)", m=rows, n=world * rows,
+                    nnz=int(rp[-1].item()), rp=rp, ci=ci, v=v, strategy=args.strategy or "adaptive", global_cols=True)
+    if w == "rmat":
+        scale = max(int(round(25 + np.log2(max(args.scale, 1e-9)))), 8)
+        m, n, nnz, rp, ci, v = synth.rmat_torch(scale, device=device, seed=0xC4 + rank)
+        return dict(name=f"R-MAT scale {scale} edge factor 16", m=m, n=n, nnz=nnz, rp=rp, ci=ci, v=v,
+                    strategy=args.strategy or "line_enhance")
+    if w in synth.LARGE_SET:
+        m, n, nnz, rp, ci, v = synth.large_set_like_torch(w, device=device, seed=0xC300 + rank, scale=args.scale)
+        return dict(name=f"{w}-like (synthetic stand-in)", m=m, n=n, nnz=nnz, rp=rp, ci=ci, v=v,
+                    strategy=args.strategy or "flat")
+    raise SystemExit(f"unknown workload {w}")
+
+
+def cpu_baseline(W, x, y0, seconds):
+    """Oracle timed on the host cores (rank 0, N = 1 only).  Whole matrix, repeated for ~`seconds`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    rp = W["rp"].cpu().numpy()
+    ci = W["ci"].cpu().numpy()
+    v = W["v"].cpu().numpy()
+    hx = x.cpu().numpy()
+    hy0 = y0.cpu().numpy()
+    nnz = W["nnz"]
+    cores = min(oracle_lib.max_threads(), os.cpu_count() or 1)
+
+    def timed(fn, budget):
+        reps, best, t_start = 0, float("inf"), time.perf_counter()
+        while True:
+            y = hy0.copy()
+            t0 = time.perf_counter()
+            fn(y)
+            dt = time.perf_counter() - t0
+            best = min(best, dt)
+            reps += 1
+            if time.perf_counter() - t_start > budget or reps >= 50:
+                return best, reps
+
+    t1, r1 = timed(lambda y: oracle_lib.host_spmv_inplace(1.0, 1.0, rp, ci, v, hx, y), seconds * 0.4)
+    tc, rc = timed(lambda y: oracle_lib.host_spmv_omp(1.0, 1.0, rp, ci, v, hx, y, cores), seconds * 0.6)
+    return {
+        "value": round(2.0 * nnz / tc / 1e9, 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
+        "sample": f"whole matrix ({W['m']} rows, {nnz} nnz), best of {rc} runs on {cores} threads (OpenMP over "
+                  f"nnz-balanced row ranges); 1 thread: {2.0 * nnz / t1 / 1e9:.3f} GFLOP/s best of {r1}",
+        "value_1thread": round(2.0 * nnz / t1 / 1e9, 3),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import spmv_acc_amd
+    from spmv_acc_amd import synth
+    from spmv_acc_amd.dist import RowShardedSpmv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    spmv_acc_amd.load_library()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    W = build_workload(args, torch, device, rank)
+    m, n, nnz = W["m"], W["n"], W["nnz"]
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234)  # x is replicated: same seed on every rank
+    x = torch.rand(n, generator=gen, device=device, dtype=torch.float64) * 2 - 1
+    y0 = torch.rand(m, generator=gen, device=device, dtype=torch.float64) * 2 - 1
+    y = y0.clone()
+    strat = W["strategy"]
+    alpha = beta = 1.0  # cli/main.cpp:95-96, benchmark/main.cpp:101-102
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out_extra = {}
+    if world == 1:
+        # ---- warm-up (builds the plan: nnz / samples / break points are fetched once here) ----
+        for _ in range(max(args.warmup, 1)):
+            spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y, strategy=strat)
+        torch.cuda.synchronize()
+        y.copy_(y0)
+        sync_all()
+        t0 = time.perf_counter()
+        ms = spmv_acc_amd.time_spmv(strat, args.steps, alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y)
+        sync_all()
+        wall = time.perf_counter() - t0
+        ev_ms = float(np.mean(ms))
+        out_extra["event_ms_median"] = round(float(np.median(ms)), 6)
+        out_extra["event_ms_min"] = round(float(np.min(ms)), 6)
+    else:
+        bounds = np.arange(world + 1, dtype=np.int64) * m  # every rank owns m rows of the (world*m) x n matrix
+        eng = RowShardedSpmv(rank, world, bounds, W["rp"], W["ci"], W["v"], n, device, strategy=strat)
+        for _ in range(max(args.warmup, 1)):
+            eng.step(alpha, beta, x, y_prev=y0, overlap=not args.no_overlap)
+        eng.wait()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.step(alpha, beta, x, y_prev=y0, overlap=not args.no_overlap)
+        eng.wait()
+        sync_all()
+        wall = time.perf_counter() - t0
+        # SpMV-only leg (no collective) for the same shard, per-launch hipEvents
+        ms = spmv_acc_amd.time_spmv(strat, min(args.steps, 50), alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y)
+        ev_ms = float(np.mean(ms))
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        out_extra["spmv_only_gflops_per_gpu"] = round(2.0 * nnz / (ev_ms * 1e-3) / 1e9, 3)
+        out_extra["allgather_bytes_per_rank_per_step"] = 8 * eng.pad * (world - 1)
+
+    ms_per_step = wall / args.steps * 1e3
+    nnz_total = nnz * world  # weak scaling: every rank processes its own nnz
+    gflops = 2.0 * nnz_total * args.steps / wall / 1e9
+    b_alg = synth.algorithmic_bytes(m, n, nnz, beta_nonzero=True)
+    achieved = b_alg / (ev_ms * 1e-3) / 1e9
+    result = {
+        "metric": "CSR SpMV GFLOP/s (fp64, int32 indices; achieved HBM GB/s in roofline)",
+        "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": W["name"], "rows_per_gpu": m, "cols": n, "nnz_per_gpu": nnz, "strategy": strat,
+                   "alpha": alpha, "beta": beta, "scale": args.scale,
+                   "parallelism": "single GPU" if world == 1 else f"row-range shard x{world} + RCCL allgather(y)"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": b_alg, "launch_ms_mean": round(ev_ms, 6)},
+        "ref_formula_gibps": round(synth.reference_bytes(m, nnz) / 2**30 / (ev_ms * 1e-3), 2),
+        "gflops_kernel_only_per_gpu": round(2.0 * nnz / (ev_ms * 1e-3) / 1e9, 3),
+    }
+    result.update(out_extra)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(W, x, y0, args.cpu_seconds)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

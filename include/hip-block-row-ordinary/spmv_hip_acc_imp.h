@@ -1,0 +1,6 @@
+// hip-block-row-ordinary/spmv_hip_acc_imp.h -- forwarding header at the reference's include path (src/acc/hip-block-row-ordinary/spmv_hip_acc_imp.h);
+// the declarations live in spmv_acc_strategies.hpp.
+#ifndef SPMV_ACC_AMD_FWD_HIP_BLOCK_ROW_ORDINARY_SPMV_HIP_ACC_IMP_H
+#define SPMV_ACC_AMD_FWD_HIP_BLOCK_ROW_ORDINARY_SPMV_HIP_ACC_IMP_H
+#include "../spmv_acc_strategies.hpp"
+#endif

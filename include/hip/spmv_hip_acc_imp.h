@@ -1,0 +1,6 @@
+// hip/spmv_hip_acc_imp.h -- forwarding header at the reference's include path (src/acc/hip/spmv_hip_acc_imp.h);
+// the declarations live in spmv_acc_strategies.hpp.
+#ifndef SPMV_ACC_AMD_FWD_HIP_SPMV_HIP_ACC_IMP_H
+#define SPMV_ACC_AMD_FWD_HIP_SPMV_HIP_ACC_IMP_H
+#include "../spmv_acc_strategies.hpp"
+#endif

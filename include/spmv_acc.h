@@ -1,0 +1,158 @@
+/*
+ * spmv_acc.h -- C ABI of the MI355X-native CSR SpMV engine (libspmv_acc.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  Every entry point
+ * names the reference interface (hpcde/spmv-acc, paths relative to the reference root) it replaces.
+ * All matrix / vector pointers are DEVICE pointers (hipMalloc) unless a parameter says "host".
+ * fp64 values, int32 indices, y = alpha*A*x + beta*y for any alpha, beta (src/acc/api/spmv.h:13-18).
+ *
+ * Calls are asynchronous: kernels are enqueued on the library stream (NULL stream unless
+ * spmv_acc_set_stream was called) and the function returns; the caller synchronises
+ * (as cli/main.cpp:104,111 does with hipDeviceSynchronize).  The reference API returns void and
+ * checks nothing; errors here are reported out of band through spmv_acc_last_error().
+ */
+#ifndef SPMV_ACC_C_ABI_H
+#define SPMV_ACC_C_ABI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- KERNEL_STRATEGY plugin surface ------------------------------------------------------------
+ * replaces: the compile-time switch -DKERNEL_STRATEGY=<name> (config.cmake:15,
+ * src/configure.cmake:17-40, src/building_config.h.in:24-34, src/acc/strategy_picker.cpp:19-65).
+ * The build-time macro KERNEL_STRATEGY_<NAME> still selects the default; the environment variable
+ * SPMV_ACC_KERNEL_STRATEGY and spmv_acc_set_strategy() override it at run time so one binary serves
+ * every configuration.  Names are matched like the reference's CMake regex: case-insensitive
+ * substring, "line_enhance" tested before "line". */
+enum spmv_acc_strategy {
+  SPMV_ACC_DEFAULT = 0,
+  SPMV_ACC_ADAPTIVE = 1,
+  SPMV_ACC_THREAD_ROW = 2,
+  SPMV_ACC_WF_ROW = 3,
+  SPMV_ACC_BLOCK_ROW_ORDINARY = 4,
+  SPMV_ACC_LIGHT = 5,
+  SPMV_ACC_VECTOR_ROW = 6,
+  SPMV_ACC_LINE_ENHANCE = 7,
+  SPMV_ACC_LINE = 8,
+  SPMV_ACC_FLAT = 9,
+  SPMV_ACC_ADAPTIVE_PLUS = 10 /* benchmark-only entry of the reference (benchmark_spmv_acc.hpp:186-200) */
+};
+int spmv_acc_set_strategy(const char *name); /* 0 on success, -1 unknown name */
+int spmv_acc_set_strategy_id(int strategy);
+int spmv_acc_get_strategy(void);
+const char *spmv_acc_strategy_name(int strategy);
+int spmv_acc_parse_strategy(const char *name); /* -1 if no match */
+
+/* ---- primary entry -------------------------------------------------------------------------------
+ * replaces: void sparse_spmv(int htrans, const double halpha, const double hbeta, int hm, int hn,
+ *           const int *rowptr, const int *colindex, const double *value, const double *x, double *y)
+ *           -- src/acc/api/spmv.h:27-28, src/acc/api/spmv_imp.cpp:10-18 (C++ linkage there; the same
+ *           ten arguments with C linkage here).
+ * The reference reads rowptr[hm] on the HOST (spmv_imp.cpp:14), which needs host-visible device
+ * memory; here nnz and the strategy pickers' rowptr samples are fetched from the device once per
+ * matrix and cached, so plain hipMalloc memory works. */
+void sparse_spmv(int htrans, const double halpha, const double hbeta, int hm, int hn, const int *rowptr,
+                 const int *colindex, const double *value, const double *x, double *y);
+
+/* ---- descriptor entry, flattened to C --------------------------------------------------------------
+ * replaces: void sparse_csr_spmv(int trans, const double alpha, const double beta,
+ *           const csr_desc<int,double> h_csr_desc, const csr_desc<int,double> d_csr_desc,
+ *           const double *dx, double *dy) -- src/acc/api/spmv.h:20-21, strategy_picker.cpp:19-65
+ *           (the entry spmv-cli calls, cli/main.cpp:102,110,117).
+ * h_rowptr: HOST copy of rowptr or NULL.  nnz: number of non-zeros, or -1 to read rowptr[m]. */
+void spmv_acc_csr_spmv(int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
+                       const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx,
+                       double *dy);
+
+/* ---- per-strategy entry ------------------------------------------------------------------------------
+ * replaces: the L1 wrappers the benchmark harness calls directly (benchmark/benchmark_spmv_acc.hpp:27-200):
+ *   default_sparse_spmv (hip/spmv_hip_acc_imp.cpp:29), adaptive_sparse_spmv (hip-adaptive/adaptive.cpp:16),
+ *   flat_sparse_spmv (hip-flat/flat.cpp:47), line_enhance_sparse_spmv / adaptive_enhance_sparse_spmv
+ *   (hip-line-enhance/line_enhance_spmv.cpp:8,23), adaptive_line_sparse_spmv (hip-line/line_strategy.cpp:52),
+ *   vec_row_sparse_spmv (hip-vector-row/vector_row.cpp:9), csr_adaptive_plus_sparse_spmv
+ *   (hip-csr-adaptive-plus/csr_adaptive_plus_spmv.cpp:132), ... selected by `strategy`. */
+void spmv_acc_csr_spmv_strategy(int strategy, int trans, double alpha, double beta, int m, int n, int nnz,
+                                const int *h_rowptr, const int *d_rowptr, const int *d_colindex,
+                                const double *d_value, const double *dx, double *dy);
+
+/* ---- row-block preprocessing pass, device form ---------------------------------------------------------
+ * replaces: pre_calc_break_point<STRIDE, BLOCKS, int><<<1024,512>>>(row_ptr, m, break_points, bp_len)
+ *           -- src/acc/hip-flat/flat_imp.inl:108-131, launched from flat.cpp:25,43.
+ * d_break_points (device, bp_len ints) receives bit-identical values; no pre-zeroing needed.
+ * Returns 0, or an error code. */
+int spmv_acc_break_points(const int *d_rowptr, int m, int nnz, int stride, int *d_break_points, int bp_len);
+int spmv_acc_break_points_len(int nnz, int stride); /* flat.cpp:35-38: ceil(nnz/stride) + 1 */
+
+/* ---- row-block preprocessing pass, host form --------------------------------------------------------------
+ * replaces: csr_adaptive_plus_analyze_imp<int, THREADS, VEC>(m, nnz, MIN_NNZ_PER_BLOCK, break_points,
+ *           first_block_of_row, host_row_ptr, dev_row_ptr) -- hip-csr-adaptive-plus/csr_adaptive_plus_analyze.cpp:13-98.
+ * h_break_points: host, capacity bp_cap (m + 2 + nnz / (2 * min_nnz_per_block) is always enough); h_first_block_of_row: host, m + 1 ints.
+ * Returns the number of row blocks, -1 if bp_cap is too small. */
+int spmv_acc_adaptive_plus_analyze(int m, int min_nnz_per_block, int threads_per_block, int vec_size,
+                                   const int *h_rowptr, int *h_break_points, int bp_cap,
+                                   int *h_first_block_of_row);
+int spmv_acc_adaptive_plus_vec(int m, int nnz); /* csr_adaptive_plus_spmv.cpp:139-165 */
+
+/* ---- strategy pickers (host logic, no GPU needed) --------------------------------------------------------------
+ * replaces: the decision tree of adaptive_sparse_spmv, hip-adaptive/adaptive.cpp:24-66, on the same four
+ * inputs rowptr[m/4], rowptr[m/2], rowptr[3m/4], rowptr[m].  Returns 1 vector-row split, 2 adaptive line,
+ * 3 adaptive line-enhance, 4 adaptive flat, 5 line-enhance. */
+int spmv_acc_adaptive_branch(int m, int rp_quarter, int rp_half, int rp_three_quarter, int rp_last);
+
+/* ---- multi-GPU row-range partition (new; the reference is single-GPU) -----------------------------------------------
+ * Contiguous row ranges for `parts` ranks.  mode 0: equal row counts (what an allgather of equal-sized
+ * y shards needs); mode 1: nnz-balanced boundaries found by binary search on rowptr.
+ * h_rowptr: host rowptr (may be NULL for mode 0).  row_begin: out, parts + 1 entries. */
+int spmv_acc_partition_rows(int m, int parts, int mode, const int *h_rowptr, int *row_begin);
+
+/* ---- host staging (new; replaces the pageable blocking hipMemcpy of cli/utils.hpp:94-117) ----------------------------
+ * Copies host CSR arrays + vectors to freshly hipMalloc'ed device buffers through a pinned bounce
+ * buffer with hipMemcpyAsync on a private copy stream (double-buffered).  Any of the host pointers
+ * may be NULL to skip that array.  Free with spmv_acc_free_device. */
+int spmv_acc_stage_csr(int m, int n, int nnz, const int *h_rowptr, const int *h_colindex, const double *h_value,
+                       const double *h_x, const double *h_y, int **d_rowptr, int **d_colindex, double **d_value,
+                       double **d_x, double **d_y);
+int spmv_acc_free_device(void *p);
+
+/* ---- plan cache, stream, errors ------------------------------------------------------------------------------------------
+ * Preprocessing results (break points, row blocks, carries) are cached per matrix, keyed by
+ * (device, rowptr, colindex, value, m, n).  Release when a matrix' structure changes in place or its
+ * buffers are freed; NULL releases everything. */
+void spmv_acc_release_plans(const int *d_rowptr);
+int spmv_acc_cached_plans(void);
+/* plan introspection: fills out[6] = {nnz, adaptive_branch, vec, flat_tiles, plus_blocks, aligned16}; 1 if found */
+int spmv_acc_query_plan(const int *d_rowptr, int m, int *out);
+
+void spmv_acc_set_stream(void *hip_stream); /* hipStream_t; NULL = the NULL stream (reference behaviour) */
+void *spmv_acc_get_stream(void);
+
+int spmv_acc_last_error(void); /* 0 = ok; see enum below */
+const char *spmv_acc_last_error_string(void);
+void spmv_acc_clear_error(void);
+enum spmv_acc_error {
+  SPMV_ACC_OK = 0,
+  SPMV_ACC_ERR_UNSUPPORTED_TRANS = 1,
+  SPMV_ACC_ERR_BAD_ARGUMENT = 2,
+  SPMV_ACC_ERR_HIP = 3,
+  SPMV_ACC_ERR_TOO_LARGE = 4,
+  SPMV_ACC_ERR_UNKNOWN_STRATEGY = 5,
+  SPMV_ACC_ERR_NO_DEVICE = 6
+};
+
+/* ---- measurement helper ----------------------------------------------------------------------------------------------------
+ * replaces: hip::timer::event_timer around the L1 call (benchmark/utils/timer_utils.h:16-51,
+ * benchmark/csr_spmv.hpp:67-74).  Runs `iters` SpMVs with `strategy`; each is bracketed by hipEvents on
+ * the library stream, y is restored from d_y0 (device, m doubles, may be NULL) outside the timed region.
+ * ms_out receives iters per-launch durations in milliseconds.  Returns 0 or an error code. */
+int spmv_acc_time_spmv(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
+                       const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
+                       const double *dx, double *dy, const double *d_y0, float *ms_out);
+
+const char *spmv_acc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SPMV_ACC_C_ABI_H */

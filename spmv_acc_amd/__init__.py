@@ -1,0 +1,237 @@
+"""spmv_acc_amd -- Python plumbing over the C ABI of libspmv_acc.so (include/spmv_acc.h).
+
+The product is the HIP library; this module only loads it with ctypes and passes raw device
+pointers (``tensor.data_ptr()``).  There is no CPU fallback: every compute entry point raises if the
+library is missing.  (The CPU oracle lives under ``oracle/`` and is test infrastructure only.)
+
+Reference interface mirrored (names and argument meaning): ``sparse_spmv`` (src/acc/api/spmv.h:27-28),
+``sparse_csr_spmv`` (api/spmv.h:20-21) and the KERNEL_STRATEGY names (src/configure.cmake:17-40).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspmv_acc.so")
+
+STRATEGIES = (
+    "default", "adaptive", "thread_row", "wf_row", "block_row_ordinary", "light",
+    "vector_row", "line_enhance", "line", "flat", "adaptive_plus",
+)
+# the strategies BASELINE.json's north_star names (+ the row-block preprocessing entry)
+HOT_STRATEGIES = ("default", "adaptive", "flat", "line_enhance", "line", "vector_row", "adaptive_plus")
+
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+
+# every symbol include/spmv_acc.h declares (tests check the library exports all of them)
+C_ABI_SYMBOLS = (
+    "sparse_spmv", "spmv_acc_csr_spmv", "spmv_acc_csr_spmv_strategy", "spmv_acc_set_strategy",
+    "spmv_acc_set_strategy_id", "spmv_acc_get_strategy", "spmv_acc_strategy_name", "spmv_acc_parse_strategy",
+    "spmv_acc_break_points", "spmv_acc_break_points_len", "spmv_acc_adaptive_plus_analyze",
+    "spmv_acc_adaptive_plus_vec", "spmv_acc_adaptive_branch", "spmv_acc_partition_rows", "spmv_acc_stage_csr",
+    "spmv_acc_free_device", "spmv_acc_release_plans", "spmv_acc_cached_plans", "spmv_acc_query_plan",
+    "spmv_acc_set_stream", "spmv_acc_get_stream", "spmv_acc_last_error", "spmv_acc_last_error_string",
+    "spmv_acc_clear_error", "spmv_acc_time_spmv", "spmv_acc_version",
+)
+
+_lib = None
+
+
+class SpmvAccError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """Load libspmv_acc.so (built by ``__graft_entry__.build()`` / ``make -C spmv_acc_amd/csrc``)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise SpmvAccError(
+            f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C spmv_acc_amd/csrc`. There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(p)
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    lib.sparse_spmv.argtypes = [ci, cd, cd, ci, ci, vp, vp, vp, vp, vp]
+    lib.sparse_spmv.restype = None
+    lib.spmv_acc_csr_spmv.argtypes = [ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+    lib.spmv_acc_csr_spmv.restype = None
+    lib.spmv_acc_csr_spmv_strategy.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+    lib.spmv_acc_csr_spmv_strategy.restype = None
+    lib.spmv_acc_set_strategy.argtypes = [ctypes.c_char_p]
+    lib.spmv_acc_set_strategy_id.argtypes = [ci]
+    lib.spmv_acc_strategy_name.argtypes = [ci]
+    lib.spmv_acc_strategy_name.restype = ctypes.c_char_p
+    lib.spmv_acc_parse_strategy.argtypes = [ctypes.c_char_p]
+    lib.spmv_acc_break_points.argtypes = [vp, ci, ci, ci, vp, ci]
+    lib.spmv_acc_break_points_len.argtypes = [ci, ci]
+    lib.spmv_acc_adaptive_plus_analyze.argtypes = [ci, ci, ci, ci, vp, vp, ci, vp]
+    lib.spmv_acc_adaptive_plus_vec.argtypes = [ci, ci]
+    lib.spmv_acc_adaptive_branch.argtypes = [ci, ci, ci, ci, ci]
+    lib.spmv_acc_partition_rows.argtypes = [ci, ci, ci, vp, vp]
+    lib.spmv_acc_stage_csr.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp] + [ctypes.POINTER(vp)] * 5
+    lib.spmv_acc_free_device.argtypes = [vp]
+    lib.spmv_acc_release_plans.argtypes = [vp]
+    lib.spmv_acc_release_plans.restype = None
+    lib.spmv_acc_query_plan.argtypes = [vp, ci, vp]
+    lib.spmv_acc_set_stream.argtypes = [vp]
+    lib.spmv_acc_set_stream.restype = None
+    lib.spmv_acc_get_stream.restype = vp
+    lib.spmv_acc_last_error_string.restype = ctypes.c_char_p
+    lib.spmv_acc_clear_error.restype = None
+    lib.spmv_acc_time_spmv.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.spmv_acc_version.restype = ctypes.c_char_p
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def strategy_id(name_or_id) -> int:
+    if isinstance(name_or_id, int):
+        return name_or_id
+    s = load_library().spmv_acc_parse_strategy(str(name_or_id).encode())
+    if s < 0:
+        raise SpmvAccError(f"unknown KERNEL_STRATEGY {name_or_id!r}")
+    return s
+
+
+def _check(lib) -> None:
+    code = lib.spmv_acc_last_error()
+    if code not in (0, 1):  # 1 = unsupported trans: reported, not fatal (reference ignores trans)
+        msg = lib.spmv_acc_last_error_string().decode()
+        lib.spmv_acc_clear_error()
+        raise SpmvAccError(f"spmv_acc error {code}: {msg}")
+
+
+def _ptr(t) -> int:
+    """Raw pointer of a torch tensor / numpy array / int (0 for None)."""
+    if t is None:
+        return 0
+    if isinstance(t, int):
+        return t
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def _require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and hasattr(t, "is_cuda") and not t.is_cuda:
+            raise SpmvAccError("device pointers required: tensor is not on the GPU (no CPU fallback)")
+
+
+def sparse_spmv(trans: int, alpha: float, beta: float, m: int, n: int, rowptr, colindex, value, x, y) -> None:
+    """Ten-argument entry with the active strategy; all tensors on the GPU; y updated in place (async)."""
+    lib = load_library()
+    _require_cuda(rowptr, colindex, value, x, y)
+    lib.sparse_spmv(trans, alpha, beta, m, n, _ptr(rowptr), _ptr(colindex), _ptr(value), _ptr(x), _ptr(y))
+    _check(lib)
+
+
+def csr_spmv(alpha: float, beta: float, m: int, n: int, nnz: int, rowptr, colindex, value, x, y,
+             strategy=None, h_rowptr=None, trans: int = 0) -> None:
+    """Descriptor entry (sparse_csr_spmv flattened).  ``h_rowptr``: optional host (numpy int32) rowptr."""
+    lib = load_library()
+    _require_cuda(rowptr, colindex, value, x, y)
+    args = (trans, alpha, beta, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr), _ptr(colindex), _ptr(value), _ptr(x), _ptr(y))
+    if strategy is None:
+        lib.spmv_acc_csr_spmv(*args)
+    else:
+        lib.spmv_acc_csr_spmv_strategy(strategy_id(strategy), *args)
+    _check(lib)
+
+
+def break_points(rowptr, m: int, nnz: int, stride: int, out) -> None:
+    """Device form of the row-block preprocessing pass into ``out`` (GPU int32, break_points_len entries)."""
+    lib = load_library()
+    _require_cuda(rowptr, out)
+    rc = lib.spmv_acc_break_points(_ptr(rowptr), m, nnz, stride, _ptr(out), out.numel())
+    if rc != 0:
+        _check(lib)
+
+
+def break_points_len(nnz: int, stride: int) -> int:
+    return load_library().spmv_acc_break_points_len(nnz, stride)
+
+
+def adaptive_plus_analyze(h_rowptr, m: int, min_nnz_per_block: int = 2048, threads_per_block: int = 512,
+                          vec_size: int = 1):
+    """Host form of the row-block preprocessing pass.  Returns (blocks, break_points, first_block_of_row)."""
+    import numpy as np
+
+    lib = load_library()
+    h_rowptr = np.ascontiguousarray(h_rowptr, dtype=np.int32)
+    nnz = int(h_rowptr[m])
+    bp = np.zeros(m + 2 + nnz // (2 * min_nnz_per_block), dtype=np.int32)  # rows + long-row slices
+    fbr = np.zeros(m + 1, dtype=np.int32)
+    blocks = lib.spmv_acc_adaptive_plus_analyze(m, min_nnz_per_block, threads_per_block, vec_size, _ptr(h_rowptr),
+                                                _ptr(bp), bp.size, _ptr(fbr))
+    if blocks < 0:
+        raise SpmvAccError(f"adaptive_plus_analyze failed ({blocks})")
+    return blocks, bp[: blocks + 1].copy(), fbr
+
+
+def adaptive_branch(m: int, h_rowptr) -> int:
+    return load_library().spmv_acc_adaptive_branch(m, int(h_rowptr[m // 4]), int(h_rowptr[m // 2]),
+                                                   int(h_rowptr[3 * m // 4]), int(h_rowptr[m]))
+
+
+def partition_rows(m: int, parts: int, mode: int = 0, h_rowptr=None):
+    import numpy as np
+
+    lib = load_library()
+    out = np.zeros(parts + 1, dtype=np.int32)
+    if h_rowptr is not None:
+        h_rowptr = np.ascontiguousarray(h_rowptr, dtype=np.int32)
+    rc = lib.spmv_acc_partition_rows(m, parts, mode, _ptr(h_rowptr), _ptr(out))
+    if rc != 0:
+        _check(lib)
+        raise SpmvAccError("partition_rows failed")
+    return out
+
+
+def time_spmv(strategy, iters: int, alpha: float, beta: float, m: int, n: int, nnz: int, rowptr, colindex, value,
+              x, y, y0=None, h_rowptr=None) -> Sequence[float]:
+    """Per-launch durations (ms) from hipEvents recorded on the library stream around each SpMV."""
+    lib = load_library()
+    _require_cuda(rowptr, colindex, value, x, y, y0)
+    out = (ctypes.c_float * iters)()
+    rc = lib.spmv_acc_time_spmv(strategy_id(strategy), iters, alpha, beta, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr),
+                                _ptr(colindex), _ptr(value), _ptr(x), _ptr(y), _ptr(y0),
+                                ctypes.cast(out, ctypes.c_void_p))
+    if rc != 0:
+        msg = lib.spmv_acc_last_error_string().decode()
+        raise SpmvAccError(f"time_spmv failed ({rc}): {msg}")
+    return list(out)
+
+
+def release_plans(rowptr=None) -> None:
+    load_library().spmv_acc_release_plans(_ptr(rowptr))
+
+
+def query_plan(rowptr, m: int):
+    import numpy as np
+
+    out = np.zeros(6, dtype=np.int32)
+    found = load_library().spmv_acc_query_plan(_ptr(rowptr), m, _ptr(out))
+    if not found:
+        return None
+    keys = ("nnz", "adaptive_branch", "vec", "flat_tiles", "plus_blocks", "aligned16")
+    return dict(zip(keys, (int(v) for v in out)))
+
+
+def set_strategy(name: str) -> None:
+    lib = load_library()
+    if lib.spmv_acc_set_strategy(name.encode()) != 0:
+        lib.spmv_acc_clear_error()
+        raise SpmvAccError(f"unknown KERNEL_STRATEGY {name!r}")
+
+
+def get_strategy() -> str:
+    lib = load_library()
+    return lib.spmv_acc_strategy_name(lib.spmv_acc_get_strategy()).decode()

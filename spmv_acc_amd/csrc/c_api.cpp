@@ -1,0 +1,252 @@
+// c_api.cpp -- extern "C" entry points declared in include/spmv_acc.h.
+// (The C++-linkage twins the reference's executables link against live in cxx_api.cpp: a function
+// cannot be declared with both linkages in one translation unit.)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../include/spmv_acc.h"
+#include "engine.hpp"
+
+using namespace spmv_acc;
+
+// ---- pinned, double-buffered host -> device staging ----------------------------------------------------
+namespace {
+struct Stager {
+  static constexpr size_t kChunk = 32u << 20; // 32 MiB per pinned bounce buffer
+  void *pinned[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  hipStream_t copy = nullptr;
+  bool ok = true;
+  Stager() {
+    ok = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 2; ++i) {
+      ok = hipHostMalloc(&pinned[i], kChunk, hipHostMallocDefault) == hipSuccess &&
+           hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
+    }
+  }
+  ~Stager() {
+    for (int i = 0; i < 2; ++i) {
+      if (done[i]) (void)hipEventDestroy(done[i]);
+      if (pinned[i]) (void)hipHostFree(pinned[i]);
+    }
+    if (copy) (void)hipStreamDestroy(copy);
+  }
+  // memcpy into one pinned buffer while the other one is in flight on the copy stream
+  bool upload(void *dst, const void *src, size_t bytes) {
+    size_t off = 0;
+    int slot = 0;
+    while (off < bytes) {
+      const size_t n = std::min(kChunk, bytes - off);
+      if (hipEventSynchronize(done[slot]) != hipSuccess) return false;
+      std::memcpy(pinned[slot], static_cast<const char *>(src) + off, n);
+      if (hipMemcpyAsync(static_cast<char *>(dst) + off, pinned[slot], n, hipMemcpyHostToDevice, copy) != hipSuccess)
+        return false;
+      if (hipEventRecord(done[slot], copy) != hipSuccess) return false;
+      off += n;
+      slot ^= 1;
+    }
+    return true;
+  }
+};
+
+template <typename T> bool stage_one(Stager &st, const T *h, size_t count, T **d) {
+  *d = nullptr;
+  if (!h || count == 0) return true;
+  if (hipMalloc(reinterpret_cast<void **>(d), sizeof(T) * count) != hipSuccess) return false;
+  return st.upload(*d, h, sizeof(T) * count);
+}
+} // namespace
+
+extern "C" {
+
+const char *spmv_acc_version(void) { return "spmv_acc_amd 0.1 (gfx950)"; }
+
+int spmv_acc_set_strategy(const char *name) {
+  const int s = parse_strategy(name);
+  if (s < 0) {
+    set_error(kErrUnknownStrategy, std::string("unknown KERNEL_STRATEGY: ") + (name ? name : "(null)"));
+    return -1;
+  }
+  return set_active_strategy(s);
+}
+int spmv_acc_set_strategy_id(int strategy) { return set_active_strategy(strategy); }
+int spmv_acc_get_strategy(void) { return active_strategy(); }
+const char *spmv_acc_strategy_name(int strategy) { return strategy_name(strategy); }
+int spmv_acc_parse_strategy(const char *name) { return parse_strategy(name); }
+
+void sparse_spmv(int htrans, const double halpha, const double hbeta, int hm, int hn, const int *rowptr,
+                 const int *colindex, const double *value, const double *x, double *y) {
+  run_spmv(active_strategy(), htrans, halpha, hbeta, hm, hn, /*nnz=*/-1, /*h_rowptr=*/nullptr, rowptr, colindex, value,
+           x, y);
+}
+
+void spmv_acc_csr_spmv(int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
+                       const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx,
+                       double *dy) {
+  run_spmv(active_strategy(), trans, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy);
+}
+
+void spmv_acc_csr_spmv_strategy(int strategy, int trans, double alpha, double beta, int m, int n, int nnz,
+                                const int *h_rowptr, const int *d_rowptr, const int *d_colindex,
+                                const double *d_value, const double *dx, double *dy) {
+  run_spmv(strategy, trans, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy);
+}
+
+int spmv_acc_break_points_len(int nnz, int stride) {
+  if (stride <= 0 || nnz < 0) return -1;
+  return nnz / stride + (nnz % stride ? 1 : 0) + 1;
+}
+
+int spmv_acc_break_points(const int *d_rowptr, int m, int nnz, int stride, int *d_break_points, int bp_len) {
+  if (!d_rowptr || !d_break_points || m < 0 || nnz < 0 || stride <= 0 || bp_len < 1) {
+    set_error(kErrBadArgument, "spmv_acc_break_points: bad argument");
+    return kErrBadArgument;
+  }
+  launch_break_points(get_stream(), d_rowptr, m, nnz, stride, d_break_points, bp_len);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(kErrHip, hipGetErrorString(e));
+    return kErrHip;
+  }
+  return kOk;
+}
+
+int spmv_acc_adaptive_plus_analyze(int m, int min_nnz_per_block, int threads_per_block, int vec_size,
+                                   const int *h_rowptr, int *h_break_points, int bp_cap,
+                                   int *h_first_block_of_row) {
+  if (m < 0 || !h_rowptr || !h_break_points || !h_first_block_of_row || min_nnz_per_block <= 0 || vec_size <= 0 ||
+      threads_per_block < vec_size) {
+    set_error(kErrBadArgument, "spmv_acc_adaptive_plus_analyze: bad argument");
+    return -2;
+  }
+  std::vector<int> bp, fbr;
+  const int blocks = plus_analyze_host(m, min_nnz_per_block, threads_per_block, vec_size, h_rowptr, bp, fbr);
+  if (static_cast<int>(bp.size()) > bp_cap) return -1;
+  std::copy(bp.begin(), bp.end(), h_break_points);
+  std::copy(fbr.begin(), fbr.end(), h_first_block_of_row);
+  return blocks;
+}
+
+int spmv_acc_adaptive_plus_vec(int m, int nnz) { return plus_pick_vec(m, nnz); }
+
+int spmv_acc_adaptive_branch(int m, int rp_quarter, int rp_half, int rp_three_quarter, int rp_last) {
+  if (m <= 0) return 0;
+  RowptrSamples s;
+  s.q1 = rp_quarter;
+  s.half = rp_half;
+  s.q3 = rp_three_quarter;
+  s.last = rp_last;
+  return adaptive_branch(m, s);
+}
+
+int spmv_acc_partition_rows(int m, int parts, int mode, const int *h_rowptr, int *row_begin) {
+  if (m < 0 || parts <= 0 || !row_begin || (mode == 1 && !h_rowptr)) {
+    set_error(kErrBadArgument, "spmv_acc_partition_rows: bad argument");
+    return kErrBadArgument;
+  }
+  row_begin[0] = 0;
+  row_begin[parts] = m;
+  if (mode == 0) {
+    // equal row counts: the first (m mod parts) ranks get one more row only if m is not divisible;
+    // callers that need identical shard sizes for an allgather pad to ceil(m/parts)
+    const long long per = (static_cast<long long>(m) + parts - 1) / parts;
+    for (int p = 1; p < parts; ++p) row_begin[p] = static_cast<int>(std::min<long long>(per * p, m));
+  } else {
+    const long long nnz = h_rowptr[m];
+    for (int p = 1; p < parts; ++p) {
+      const long long target = nnz * p / parts;
+      const int *it = std::lower_bound(h_rowptr, h_rowptr + m + 1, static_cast<int>(target));
+      int r = static_cast<int>(it - h_rowptr);
+      r = std::max(r, row_begin[p - 1]);
+      row_begin[p] = std::min(r, m);
+    }
+  }
+  return kOk;
+}
+
+int spmv_acc_stage_csr(int m, int n, int nnz, const int *h_rowptr, const int *h_colindex, const double *h_value,
+                       const double *h_x, const double *h_y, int **d_rowptr, int **d_colindex, double **d_value,
+                       double **d_x, double **d_y) {
+  if (m < 0 || n < 0 || nnz < 0 || !d_rowptr || !d_colindex || !d_value || !d_x || !d_y) {
+    set_error(kErrBadArgument, "spmv_acc_stage_csr: bad argument");
+    return kErrBadArgument;
+  }
+  Stager st;
+  bool ok = st.ok;
+  ok = ok && stage_one(st, h_rowptr, static_cast<size_t>(m) + 1, d_rowptr);
+  ok = ok && stage_one(st, h_colindex, static_cast<size_t>(nnz), d_colindex);
+  ok = ok && stage_one(st, h_value, static_cast<size_t>(nnz), d_value);
+  ok = ok && stage_one(st, h_x, static_cast<size_t>(n), d_x);
+  ok = ok && stage_one(st, h_y, static_cast<size_t>(m), d_y);
+  ok = ok && hipStreamSynchronize(st.copy) == hipSuccess;
+  if (!ok) {
+    const hipError_t e = hipGetLastError();
+    set_error(kErrHip, std::string("spmv_acc_stage_csr: ") + hipGetErrorString(e));
+    return kErrHip;
+  }
+  return kOk;
+}
+
+int spmv_acc_free_device(void *p) {
+  if (!p) return kOk;
+  return hipFree(p) == hipSuccess ? kOk : kErrHip;
+}
+
+void spmv_acc_release_plans(const int *d_rowptr) { release_plans(d_rowptr); }
+int spmv_acc_cached_plans(void) { return cached_plan_count(); }
+int spmv_acc_query_plan(const int *d_rowptr, int m, int *out) {
+  PlanInfo info;
+  if (!out || !query_plan(d_rowptr, m, &info)) return 0;
+  out[0] = info.nnz;
+  out[1] = info.adaptive_branch;
+  out[2] = info.vec;
+  out[3] = info.flat_tiles;
+  out[4] = info.plus_blocks;
+  out[5] = info.aligned16;
+  return 1;
+}
+
+void spmv_acc_set_stream(void *hip_stream) { set_stream(static_cast<hipStream_t>(hip_stream)); }
+void *spmv_acc_get_stream(void) { return static_cast<void *>(get_stream()); }
+
+int spmv_acc_last_error(void) { return last_error(); }
+const char *spmv_acc_last_error_string(void) { return last_error_string(); }
+void spmv_acc_clear_error(void) { clear_error(); }
+
+int spmv_acc_time_spmv(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
+                       const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
+                       const double *dx, double *dy, const double *d_y0, float *ms_out) {
+  if (iters <= 0 || !ms_out) {
+    set_error(kErrBadArgument, "spmv_acc_time_spmv: bad argument");
+    return kErrBadArgument;
+  }
+  hipStream_t st = get_stream();
+  std::vector<hipEvent_t> ev(2 * static_cast<size_t>(iters));
+  for (auto &e : ev) {
+    if (hipEventCreate(&e) != hipSuccess) {
+      set_error(kErrHip, "hipEventCreate failed");
+      return kErrHip;
+    }
+  }
+  clear_error();
+  for (int i = 0; i < iters; ++i) {
+    if (d_y0) (void)hipMemcpyAsync(dy, d_y0, sizeof(double) * static_cast<size_t>(m), hipMemcpyDeviceToDevice, st);
+    (void)hipEventRecord(ev[2 * i], st);
+    run_spmv(strategy, 0, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy);
+    (void)hipEventRecord(ev[2 * i + 1], st);
+  }
+  int rc = kOk;
+  if (hipStreamSynchronize(st) != hipSuccess) rc = kErrHip;
+  for (int i = 0; i < iters && rc == kOk; ++i) {
+    if (hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = kErrHip;
+  }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  if (rc != kOk) set_error(kErrHip, "spmv_acc_time_spmv: HIP failure while timing");
+  if (rc == kOk && last_error() != kOk) rc = last_error();
+  return rc;
+}
+
+} // extern "C"

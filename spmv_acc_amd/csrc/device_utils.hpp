@@ -1,0 +1,96 @@
+// device_utils.hpp -- wave64 building blocks shared by every kernel (gfx950 / CDNA4 only).
+//
+// Role in the reference: src/acc/common/ (dpp_reduce.h:13-54, utils.h:38-59, rocm_global_mem_ops.hpp:25-45)
+// provides a DPP wave reduction, a shfl_down reduction and inline-asm wide loads, all behind the
+// long-removed __HIP_PLATFORM_HCC__ macro.  This file is the gfx950-native counterpart: DPP
+// butterflies expressed with compiler builtins (so hipcc schedules and counts them), 16-byte
+// non-temporal streaming loads for the once-read CSR arrays, and an XCD-aware block remap.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spmv_acc {
+namespace dev {
+
+constexpr int kWave = 64;
+constexpr int kXcds = 8; // MI355X: 8 XCDs, workgroups dealt round-robin (b and b+8 share an L2)
+
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef double double2v __attribute__((ext_vector_type(2)));
+
+// ---- cross-lane -------------------------------------------------------------------------------
+// One DPP move of a 64-bit value = two v_mov_b32_dpp.  All lanes must be active at the call site.
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v);
+  int hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double swizzle_xor16_f64(double v) {
+  // ds_swizzle bit mode: and_mask 0x1F, or_mask 0, xor_mask 0x10 -> lane ^ 16 inside each 32-lane half
+  int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F);
+  int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
+  return __hiloint2double(hi, lo);
+}
+
+// Butterfly all-reduce inside aligned groups of VEC lanes (VEC = 1,2,4,...,64): every lane of a
+// group ends with the group's sum.  quad_perm -> row_half_mirror -> row_mirror stay in the DPP
+// network (no LDS traffic); the 32- and 64-lane steps cross DPP rows and go through ds_swizzle /
+// ds_bpermute.
+template <int VEC> __device__ __forceinline__ double group_sum(double v) {
+  static_assert(VEC >= 1 && VEC <= 64 && (VEC & (VEC - 1)) == 0, "VEC must be a power of two <= 64");
+  if (VEC >= 2) v += dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+  if (VEC >= 4) v += dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+  if (VEC >= 8) v += dpp_f64<0x141>(v); // row_half_mirror
+  if (VEC >= 16) v += dpp_f64<0x140>(v); // row_mirror
+  if (VEC >= 32) v += swizzle_xor16_f64(v);
+  if (VEC >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// Same butterfly with a run-time (wave-uniform) group width w in {1,2,4,...,64}.
+__device__ __forceinline__ double group_sum_dyn(double v, int w) {
+  if (w >= 2) v += dpp_f64<0xB1>(v);
+  if (w >= 4) v += dpp_f64<0x4E>(v);
+  if (w >= 8) v += dpp_f64<0x141>(v);
+  if (w >= 16) v += dpp_f64<0x140>(v);
+  if (w >= 32) v += swizzle_xor16_f64(v);
+  if (w >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// ---- streaming loads ----------------------------------------------------------------------------
+// values / colindex are read exactly once per SpMV: 16 B per lane, non-temporal so they do not
+// evict the x[] lines that the gathers want to find in L2 / Infinity Cache.
+__device__ __forceinline__ int4v load_stream_i4(const int *p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const int4v *>(p));
+}
+__device__ __forceinline__ double2v load_stream_d2(const double *p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const double2v *>(p));
+}
+__device__ __forceinline__ int load_stream(const int *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ double load_stream(const double *p) { return __builtin_nontemporal_load(p); }
+
+// ---- XCD-aware block remap ------------------------------------------------------------------------
+// Hardware deals block b to XCD (b mod 8).  Neighbouring row blocks share x[] lines, so give each
+// XCD one contiguous chunk of the logical block range (bijective for any nblocks).  Placement is a
+// speed matter only: any mapping is correct.
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nblocks) {
+  const int q = nblocks / kXcds;
+  const int rem = nblocks % kXcds;
+  const int xcd = b % kXcds;
+  const int idx = b / kXcds;
+  return xcd * q + (xcd < rem ? xcd : rem) + idx;
+}
+
+// y update with the documented semantics y = alpha*A*x + beta*y (api/spmv.h:14).  beta == 0 does
+// not read y (BLAS convention; for finite y it equals the reference's alpha*s + 0*y).
+__device__ __forceinline__ void store_y(double *y, int row, double alpha, double beta, double s) {
+  y[row] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[row];
+}
+
+} // namespace dev
+} // namespace spmv_acc

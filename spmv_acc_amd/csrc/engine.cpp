@@ -1,0 +1,505 @@
+// engine.cpp -- plan cache, strategy dispatch and the host form of the row-block preprocessing pass.
+//
+// Reference roles: src/acc/strategy_picker.cpp:19-65 (dispatch), hip-adaptive/adaptive.cpp:16-67
+// (adaptive decision), hip-flat/flat.cpp:30-57 (break-point staging), and
+// hip-csr-adaptive-plus/csr_adaptive_plus_spmv.cpp:16-72 (analysis staging / destroy).
+// The reference allocates (and for flat: leaks) its scratch on EVERY SpMV call and re-runs the
+// preprocessing each time; here scratch and preprocessing results live in a plan that is created the
+// first time a matrix (identified by its device pointers and shape) is seen, so the steady-state call
+// is launches only: no hipMalloc / hipMemcpy / synchronisation, hipGraph-capturable.
+#include "engine.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+
+namespace spmv_acc {
+
+// ---- errors ----------------------------------------------------------------------------------------------
+namespace {
+thread_local int g_err = kOk;
+thread_local std::string g_err_msg;
+hipStream_t g_stream = nullptr;
+std::mutex g_mu;
+
+bool hip_ok(hipError_t e, const char *what) {
+  if (e == hipSuccess) return true;
+  set_error(kErrHip, std::string(what) + ": " + hipGetErrorString(e));
+  return false;
+}
+} // namespace
+
+void set_error(int code, const std::string &what) {
+  g_err = code;
+  g_err_msg = what;
+}
+int last_error() { return g_err; }
+const char *last_error_string() { return g_err_msg.c_str(); }
+void clear_error() {
+  g_err = kOk;
+  g_err_msg.clear();
+}
+
+void set_stream(hipStream_t s) { g_stream = s; }
+hipStream_t get_stream() { return g_stream; }
+
+// ---- strategy names -----------------------------------------------------------------------------------------
+static const char *const kNames[kStrategyCount] = {"default",   "adaptive",     "thread_row", "wf_row",
+                                                   "block_row_ordinary", "light", "vector_row", "line_enhance",
+                                                   "line",      "flat",         "adaptive_plus"};
+
+const char *strategy_name(int s) { return (s >= 0 && s < kStrategyCount) ? kNames[s] : "unknown"; }
+
+int parse_strategy(const char *name) {
+  if (!name) return -1;
+  std::string s(name);
+  for (auto &c : s) c = static_cast<char>(::tolower(static_cast<unsigned char>(c)));
+  auto has = [&](const char *k) { return s.find(k) != std::string::npos; };
+  // same test order as src/configure.cmake:18-37 ("line_enhance" before "line"); adaptive_plus is ours
+  // and must be tested before "adaptive".
+  if (has("adaptive_plus") || has("adaptive-plus")) return kAdaptivePlus;
+  if (has("default")) return kDefault;
+  if (has("adaptive")) return kAdaptive;
+  if (has("thread_row")) return kThreadRow;
+  if (has("wf_row")) return kWfRow;
+  if (has("block_row_ordinary")) return kBlockRowOrdinary;
+  if (has("light")) return kLight;
+  if (has("vector_row")) return kVectorRow;
+  if (has("line_enhance")) return kLineEnhance;
+  if (has("line")) return kLine;
+  if (has("flat")) return kFlat;
+  return -1;
+}
+
+namespace {
+int build_time_strategy() {
+#if defined(KERNEL_STRATEGY_ADAPTIVE)
+  return kAdaptive;
+#elif defined(KERNEL_STRATEGY_THREAD_ROW)
+  return kThreadRow;
+#elif defined(KERNEL_STRATEGY_WAVEFRONT_ROW)
+  return kWfRow;
+#elif defined(KERNEL_STRATEGY_BLOCK_ROW_ORDINARY)
+  return kBlockRowOrdinary;
+#elif defined(KERNEL_STRATEGY_LIGHT)
+  return kLight;
+#elif defined(KERNEL_STRATEGY_VECTOR_ROW)
+  return kVectorRow;
+#elif defined(KERNEL_STRATEGY_LINE_ENHANCE)
+  return kLineEnhance;
+#elif defined(KERNEL_STRATEGY_LINE)
+  return kLine;
+#elif defined(KERNEL_STRATEGY_FLAT)
+  return kFlat;
+#elif defined(KERNEL_STRATEGY_DEFAULT)
+  return kDefault;
+#else
+  return kAdaptive; // config.cmake:15 ships KERNEL_STRATEGY "DEFAULT"; the headline config is adaptive
+#endif
+}
+int g_strategy = -1;
+} // namespace
+
+int active_strategy() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_strategy < 0) {
+    g_strategy = build_time_strategy();
+    if (const char *e = std::getenv("SPMV_ACC_KERNEL_STRATEGY")) {
+      const int s = parse_strategy(e);
+      if (s >= 0) g_strategy = s;
+    }
+  }
+  return g_strategy;
+}
+
+int set_active_strategy(int s) {
+  if (s < 0 || s >= kStrategyCount) {
+    set_error(kErrUnknownStrategy, "unknown strategy id");
+    return -1;
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_strategy = s;
+  return 0;
+}
+
+// ---- pickers --------------------------------------------------------------------------------------------------
+int adaptive_branch(int m, const RowptrSamples &s) {
+  const long long upper = s.half;           // nnz of rows [0, m/2)
+  const long long lower = static_cast<long long>(s.last) - s.half; // nnz of rows [m/2, m)
+  const long long big = upper > lower ? upper : lower;
+  const long long small = upper > lower ? lower : upper;
+  // "the two halves differ by 4x or more" (integer ratio as in adaptive.cpp:34-35; an empty half
+  // counts as an unbounded ratio instead of dividing by zero)
+  if (big != small && (small == 0 || big / small >= 4)) return 1;
+  if (s.last / m <= 4) return 2;
+  if (s.last <= 0xC00000) return 3;
+  if (s.last > (1 << 23)) return 4;
+  return 5;
+}
+
+namespace {
+// lanes per row by average row length: vector_row.cpp:15-27 / line_strategy.cpp:61-76
+int classic_vec(long long avg) {
+  if (avg <= 4) return 2;
+  if (avg <= 8) return 4;
+  if (avg <= 16) return 8;
+  if (avg <= 32) return 16;
+  if (avg <= 64) return 32;
+  return 64;
+}
+} // namespace
+
+int plus_pick_vec(int m, int nnz) {
+  const int avg = (m > 0) ? nnz / m : 0;
+  int v = 1;
+  while (v < 64 && avg > 2 * v) v <<= 1; // avg<=2 ->1, <=4 ->2, <=8 ->4, ... >64 ->64
+  return v;
+}
+
+// Host form of the row-block preprocessing pass.  Written as "where does the block that starts at
+// row s end" so the device form can later replace the scan by searches; the emitted tables are
+// bit-identical to the reference's single-pass loop (tests pin this against oracle/_ref).
+int plus_analyze_host(int m, int min_nnz, int threads_per_block, int vec_size, const int *rp,
+                      std::vector<int> &bp, std::vector<int> &fbr) {
+  const int row_cap = threads_per_block / vec_size;
+  const long long long_row = 2LL * min_nnz; // rows at least this long get dedicated blocks
+  bp.clear();
+  fbr.assign(static_cast<size_t>(m) + 1, 0);
+  bp.push_back(0);
+  int start = 0; // first row of the open block
+  while (start < m) {
+    // grow the open block one row at a time until it closes
+    int row = start;
+    long long acc = 0;
+    for (;; ++row) {
+      const long long len = static_cast<long long>(rp[row + 1]) - rp[row];
+      acc += len;
+      if (acc >= min_nnz) {
+        if (len >= long_row) {
+          const int slices = static_cast<int>(len / long_row);
+          const bool alone = (acc == len); // nothing but this row's non-zeros in the open block
+          for (int k = 0; k < slices; ++k) {
+            if (!(k == 0 && alone)) bp.push_back(row);
+            if (k == 0) fbr[row] = (static_cast<int>(bp.size()) - 1) * 2 + 1;
+          }
+        }
+        bp.push_back(row + 1);
+        break;
+      }
+      if (row - start + 1 >= row_cap || row == m - 1) {
+        bp.push_back(row + 1);
+        fbr[row + 1] = (static_cast<int>(bp.size()) - 1) * 2;
+        break;
+      }
+    }
+    start = row + 1;
+  }
+  return static_cast<int>(bp.size()) - 1;
+}
+
+// ---- plans ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Plan {
+  int device = 0;
+  CsrDev A;
+  bool have_samples = false;
+  RowptrSamples samples;
+  // flat
+  int flat_tiles = -1;
+  int *d_bp = nullptr;
+  double *d_head = nullptr;
+  double *d_tail = nullptr;
+  // row-block-plus
+  int plus_blocks = -1;
+  int plus_vec = 0;
+  int *d_pbp = nullptr;
+  int *d_pfbr = nullptr;
+  double *d_ppartial = nullptr;
+
+  void free_device() {
+    if (d_bp) (void)hipFree(d_bp);
+    if (d_head) (void)hipFree(d_head);
+    if (d_tail) (void)hipFree(d_tail);
+    if (d_pbp) (void)hipFree(d_pbp);
+    if (d_pfbr) (void)hipFree(d_pfbr);
+    if (d_ppartial) (void)hipFree(d_ppartial);
+    d_bp = nullptr;
+    d_head = d_tail = d_ppartial = nullptr;
+    d_pbp = d_pfbr = nullptr;
+  }
+};
+
+typedef std::tuple<int, const void *, const void *, const void *, int, int> PlanKey;
+std::map<PlanKey, Plan *> g_plans;
+constexpr size_t kMaxPlans = 256;
+
+// Is p readable by the host?  The reference's sparse_spmv hands the SAME device pointer in as "host"
+// rowptr (api/spmv_imp.cpp:14-17), which only works with host-visible device memory.
+bool host_readable(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  std::memset(&attr, 0, sizeof(attr));
+  const hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError(); // plain malloc'ed memory is not known to HIP: that is a host pointer
+    return true;
+  }
+  return attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeUnregistered ||
+         attr.type == hipMemoryTypeManaged;
+}
+
+// h if the host may dereference it, else null (checked only on the once-per-matrix paths)
+const int *host_view(const int *h) { return host_readable(h) ? h : nullptr; }
+
+bool fetch_samples(Plan &p, const int *h_rowptr) {
+  if (p.have_samples) return true;
+  h_rowptr = host_view(h_rowptr);
+  const int m = p.A.m;
+  const int idx[4] = {m / 4, m / 2, static_cast<int>(3LL * m / 4), m};
+  int out[4];
+  if (h_rowptr) {
+    for (int i = 0; i < 4; ++i) out[i] = h_rowptr[idx[i]];
+  } else {
+    for (int i = 0; i < 4; ++i) {
+      if (!hip_ok(hipMemcpy(&out[i], p.A.rp + idx[i], sizeof(int), hipMemcpyDeviceToHost), "read rowptr sample"))
+        return false;
+    }
+  }
+  p.samples.q1 = out[0];
+  p.samples.half = out[1];
+  p.samples.q3 = out[2];
+  p.samples.last = out[3];
+  p.have_samples = true;
+  return true;
+}
+
+Plan *get_plan(int m, int n, int nnz, const int *h_rowptr, const int *rp, const int *ci, const double *v) {
+  int dev = 0;
+  if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
+  const PlanKey key(dev, rp, ci, v, m, n);
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_plans.find(key);
+  if (it != g_plans.end()) {
+    if (nnz < 0 || nnz == it->second->A.nnz) return it->second;
+    // same buffers, different nnz: the caller rebuilt the matrix in place
+    it->second->free_device();
+    delete it->second;
+    g_plans.erase(it);
+  }
+  if (g_plans.size() >= kMaxPlans) {
+    for (auto &kv : g_plans) {
+      kv.second->free_device();
+      delete kv.second;
+    }
+    g_plans.clear();
+  }
+  if (nnz < 0) {
+    if ((h_rowptr = host_view(h_rowptr)) != nullptr) {
+      nnz = h_rowptr[m];
+    } else if (!hip_ok(hipMemcpy(&nnz, rp + m, sizeof(int), hipMemcpyDeviceToHost), "read rowptr[m]")) {
+      return nullptr;
+    }
+  }
+  if (nnz < 0 || nnz > INT_MAX - (1 << 16)) {
+    set_error(kErrTooLarge, "nnz does not leave room for tile arithmetic in int32; shard the matrix");
+    return nullptr;
+  }
+  Plan *p = new Plan();
+  p->device = dev;
+  p->A.m = m;
+  p->A.n = n;
+  p->A.nnz = nnz;
+  p->A.rp = rp;
+  p->A.ci = ci;
+  p->A.v = v;
+  p->A.aligned16 = (reinterpret_cast<uintptr_t>(ci) % 16 == 0) && (reinterpret_cast<uintptr_t>(v) % 16 == 0) &&
+                   nnz >= 8;
+  g_plans[key] = p;
+  return p;
+}
+
+bool ensure_flat(Plan &p, hipStream_t stream) {
+  if (p.flat_tiles >= 0) return true;
+  const int nnz = p.A.nnz;
+  const int tiles = nnz / kFlatStride + (nnz % kFlatStride ? 1 : 0);
+  const int bp_len = tiles + 1;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_bp), sizeof(int) * bp_len), "hipMalloc break points"))
+    return false;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_head), sizeof(double) * (tiles + 1)), "hipMalloc head carries"))
+    return false;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_tail), sizeof(double) * (tiles + 1)), "hipMalloc tail carries"))
+    return false;
+  launch_break_points(stream, p.A.rp, p.A.m, nnz, kFlatStride, p.d_bp, bp_len);
+  p.flat_tiles = tiles;
+  return true;
+}
+
+bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
+  if (p.plus_blocks >= 0) return true;
+  const int m = p.A.m;
+  std::vector<int> staged;
+  const int *hrp = host_view(h_rowptr);
+  if (!hrp) {
+    staged.resize(static_cast<size_t>(m) + 1);
+    if (!hip_ok(hipMemcpy(staged.data(), p.A.rp, sizeof(int) * (static_cast<size_t>(m) + 1), hipMemcpyDeviceToHost),
+                "stage rowptr for analysis"))
+      return false;
+    hrp = staged.data();
+  }
+  const int vec = plus_pick_vec(m, p.A.nnz);
+  std::vector<int> bp, fbr;
+  const int blocks = plus_analyze_host(m, kPlusMinNnz, kPlusThreads, vec, hrp, bp, fbr);
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pbp), sizeof(int) * bp.size()), "hipMalloc plus bp")) return false;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pfbr), sizeof(int) * fbr.size()), "hipMalloc plus fbr"))
+    return false;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_ppartial), sizeof(double) * (blocks + 1)), "hipMalloc plus partial"))
+    return false;
+  // blocking copies: the host vectors die at scope exit (this runs once per matrix)
+  if (!hip_ok(hipMemcpy(p.d_pbp, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice), "copy plus bp")) return false;
+  if (!hip_ok(hipMemcpy(p.d_pfbr, fbr.data(), sizeof(int) * fbr.size(), hipMemcpyHostToDevice), "copy plus fbr"))
+    return false;
+  (void)stream;
+  p.plus_vec = vec;
+  p.plus_blocks = blocks;
+  return true;
+}
+
+void run_rowblock(hipStream_t st, const Plan &p, double alpha, double beta, const double *x, double *y) {
+  launch_rowblock_stream(st, p.A, pick_vec_width(p.A.m, p.A.nnz), /*xcd_remap=*/true, alpha, beta, x, y);
+}
+
+bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *x, double *y) {
+  if (!ensure_flat(p, st)) return false;
+  launch_flat(st, p.A, p.d_bp, p.flat_tiles, p.d_head, p.d_tail, alpha, beta, x, y);
+  launch_flat_fixup(st, p.A, p.d_bp, p.flat_tiles, p.d_head, p.d_tail, alpha, beta, y);
+  return true;
+}
+
+} // namespace
+
+void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
+              const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx, double *dy) {
+  if (trans != 0) {
+    // the reference never reads `trans` (only operation_none is supported, api/spmv.h:13); it computes
+    // the non-transposed product.  Same here, but the mismatch is reported out of band.
+    set_error(kErrUnsupportedTrans, "only operation_none is supported; computed y = alpha*A*x + beta*y");
+  }
+  if (m <= 0) return;
+  if (!d_rowptr || !dy || (n > 0 && !dx)) {
+    set_error(kErrBadArgument, "null rowptr / x / y");
+    return;
+  }
+  if (strategy < 0 || strategy >= kStrategyCount) {
+    set_error(kErrUnknownStrategy, "unknown strategy id");
+    return;
+  }
+  Plan *p = get_plan(m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value);
+  if (!p) return;
+  hipStream_t st = g_stream;
+
+  if (p->A.nnz == 0) {
+    launch_scale_y(st, m, beta, dy);
+    return;
+  }
+  if (!d_colindex || !d_value) {
+    set_error(kErrBadArgument, "null colindex / value with nnz > 0");
+    return;
+  }
+
+  const long long avg = static_cast<long long>(p->A.nnz) / m;
+  switch (strategy) {
+  case kDefault:
+  case kLight:
+    launch_vector_row(st, p->A, m, pick_vec_width(m, p->A.nnz), 1, alpha, beta, dx, dy);
+    break;
+  case kVectorRow:
+    launch_vector_row(st, p->A, m, classic_vec(avg), 1, alpha, beta, dx, dy);
+    break;
+  case kWfRow:
+  case kBlockRowOrdinary:
+    launch_vector_row(st, p->A, m, 64, 1, alpha, beta, dx, dy);
+    break;
+  case kThreadRow:
+    launch_rowblock_stream(st, p->A, 1, true, alpha, beta, dx, dy);
+    break;
+  case kLineEnhance:
+  case kLine:
+    run_rowblock(st, *p, alpha, beta, dx, dy);
+    break;
+  case kFlat:
+    run_flat(st, *p, alpha, beta, dx, dy);
+    break;
+  case kAdaptive: {
+    if (!fetch_samples(*p, h_rowptr)) return;
+    switch (adaptive_branch(m, p->samples)) {
+    case 1: {
+      const int half_rows = m / 2;
+      const long long a0 = half_rows > 0 ? p->samples.half / half_rows : 0;
+      const long long a1 = (static_cast<long long>(p->samples.last) - p->samples.half) / (m - half_rows);
+      launch_vector_row(st, p->A, half_rows, classic_vec(a0), classic_vec(a1), alpha, beta, dx, dy);
+      break;
+    }
+    case 4:
+      run_flat(st, *p, alpha, beta, dx, dy);
+      break;
+    default: // 2 (adaptive line), 3 (adaptive line-enhance), 5 (line-enhance): one row-block kernel family
+      run_rowblock(st, *p, alpha, beta, dx, dy);
+      break;
+    }
+    break;
+  }
+  case kAdaptivePlus:
+    if (!ensure_plus(*p, h_rowptr, st)) return;
+    launch_plus(st, p->A, p->d_pbp, p->d_pfbr, p->plus_blocks, p->plus_vec, p->d_ppartial, alpha, beta, dx, dy);
+    launch_plus_fixup(st, p->A, p->d_pbp, p->d_pfbr, p->plus_blocks, p->d_ppartial, alpha, beta, dy);
+    break;
+  default:
+    set_error(kErrUnknownStrategy, "unknown strategy id");
+    break;
+  }
+}
+
+void release_plans(const int *d_rowptr) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto it = g_plans.begin(); it != g_plans.end();) {
+    if (!d_rowptr || std::get<1>(it->first) == d_rowptr) {
+      it->second->free_device();
+      delete it->second;
+      it = g_plans.erase(it);
+    } else {
+      ++it;
+    }
+  }
+}
+
+bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto &kv : g_plans) {
+    if (std::get<1>(kv.first) == d_rowptr && std::get<4>(kv.first) == m) {
+      const Plan &p = *kv.second;
+      out->nnz = p.A.nnz;
+      out->adaptive_branch = p.have_samples ? adaptive_branch(m, p.samples) : 0;
+      out->vec = pick_vec_width(m, p.A.nnz);
+      out->flat_tiles = p.flat_tiles;
+      out->plus_blocks = p.plus_blocks;
+      out->aligned16 = p.A.aligned16 ? 1 : 0;
+      return true;
+    }
+  }
+  return false;
+}
+
+int cached_plan_count() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return static_cast<int>(g_plans.size());
+}
+
+} // namespace spmv_acc

@@ -1,0 +1,103 @@
+// engine.hpp -- host-side engine behind both API surfaces (the C ABI of include/spmv_acc.h and the
+// C++ mirror of the reference's src/acc/api + per-strategy wrappers).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace spmv_acc {
+
+// The reference's KERNEL_STRATEGY names (src/configure.cmake:17-40) + the benchmark-only
+// csr-adaptive-plus entry (benchmark_spmv_acc.hpp:186-200).
+enum Strategy {
+  kDefault = 0,
+  kAdaptive = 1,
+  kThreadRow = 2,
+  kWfRow = 3,
+  kBlockRowOrdinary = 4,
+  kLight = 5,
+  kVectorRow = 6,
+  kLineEnhance = 7,
+  kLine = 8,
+  kFlat = 9,
+  kAdaptivePlus = 10,
+  kStrategyCount = 11
+};
+
+// error codes reported out-of-band (the reference API returns void and checks nothing)
+enum Error {
+  kOk = 0,
+  kErrUnsupportedTrans = 1,
+  kErrBadArgument = 2,
+  kErrHip = 3,
+  kErrTooLarge = 4,
+  kErrUnknownStrategy = 5,
+  kErrNoDevice = 6
+};
+
+const char *strategy_name(int s);
+// Case-insensitive substring match in the reference's order (configure.cmake:18-37 uses regex
+// MATCHES, so "line_enhance" is tested before "line"); returns -1 if nothing matches.
+int parse_strategy(const char *name);
+
+void set_error(int code, const std::string &what);
+int last_error();
+const char *last_error_string();
+void clear_error();
+
+void set_stream(hipStream_t s);
+hipStream_t get_stream();
+
+// process-wide strategy: build-time KERNEL_STRATEGY_* macro, overridden by the environment variable
+// SPMV_ACC_KERNEL_STRATEGY at first use, overridden by set_active_strategy().
+int active_strategy();
+int set_active_strategy(int s);
+
+// Host samples of rowptr that the reference's pickers read from h_csr_desc (adaptive.cpp:24-27,
+// flat.cpp:51-52).
+struct RowptrSamples {
+  int q1 = 0;   // rowptr[m/4]
+  int half = 0; // rowptr[m/2]
+  int q3 = 0;   // rowptr[3m/4]
+  int last = 0; // rowptr[m] = nnz
+};
+
+// Which branch adaptive_sparse_spmv takes (adaptive.cpp:30-66): 1 vector-row split, 2 adaptive line,
+// 3 adaptive line-enhance, 4 adaptive flat, 5 line-enhance.
+int adaptive_branch(int m, const RowptrSamples &s);
+
+// ---- host form of the row-block preprocessing pass ----------------------------------------------------
+// Bit-identical to csr_adaptive_plus_analyze_imp (csr_adaptive_plus_analyze.cpp:13-98).
+// break_points gets blocks+1 entries, first_block_of_row m+1 entries.  Returns the block count.
+int plus_analyze_host(int m, int min_nnz_per_block, int threads_per_block, int vec_size, const int *host_row_ptr,
+                      std::vector<int> &break_points, std::vector<int> &first_block_of_row);
+int plus_pick_vec(int m, int nnz); // csr_adaptive_plus_spmv.cpp:139-165
+
+// ---- execution ------------------------------------------------------------------------------------------
+// One SpMV y = alpha*A*x + beta*y with the given strategy.  h_rowptr may be null: the four samples
+// and (for adaptive-plus) the whole rowptr are then fetched from the device once and cached in the
+// plan.  nnz < 0 means "unknown": it is read from d_rowptr[m] once.
+void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
+              const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx, double *dy);
+
+// Drop cached plans (all, or those keyed on this rowptr).  Call when a matrix' structure changes in
+// place or its buffers are freed.
+void release_plans(const int *d_rowptr);
+
+// Introspection for tests / benchmarks.
+struct PlanInfo {
+  int nnz = 0;
+  int adaptive_branch = 0;
+  int vec = 0;
+  int flat_tiles = 0;
+  int plus_blocks = 0;
+  int aligned16 = 0;
+};
+bool query_plan(const int *d_rowptr, int m, PlanInfo *out);
+int cached_plan_count();
+
+} // namespace spmv_acc

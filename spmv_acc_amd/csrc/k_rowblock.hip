@@ -1,0 +1,103 @@
+// k_rowblock.hip -- LINE_ENHANCE family: fixed row blocks, non-zeros streamed through LDS in rounds.
+//
+// Reference roles (all reached from KERNEL_STRATEGY=LINE_ENHANCE / LINE / ADAPTIVE):
+//   * hip-line-enhance/line_enhance_spmv_imp.inl:12-95 (line_enhance_kernel) with the parameter
+//     picks of line_enhance_spmv.cpp:8-69 (line_enhance_sparse_spmv, adaptive_enhance_sparse_spmv)
+//   * hip-line/line_adaptive_one_pass.inl:42-115 (spmv_adaptive_line_kernel) -- the short-row case
+//     is the VEC=1 instance of the same structure.
+// What is kept: a workgroup owns consecutive rows, their non-zeros are multiplied into an LDS tile
+// cooperatively (coalesced, independent of row boundaries), each row's VEC lanes then add the part
+// of the row that lies in the tile, and partial sums live in registers across rounds.
+// What is different (MI355X-first):
+//   * y = alpha*s + beta*y for any beta (the reference stores alpha*s + y, i.e. beta = 1 only)
+//   * rows per workgroup = THREADS/VEC so every lane has a row to reduce (the reference leaves
+//     3/4 of the lanes idle in the reduce phase for RPB=32, VEC=4, THREADS=512)
+//   * 16-B non-temporal loads of colindex/value, 4 non-zeros per lane per step, tile start aligned
+//     down to a multiple of 4 so the wide loads stay aligned for any row-block start
+//   * optional XCD-contiguous block order: neighbouring row blocks (which share x[] lines for
+//     banded / FEM matrices) run on the same XCD and hit in its 4 MB L2
+#include "device_utils.hpp"
+#include "kernels.hpp"
+#include "tile_stage.hpp"
+
+namespace spmv_acc {
+namespace {
+
+using namespace dev;
+
+template <int VEC, bool ALIGNED>
+__global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nnz, int nblocks, int xcd_remap,
+                                                                   double alpha, double beta,
+                                                                   const int *__restrict__ rp,
+                                                                   const int *__restrict__ ci,
+                                                                   const double *__restrict__ v,
+                                                                   const double *__restrict__ x,
+                                                                   double *__restrict__ y) {
+  constexpr int RPB = kThreads / VEC;
+  __shared__ double lds[kTile];
+
+  int b = blockIdx.x;
+  if (xcd_remap) b = xcd_contiguous_block(b, nblocks);
+
+  const long long base_ll = static_cast<long long>(b) * RPB;
+  const int row_base = static_cast<int>(base_ll);
+  const int row_end = (base_ll + RPB < m) ? row_base + RPB : m;
+  // wave-uniform: the non-zero range of the whole block
+  const int s0 = rp[row_base];
+  const int s1 = rp[row_end];
+
+  const int lane = threadIdx.x % VEC;
+  const int row = row_base + threadIdx.x / VEC;
+  const bool live = row < row_end;
+  int r0 = 0, r1 = 0;
+  if (live) {
+    r0 = rp[row];
+    r1 = rp[row + 1];
+  }
+
+  double acc = 0.0;
+  // tile origin aligned down so 16-B loads stay aligned; the (at most 3) extra leading products are never read
+  for (int off = s0 & ~3; off < s1; off += kTile) {
+    stage_products<kThreads, kNnzPerThread, ALIGNED>(lds, off, s1, nnz, ci, v, x);
+    __syncthreads();
+    const int lo = (r0 > off ? r0 : off) - off;
+    const int hi = (r1 < off + kTile ? r1 : off + kTile) - off;
+    for (int j = lo + lane; j < hi; j += VEC) acc += lds[j];
+    if (off + kTile < s1) __syncthreads(); // next round overwrites the tile
+  }
+  acc = group_sum<VEC>(acc);
+  if (live && lane == 0) store_y(y, row, alpha, beta, acc);
+}
+
+template <int VEC>
+void launch_vec(hipStream_t stream, const CsrDev &A, bool xcd, double alpha, double beta, const double *x,
+                double *y) {
+  constexpr int RPB = kThreads / VEC;
+  const int nblocks = static_cast<int>((static_cast<long long>(A.m) + RPB - 1) / RPB);
+  if (nblocks == 0) return;
+  const int remap = (xcd && nblocks >= 64) ? 1 : 0;
+  if (A.aligned16) {
+    hipLaunchKernelGGL((rowblock_stream_kernel<VEC, true>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,
+                       nblocks, remap, alpha, beta, A.rp, A.ci, A.v, x, y);
+  } else {
+    hipLaunchKernelGGL((rowblock_stream_kernel<VEC, false>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,
+                       nblocks, remap, alpha, beta, A.rp, A.ci, A.v, x, y);
+  }
+}
+
+} // namespace
+
+void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, bool xcd_remap, double alpha, double beta,
+                            const double *x, double *y) {
+  switch (vec) {
+  case 1: launch_vec<1>(stream, A, xcd_remap, alpha, beta, x, y); break;
+  case 2: launch_vec<2>(stream, A, xcd_remap, alpha, beta, x, y); break;
+  case 4: launch_vec<4>(stream, A, xcd_remap, alpha, beta, x, y); break;
+  case 8: launch_vec<8>(stream, A, xcd_remap, alpha, beta, x, y); break;
+  case 16: launch_vec<16>(stream, A, xcd_remap, alpha, beta, x, y); break;
+  case 32: launch_vec<32>(stream, A, xcd_remap, alpha, beta, x, y); break;
+  default: launch_vec<64>(stream, A, xcd_remap, alpha, beta, x, y); break;
+  }
+}
+
+} // namespace spmv_acc

@@ -1,0 +1,64 @@
+// kernels.hpp -- host-side launchers of the gfx950 kernels (definitions in k_*.hip).
+// Launchers only enqueue work on `stream`; they never allocate, copy or synchronise, so a caller
+// may capture them into a hipGraph.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+namespace spmv_acc {
+
+// Device-side CSR view (all pointers are device pointers; int32 indices, fp64 values).
+struct CsrDev {
+  int m = 0;
+  int n = 0;
+  int nnz = 0;
+  const int *rp = nullptr;
+  const int *ci = nullptr;
+  const double *v = nullptr;
+  bool aligned16 = false; // ci and v are 16-byte aligned and nnz >= 8: wide-load kernels allowed
+};
+
+// ---- tile geometry (fixed at build time) -----------------------------------------------------------
+constexpr int kThreads = 256;             // 4 waves per workgroup
+constexpr int kNnzPerThread = 8;          // two 4-wide steps per lane per round
+constexpr int kTile = kThreads * kNnzPerThread; // 2048 products = 16 KB of LDS per workgroup
+constexpr int kFlatStride = kTile;        // nnz per flat block (the reference uses R*THREADS = 1024)
+constexpr int kPlusThreads = 512;         // row-block-plus geometry mirrors the reference's analysis
+constexpr int kPlusR = 2;                 // (csr_adaptive_plus_spmv.cpp:135-138): THREADS 512, R 2,
+constexpr int kPlusMinNnz = 2 * kPlusR * kPlusThreads; // MIN_NNZ_PER_BLOCK 2048
+constexpr int kPlusLongChunk = 2 * kPlusMinNnz;        // NN_EI * MIN_NNZ_PER_BLOCK non-zeros per long-row block
+
+// Smallest power of two >= avg/8, clamped to [1, 64]: lanes cooperating on one row.
+int pick_vec_width(int m, int nnz);
+
+// default / vector-row family: `w` lanes per row straight from global memory.
+// Rows [0, row_split) use width w0, rows [row_split, m) use width w1 (row_split = m: one width).
+void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w0, int w1, double alpha, double beta,
+                       const double *x, double *y);
+
+// line-enhance family: THREADS/vec consecutive rows per workgroup, non-zeros streamed through an
+// LDS tile in rounds.  vec in {1,2,4,8,16,32,64}.
+void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, bool xcd_remap, double alpha, double beta,
+                            const double *x, double *y);
+
+// row-block preprocessing pass, device form: break points with the reference's exact semantics
+// (hip-flat/flat_imp.inl:108-131) computed by one binary search per entry; no memset needed.
+void launch_break_points(hipStream_t stream, const int *rp, int m, int nnz, int stride, int *bp, int bp_len);
+
+// flat family: one workgroup per kFlatStride non-zeros; complete rows are stored directly, the two
+// possible partial rows per tile go to head/tail carries that launch_flat_fixup folds into y.
+void launch_flat(hipStream_t stream, const CsrDev &A, const int *bp, int ntiles, double *head, double *tail,
+                 double alpha, double beta, const double *x, double *y);
+void launch_flat_fixup(hipStream_t stream, const CsrDev &A, const int *bp, int ntiles, const double *head,
+                       const double *tail, double alpha, double beta, double *y);
+
+// row-block-plus family: row blocks from the adaptive-plus analysis (break_points + first_block_of_row).
+void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, int vec,
+                 double *partial, double alpha, double beta, const double *x, double *y);
+void launch_plus_fixup(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks,
+                       const double *partial, double alpha, double beta, double *y);
+
+// y[i] = beta * y[i] (used for m > 0, nnz == 0 and as a building block)
+void launch_scale_y(hipStream_t stream, int m, double beta, double *y);
+
+} // namespace spmv_acc

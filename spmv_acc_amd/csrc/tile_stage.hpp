@@ -1,0 +1,98 @@
+// tile_stage.hpp -- cooperative "multiply into LDS" step shared by the row-block, nnz-tile and
+// row-block-plus kernels.
+//
+// Role in the reference: the `shared_val[i] = csr_val[idx] * x[csr_col_ind[idx]]` loops of
+// hip-flat/flat_imp_one_pass.hpp:35-39, hip-line-enhance/line_enhance_spmv_imp.inl:55-62 and
+// hip-csr-adaptive-plus/csr_adaptive_plus_spmv_imp.inl:152-160 (one 4- or 8-byte load per lane).
+// Here a lane owns 4 consecutive non-zeros per step: one 16-B colindex load, two 16-B value loads
+// (all non-temporal), four x[] gathers, one 32-B LDS store.  Loads of all steps are issued before
+// the first gather so every lane keeps NPT/4 * 48 B of stream plus NPT gathers in flight.
+#pragma once
+
+#include "device_utils.hpp"
+
+namespace spmv_acc {
+namespace dev {
+
+// Stage products of non-zeros [a0, a0 + THREADS*NPT) that lie below `hi` into lds[0 .. THREADS*NPT).
+//   a0  : first non-zero of the tile, multiple of 4 (so 16-B loads are aligned when ALIGNED)
+//   hi  : exclusive bound of the non-zeros this block needs (hi <= nnz); groups at or above it are skipped
+//   nnz : total non-zeros (array length) -- only the last, ragged group of the arrays takes the scalar path
+// Slots of lds whose non-zero index is < a-block's-first-nnz or >= hi hold unspecified values; no
+// reader touches them.
+template <int THREADS, int NPT, bool ALIGNED>
+__device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0, int hi, int nnz,
+                                               const int *__restrict__ ci, const double *__restrict__ v,
+                                               const double *__restrict__ x) {
+  static_assert(NPT % 4 == 0, "NPT must be a multiple of 4");
+  constexpr int K = NPT / 4;
+  if (ALIGNED) {
+    int4v c[K];
+    double2v va[K], vb[K];
+    bool full[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int j = a0 + 4 * (threadIdx.x + k * THREADS);
+      full[k] = (j < hi) && (j + 4 <= nnz);
+      if (full[k]) {
+        c[k] = load_stream_i4(ci + j);
+        va[k] = load_stream_d2(v + j);
+        vb[k] = load_stream_d2(v + j + 2);
+      }
+    }
+    double xg[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (full[k]) {
+        xg[k][0] = x[c[k].x];
+        xg[k][1] = x[c[k].y];
+        xg[k][2] = x[c[k].z];
+        xg[k][3] = x[c[k].w];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int g = threadIdx.x + k * THREADS;
+      if (full[k]) {
+        double2v p0, p1;
+        p0.x = va[k].x * xg[k][0];
+        p0.y = va[k].y * xg[k][1];
+        p1.x = vb[k].x * xg[k][2];
+        p1.y = vb[k].y * xg[k][3];
+        double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
+        dst[0] = p0;
+        dst[1] = p1;
+      } else {
+        // ragged end of the arrays (at most one group in the whole grid)
+        const int j = a0 + 4 * g;
+        if (j < hi) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (j + e < nnz) lds[4 * g + e] = v[j + e] * x[ci[j + e]];
+          }
+        }
+      }
+    }
+  } else {
+    // unaligned base pointers (e.g. a sub-array view): element-per-lane loads, still phase-separated
+    constexpr int E = NPT;
+    int cc[E];
+    double vv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = a0 + threadIdx.x + e * THREADS;
+      if (j < hi) {
+        cc[e] = load_stream(ci + j);
+        vv[e] = load_stream(v + j);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = a0 + threadIdx.x + e * THREADS;
+      if (j < hi) lds[threadIdx.x + e * THREADS] = vv[e] * x[cc[e]];
+    }
+  }
+}
+
+} // namespace dev
+} // namespace spmv_acc

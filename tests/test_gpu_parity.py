@@ -1,0 +1,354 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes -- through
+size-independent properties.
+
+Tolerances (fp64, north_star: 1e-9 relative vs the reference CPU verification path):
+  * scaled error  |d-h| / (|alpha| sum_j |a_ij x_j| + |beta y0_i|)  <= 1e-12   (robust form)
+  * plain relative error |d-h|/|h| <= 1e-9 on rows with |h| >= 1e-6 * scale (no cancellation)
+  * the reference's own verdicts (cli/verification.cpp:43-54 and :15-38, rel 1e-7) must pass
+  * integer preprocessing (break points, row blocks): bit-exact
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import spmv_acc_amd
+from spmv_acc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+SCALED_TOL = 1e-12
+REL_TOL = 1e-9
+ALL = spmv_acc_amd.STRATEGIES
+
+
+@pytest.fixture(scope="module")
+def torch_dev(hiplib):
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run(torch, strat, alpha, beta, rowptr, cols, vals, x, y0, pass_host_rowptr=True):
+    m, n, nnz = rowptr.size - 1, x.size, int(rowptr[-1])
+    drp, dci, dv, dx, dy = dev(torch, rowptr), dev(torch, cols), dev(torch, vals), dev(torch, x), dev(torch, y0)
+    spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat,
+                          h_rowptr=rowptr if pass_host_rowptr else None)
+    torch.cuda.synchronize()
+    out = dy.cpu().numpy()
+    spmv_acc_amd.release_plans(drp)
+    return out
+
+
+def check(oracle, got, alpha, beta, rowptr, cols, vals, x, y0, tag):
+    ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+    err = oracle.scaled_error(got, ref, alpha, beta, rowptr, cols, vals, x, y0)
+    assert err <= SCALED_TOL, (tag, "scaled error", err)
+    import scipy.sparse as sp
+
+    m = rowptr.size - 1
+    scale = abs(alpha) * (sp.csr_matrix((np.abs(vals), cols, rowptr), shape=(m, x.size)) @ np.abs(x)) + np.abs(beta * y0)
+    solid = np.abs(ref) >= 1e-6 * np.maximum(scale, 1e-300)
+    if np.any(solid):
+        rel = np.max(np.abs(got[solid] - ref[solid]) / np.abs(ref[solid]))
+        assert rel <= REL_TOL, (tag, "relative error", rel)
+    me, first, cnt = oracle.verify_y(got, ref)
+    assert cnt == 0, (tag, "reference benchmark verdict", first, cnt, me)
+
+
+KINDS = [("uniform", 3000, 3100, 5), ("short", 5000, 5000, 2), ("powerlaw", 2500, 4000, 6),
+         ("spikes", 1500, 9000, 3), ("empty_rows", 4000, 2500, 4), ("dense_rows", 40, 5000, 400),
+         ("single", 2049, 2049, 1), ("uniform", 700, 700, 33), ("uniform", 300, 900, 100)]
+
+
+@pytest.mark.parametrize("strat", ALL)
+def test_parity_all_strategies(torch_dev, oracle, strat):
+    torch = torch_dev
+    for i, (kind, m, n, avg) in enumerate(KINDS):
+        rowptr, cols, vals = synth.random_csr(m, n, avg, seed=100 + i, kind=kind)
+        rng = np.random.default_rng(200 + i)
+        x, y0 = synth.reference_rand_grid(n, rng), synth.reference_rand_grid(m, rng)
+        for alpha, beta in ((1.0, 1.0), (0.5, -2.0), (1.0, 0.0)):
+            got = run(torch, strat, alpha, beta, rowptr, cols, vals, x, y0)
+            check(oracle, got, alpha, beta, rowptr, cols, vals, x, y0, (strat, kind, m, alpha, beta))
+
+
+@pytest.mark.parametrize("strat", spmv_acc_amd.HOT_STRATEGIES)
+def test_golden_fixtures(torch_dev, oracle, strat):
+    torch = torch_dev
+    g = np.load(os.path.join(GOLD, "spmv_cases.npz"))
+    for name in g["names"]:
+        rowptr, cols, vals = g[f"{name}__rowptr"], g[f"{name}__cols"], g[f"{name}__vals"]
+        x, y0 = g[f"{name}__x"], g[f"{name}__y0"]
+        for k, (a, b) in enumerate(g["alpha_beta"]):
+            got = run(torch, strat, float(a), float(b), rowptr, cols, vals, x, y0)
+            want = g[f"{name}__out{k}"]
+            err = oracle.scaled_error(got, want, float(a), float(b), rowptr, cols, vals, x, y0)
+            assert err <= SCALED_TOL, (strat, name, a, b, err)
+
+
+def test_rajat03_like_cli_protocol(torch_dev, oracle):
+    """configs[0]'s protocol on the GPU path: alpha = beta = 1, 10 warm-ups with y reset, verify -> pass 7602."""
+    torch = torch_dev
+    rowptr, cols, vals = synth.rajat03_like()
+    m = n = rowptr.size - 1
+    rng = np.random.default_rng(1)
+    x, y0 = synth.reference_rand_grid(n, rng), synth.reference_rand_grid(m, rng)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    dy = dy0.clone()
+    for _ in range(11):
+        dy.copy_(dy0)
+        spmv_acc_amd.sparse_spmv(0, 1.0, 1.0, m, n, drp, dci, dv, dx, dy)  # ten-argument entry, device pointers only
+    torch.cuda.synchronize()
+    ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+    assert oracle.verify(dy.cpu().numpy(), ref) == -1  # "pass 7602 validation"
+    info = spmv_acc_amd.query_plan(drp, m)
+    assert info is not None and info["nnz"] == int(rowptr[-1])
+    spmv_acc_amd.release_plans(drp)
+
+
+@pytest.mark.parametrize("strat", spmv_acc_amd.HOT_STRATEGIES)
+def test_edge_shapes(torch_dev, oracle, strat):
+    torch = torch_dev
+    rng = np.random.default_rng(42)
+    cases = []
+    # one row, one nnz; one long row; nnz not a multiple of 4; all rows empty; trailing/leading empties
+    cases.append((np.array([0, 1], np.int32), np.array([0], np.int32), np.array([2.5]), 1))
+    cases.append((np.array([0, 5001], np.int32), rng.integers(0, 64, 5001).astype(np.int32), rng.standard_normal(5001), 64))
+    cases.append((np.array([0, 3, 3, 7], np.int32), np.array([0, 1, 2, 0, 1, 2, 3], np.int32), rng.standard_normal(7), 4))
+    cases.append((np.zeros(100, np.int32), np.zeros(0, np.int32), np.zeros(0), 5))
+    lens = np.zeros(9000, np.int64)
+    lens[4000:4100] = 41
+    rp = np.zeros(9001, np.int32)
+    np.cumsum(lens, out=rp[1:])
+    cases.append((rp, rng.integers(0, 300, int(rp[-1])).astype(np.int32), rng.standard_normal(int(rp[-1])), 300))
+    # rows ending exactly on tile boundaries (2048 | 1024 | 4096)
+    lens = np.full(40, 1024, np.int64)
+    rp = np.zeros(41, np.int32)
+    np.cumsum(lens, out=rp[1:])
+    cases.append((rp, rng.integers(0, 500, int(rp[-1])).astype(np.int32), rng.standard_normal(int(rp[-1])), 500))
+    # a long row preceded by empty rows inside one analysis block (the reference loses its first slice)
+    lens = np.zeros(1500, np.int64)
+    lens[700], lens[701], lens[1400:] = 9000, 4096, 5
+    rp = np.zeros(1501, np.int32)
+    np.cumsum(lens, out=rp[1:])
+    cases.append((rp, rng.integers(0, 2000, int(rp[-1])).astype(np.int32), rng.standard_normal(int(rp[-1])), 2000))
+    for ci_, (rowptr, cols, vals, n) in enumerate(cases):
+        m = rowptr.size - 1
+        x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+        for alpha, beta in ((1.0, 1.0), (-0.75, 0.0), (2.0, 0.5)):
+            got = run(torch, strat, alpha, beta, rowptr, cols, vals, x, y0)
+            check(oracle, got, alpha, beta, rowptr, cols, vals, x, y0, (strat, "edge", ci_, alpha, beta))
+
+
+@pytest.mark.parametrize("strat", spmv_acc_amd.HOT_STRATEGIES)
+def test_unaligned_views_and_device_only_rowptr(torch_dev, oracle, strat):
+    """Sub-array views whose base is not 16-byte aligned take the element-wise load path; a NULL host
+    rowptr makes the engine fetch its samples / rowptr from the device."""
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(3000, 3000, 9, seed=77, kind="uniform")
+    m, n, nnz = 3000, 3000, int(rowptr[-1])
+    rng = np.random.default_rng(5)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    pad_c = torch.zeros(nnz + 1, dtype=torch.int32, device="cuda")
+    pad_v = torch.zeros(nnz + 1, dtype=torch.float64, device="cuda")
+    pad_c[1:] = dev(torch, cols)
+    pad_v[1:] = dev(torch, vals)
+    dci, dv = pad_c[1:], pad_v[1:]
+    assert dci.data_ptr() % 16 != 0
+    drp, dx, dy = dev(torch, rowptr), dev(torch, x), dev(torch, y0)
+    spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, -1, drp, dci, dv, dx, dy, strategy=strat, h_rowptr=None)
+    torch.cuda.synchronize()
+    info = spmv_acc_amd.query_plan(drp, m)
+    assert info["aligned16"] == 0 and info["nnz"] == nnz
+    check(oracle, dy.cpu().numpy(), 1.0, 1.0, rowptr, cols, vals, x, y0, (strat, "unaligned"))
+    spmv_acc_amd.release_plans(drp)
+
+
+def test_bitwise_reproducible(torch_dev):
+    """No atomics anywhere: two runs give identical bits for every strategy."""
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(20000, 20000, 12, seed=9, kind="powerlaw")
+    rng = np.random.default_rng(3)
+    x, y0 = rng.standard_normal(20000), rng.standard_normal(20000)
+    for strat in ALL:
+        a = run(torch, strat, 1.0, 1.0, rowptr, cols, vals, x, y0)
+        b = run(torch, strat, 1.0, 1.0, rowptr, cols, vals, x, y0)
+        assert np.array_equal(a, b), strat
+
+
+def test_trans_is_reported_not_applied(torch_dev, oracle, hiplib):
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(500, 500, 5, seed=1)
+    rng = np.random.default_rng(1)
+    x, y0 = rng.standard_normal(500), rng.standard_normal(500)
+    drp, dci, dv, dx, dy = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    hiplib.spmv_acc_clear_error()
+    spmv_acc_amd.sparse_spmv(1, 1.0, 1.0, 500, 500, drp, dci, dv, dx, dy)  # operation_transpose: unsupported
+    torch.cuda.synchronize()
+    assert hiplib.spmv_acc_last_error() == 1
+    hiplib.spmv_acc_clear_error()
+    # like the reference (which never reads trans) the non-transposed product is computed
+    check(oracle, dy.cpu().numpy(), 1.0, 1.0, rowptr, cols, vals, x, y0, "trans")
+    spmv_acc_amd.release_plans(drp)
+
+
+# ---- row-block preprocessing pass ------------------------------------------------------------------------
+def test_break_points_bit_exact(torch_dev, oracle):
+    torch = torch_dev
+    g = np.load(os.path.join(GOLD, "breakpoint_cases.npz"))
+    cases = [(str(nm), g[f"{nm}__rowptr"]) for nm in g["names"]]
+    for i, kind in enumerate(("uniform", "powerlaw", "spikes", "empty_rows", "dense_rows")):
+        rp, _, _ = synth.random_csr(20000, 20000, 7, seed=300 + i, kind=kind)
+        cases.append((kind, rp))
+    for name, rp in cases:
+        m, nnz = rp.size - 1, int(rp[-1])
+        drp = dev(torch, rp)
+        for stride in (256, 1024, 2048):
+            n = spmv_acc_amd.break_points_len(nnz, stride)
+            out = torch.full((n,), -7, dtype=torch.int32, device="cuda")  # no pre-zeroing needed
+            spmv_acc_amd.break_points(drp, m, nnz, stride, out)
+            torch.cuda.synchronize()
+            want = oracle.break_points(rp, stride)
+            assert np.array_equal(out.cpu().numpy(), want), (name, stride)
+            key = f"{name}__{stride}"
+            if key in g.files:
+                assert np.array_equal(out.cpu().numpy(), g[key]), (name, stride, "golden")
+
+
+def test_adaptive_branches_reached(torch_dev, oracle):
+    """Each branch of the adaptive decision runs its kernel family and stays in parity."""
+    torch = torch_dev
+    rng = np.random.default_rng(8)
+    specs = {
+        1: np.concatenate([rng.integers(0, 3, 3000), rng.integers(20, 40, 3000)]),  # halves differ >= 4x
+        2: rng.integers(0, 6, 6000),  # avg <= 4
+        3: rng.integers(5, 12, 6000),  # small nnz, avg > 4
+    }
+    for want, lens in specs.items():
+        rowptr, cols, vals = synth.csr_from_row_lengths(lens, 6000, rng)
+        assert oracle.adaptive_pick(rowptr) == want
+        x, y0 = rng.standard_normal(6000), rng.standard_normal(6000)
+        got = run(torch, "adaptive", 1.0, 1.0, rowptr, cols, vals, x, y0)
+        check(oracle, got, 1.0, 1.0, rowptr, cols, vals, x, y0, ("adaptive", want))
+        got = run(torch, "adaptive", 1.0, 1.0, rowptr, cols, vals, x, y0, pass_host_rowptr=False)
+        check(oracle, got, 1.0, 1.0, rowptr, cols, vals, x, y0, ("adaptive-device-samples", want))
+
+
+# ---- full-size checks (BASELINE.json configs[1]: Hardesty3-like, 8.2M rows / 40.5M nnz) --------------------------
+@pytest.fixture(scope="module")
+def hardesty(torch_dev):
+    torch = torch_dev
+    m, n, nnz, rp, ci, v = synth.hardesty3_like_torch(device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    x = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    y0 = torch.rand(m, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    return dict(m=m, n=n, nnz=nnz, rp=rp, ci=ci, v=v, x=x, y0=y0)
+
+
+def _spmv(torch, H, strat, alpha, beta, x, y0):
+    y = y0.clone()
+    spmv_acc_amd.csr_spmv(alpha, beta, H["m"], H["n"], H["nnz"], H["rp"], H["ci"], H["v"], x, y, strategy=strat)
+    torch.cuda.synchronize()
+    return y
+
+
+def test_full_size_adaptive_takes_line_branch(torch_dev, hardesty):
+    H = hardesty
+    assert (H["m"], H["n"], H["nnz"]) == synth.LARGE_SET["Hardesty3"]
+    _spmv(torch_dev, H, "adaptive", 1.0, 1.0, H["x"], H["y0"])
+    info = spmv_acc_amd.query_plan(H["rp"], H["m"])
+    assert info["adaptive_branch"] == 2 and info["nnz"] == H["nnz"]  # 40451632 / 8217820 = 4 -> adaptive line
+
+
+def test_full_size_row_sums_and_strategy_agreement(torch_dev, hardesty):
+    """x = 1 makes y the row sums, which torch computes independently (index_add in fp64); all
+    strategies must agree with it and with each other at full size."""
+    torch = torch_dev
+    H = hardesty
+    m, nnz = H["m"], H["nnz"]
+    rows = torch.repeat_interleave(torch.arange(m, device="cuda"), (H["rp"][1:] - H["rp"][:-1]).long(), output_size=nnz)
+    want = torch.zeros(m, dtype=torch.float64, device="cuda").index_add_(0, rows, H["v"])
+    scale = torch.zeros(m, dtype=torch.float64, device="cuda").index_add_(0, rows, H["v"].abs())
+    ones = torch.ones(H["n"], dtype=torch.float64, device="cuda")
+    zeros = torch.zeros(m, dtype=torch.float64, device="cuda")
+    for strat in spmv_acc_amd.HOT_STRATEGIES:
+        y = _spmv(torch, H, strat, 1.0, 0.0, ones, zeros)
+        err = ((y - want).abs() / scale.clamp_min(1e-300)).max().item()
+        assert err <= SCALED_TOL, (strat, err)
+
+
+def test_full_size_linearity_and_beta(torch_dev, hardesty):
+    """A(a*x1 + x2) = a*A x1 + A x2 and y = alpha*A*x + beta*y0 decomposes as alpha*(A x) + beta*y0."""
+    torch = torch_dev
+    H = hardesty
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2)
+    x2 = torch.rand(H["n"], generator=g, device="cuda", dtype=torch.float64) - 0.5
+    zeros = torch.zeros(H["m"], dtype=torch.float64, device="cuda")
+    for strat in ("adaptive", "flat", "line_enhance"):
+        ax1 = _spmv(torch, H, strat, 1.0, 0.0, H["x"], zeros)
+        ax2 = _spmv(torch, H, strat, 1.0, 0.0, x2, zeros)
+        both = _spmv(torch, H, strat, 1.0, 0.0, 3.0 * H["x"] + x2, zeros)
+        scale = (3.0 * ax1.abs() + ax2.abs()).clamp_min(1e-30)
+        assert (((both - (3.0 * ax1 + ax2)).abs() / scale).max().item()) <= 1e-9, strat
+        full = _spmv(torch, H, strat, 0.5, -2.0, H["x"], H["y0"])
+        want = 0.5 * ax1 - 2.0 * H["y0"]
+        scale = (0.5 * ax1.abs() + 2.0 * H["y0"].abs()).clamp_min(1e-30)
+        assert (((full - want).abs() / scale).max().item()) <= 1e-12, strat
+
+
+def test_full_size_sample_rows_vs_oracle(torch_dev, oracle, hardesty):
+    """The first 200k rows of the full-size run against the CPU oracle (the oracle finishes in < 1 s)."""
+    torch = torch_dev
+    H = hardesty
+    k = 200_000
+    rp = H["rp"][: k + 1].cpu().numpy()
+    e = int(rp[-1])
+    ci, v = H["ci"][:e].cpu().numpy(), H["v"][:e].cpu().numpy()
+    x, y0 = H["x"].cpu().numpy(), H["y0"][:k].cpu().numpy()
+    ref = oracle.host_spmv(1.0, 1.0, rp, ci, v, x, y0)
+    for strat in spmv_acc_amd.HOT_STRATEGIES:
+        y = _spmv(torch, H, strat, 1.0, 1.0, H["x"], H["y0"])[:k].cpu().numpy()
+        err = oracle.scaled_error(y, ref, 1.0, 1.0, rp, ci, v, x, y0)
+        assert err <= SCALED_TOL, (strat, err)
+        assert oracle.verify_y(y, ref)[2] == 0, strat
+
+
+# ---- the C++ surface the reference's executables link against ----------------------------------------------------------
+def test_cxx_api_driver(torch_dev, oracle, tmp_path):
+    """Compiles a small C++ program against include/api/spmv.h + the per-strategy headers at the
+    reference's include paths, links libspmv_acc.so and runs sparse_csr_spmv / the L1 wrappers."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    exe = str(tmp_path / "api_driver")
+    libdir = os.path.dirname(spmv_acc_amd.LIB_PATH)
+    subprocess.run([hipcc, "-O2", "-std=c++14", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cxx", "api_driver.cpp"), "-L", libdir, "-lspmv_acc",
+                    f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    rowptr, cols, vals = synth.random_csr(4000, 4000, 9, seed=21, kind="powerlaw")
+    rng = np.random.default_rng(6)
+    x, y0 = rng.standard_normal(4000), rng.standard_normal(4000)
+    inp = str(tmp_path / "in.bin")
+    with open(inp, "wb") as f:
+        np.array([4000, 4000, int(rowptr[-1])], dtype=np.int32).tofile(f)
+        rowptr.tofile(f)
+        cols.tofile(f)
+        vals.tofile(f)
+        x.tofile(f)
+        y0.tofile(f)
+    outp = str(tmp_path / "out.bin")
+    subprocess.run([exe, inp, outp], check=True)
+    ys = np.fromfile(outp, dtype=np.float64).reshape(-1, 4000)
+    assert ys.shape[0] >= 8
+    for k, y in enumerate(ys):
+        check(oracle, y, 1.0, 1.0, rowptr, cols, vals, x, y0, ("cxx", k))

@@ -1,0 +1,174 @@
+"""CPU suite: the product library loads without a GPU, exports every C-ABI symbol include/spmv_acc.h
+declares, and its host-side logic (strategy names, pickers, host form of the row-block preprocessing
+pass, row partition) matches the oracle / the reference-generated goldens.  No compute calls here."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import spmv_acc_amd
+from spmv_acc_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol(hiplib):
+    header = open(os.path.join(ROOT, "include", "spmv_acc.h")).read()
+    # names followed by '(' at declaration level
+    declared = set(re.findall(r"\b(sparse_spmv|spmv_acc_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(spmv_acc_amd.C_ABI_SYMBOLS), declared ^ set(spmv_acc_amd.C_ABI_SYMBOLS)
+    for s in declared:
+        assert hasattr(hiplib, s), s
+
+
+def test_cxx_symbols_for_cli_and_benchmark(hiplib):
+    """The mangled C++ entry points spmv-cli / spmv-gpu-benchmark link against."""
+    out = subprocess.run(["nm", "-D", "--defined-only", "-C", spmv_acc_amd.LIB_PATH], capture_output=True,
+                         text=True, check=True).stdout
+    for name in ("sparse_csr_spmv(int, double, double, csr_desc<int, double>, csr_desc<int, double>",
+                 "sparse_spmv(int, double, double, int, int, int const*", "default_sparse_spmv(",
+                 "adaptive_sparse_spmv(", "flat_sparse_spmv(", "line_enhance_sparse_spmv(",
+                 "adaptive_enhance_sparse_spmv(", "adaptive_line_sparse_spmv(", "vec_row_sparse_spmv(",
+                 "adaptive_vec_row_sparse_spmv(", "adaptive_flat_sparse_spmv(", "thread_row_sparse_spmv(",
+                 "wf_row_sparse_spmv(", "light_sparse_spmv(", "block_row_sparse_spmv(",
+                 "void csr_adaptive_plus_sparse_spmv<true, int, double>(SpMVAccHanele*",
+                 "void csr_adaptive_plus_sparse_spmv<false, int, double>(SpMVAccHanele*"):
+        assert name in out, name
+
+
+def test_strategy_names_follow_reference_matching(hiplib):
+    P = lambda s: hiplib.spmv_acc_parse_strategy(s.encode())
+    names = [hiplib.spmv_acc_strategy_name(i).decode() for i in range(11)]
+    assert tuple(names) == spmv_acc_amd.STRATEGIES
+    for i, n in enumerate(names):
+        assert P(n) == i and P(n.upper()) == i
+    assert P("LINE_ENHANCE") == 7 and P("LINE") == 8  # line_enhance is tested before line
+    assert P("my_default_build") == 0  # regex MATCHES = substring (configure.cmake:18-37)
+    assert P("nonsense") == -1
+    assert hiplib.spmv_acc_set_strategy(b"nonsense") == -1
+    hiplib.spmv_acc_clear_error()
+
+
+def test_strategy_env_and_setter():
+    code = ("import spmv_acc_amd as s; print(s.get_strategy()); s.set_strategy('FLAT'); print(s.get_strategy())")
+    env = dict(os.environ, SPMV_ACC_KERNEL_STRATEGY="line_enhance", PYTHONPATH=ROOT)
+    out = subprocess.run(["python", "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["line_enhance", "flat"]
+    env.pop("SPMV_ACC_KERNEL_STRATEGY")
+    out = subprocess.run(["python", "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["adaptive", "flat"]  # build-time default of this tree: KERNEL_STRATEGY_ADAPTIVE
+
+
+def test_adaptive_branch_matches_oracle(hiplib, oracle):
+    rng = np.random.default_rng(3)
+    seen = set()
+    for trial in range(300):
+        m = int(rng.integers(1, 5000))
+        kind = trial % 5
+        lens = rng.integers(0, [3, 9, 60, 9, 9][kind], m).astype(np.int64)
+        if kind == 3:
+            lens[: m // 2] *= 7  # heavy first half
+        if kind == 4:
+            lens[: m // 2] = 0  # empty first half: the reference would divide by zero here
+        scale = [1, 1, 1, 1, 1][kind]
+        rp = np.zeros(m + 1, dtype=np.int64)
+        np.cumsum(lens * scale, out=rp[1:])
+        # blow nnz up so every threshold (0xC00000, 2^23) is crossed by some trials
+        mult = int(rng.choice([1, 1, 2000, 20000]))
+        rp = np.minimum(rp * mult, 2**31 - 2).astype(np.int32)
+        got = spmv_acc_amd.adaptive_branch(m, rp)
+        assert got == oracle.adaptive_pick(rp), (m, kind, mult)
+        seen.add(got)
+    assert seen >= {1, 2, 3, 4}
+
+
+def test_plus_analysis_matches_reference_goldens(hiplib):
+    g = np.load(os.path.join(GOLD, "analysis_cases.npz"))
+    for name in g["names"]:
+        rp = g[f"{name}__rowptr"]
+        m = rp.size - 1
+        for k, (threads, vec, min_nnz) in enumerate(g["params"]):
+            blocks, bp, fbr = spmv_acc_amd.adaptive_plus_analyze(rp, m, int(min_nnz), int(threads), int(vec))
+            assert np.array_equal(bp, g[f"{name}__{k}__bp"]), (name, k)
+            assert np.array_equal(fbr, g[f"{name}__{k}__fbr"]), (name, k)
+
+
+def test_plus_analysis_matches_oracle_random(hiplib, oracle):
+    rng = np.random.default_rng(5)
+    for trial in range(150):
+        m = int(rng.integers(1, 3000))
+        kind = trial % 4
+        if kind == 0:
+            lens = rng.integers(0, 12, m)
+        elif kind == 1:
+            lens = np.minimum((rng.pareto(1.2, m) * 3).astype(np.int64), 20000)
+        elif kind == 2:
+            lens = rng.integers(0, 3, m)
+            lens[rng.integers(0, m, 3)] = rng.integers(2000, 30000, 3)
+        else:
+            lens = rng.integers(0, 700, m)
+        rp = np.zeros(m + 1, dtype=np.int32)
+        np.cumsum(lens, out=rp[1:])
+        for threads, vec, min_nnz in ((512, 1, 2048), (512, 8, 2048), (256, 2, 1024), (1024, 32, 4096)):
+            a = spmv_acc_amd.adaptive_plus_analyze(rp, m, min_nnz, threads, vec)
+            b = oracle.adaptive_plus_analyze(rp, min_nnz, threads, vec)
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (trial, vec)
+            if oracle.ref() is not None:
+                c = oracle.ref_adaptive_plus_analyze(rp, min_nnz, threads, vec)
+                assert a[0] == c[0] and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
+
+
+def test_plus_vec_and_bp_len(hiplib, oracle):
+    L = oracle.lib()
+    for m, nnz in ((10, 0), (10, 20), (10, 21), (100, 450), (7, 7 * 64), (7, 7 * 65), (8_217_820, 40_451_632)):
+        assert hiplib.spmv_acc_adaptive_plus_vec(m, nnz) == L.oracle_adaptive_plus_vec(m, nnz)
+    for nnz in (0, 1, 1023, 1024, 1025, 40_451_632):
+        for s in (1024, 2048):
+            assert hiplib.spmv_acc_break_points_len(nnz, s) == L.oracle_break_points_len(nnz, s)
+
+
+def test_partition_rows(hiplib):
+    rowptr, _, _ = synth.random_csr(10_000, 10_000, 8, seed=9, kind="powerlaw")
+    eq = spmv_acc_amd.partition_rows(10_000, 8, mode=0)
+    assert eq[0] == 0 and eq[-1] == 10_000 and np.all(np.diff(eq) == 1250)
+    eq = spmv_acc_amd.partition_rows(10_001, 8, mode=0)
+    assert eq[-1] == 10_001 and np.all(np.diff(eq)[:-1] == 1251) and np.diff(eq)[-1] <= 1251
+    bal = spmv_acc_amd.partition_rows(10_000, 8, mode=1, h_rowptr=rowptr)
+    assert bal[0] == 0 and bal[-1] == 10_000 and np.all(np.diff(bal) >= 0)
+    shares = np.diff(rowptr[bal].astype(np.int64))
+    longest = int(np.diff(rowptr).max())
+    assert shares.max() - shares.min() <= 2 * longest + 1  # balanced up to one row at each cut
+
+
+def test_no_cpu_fallback_for_compute(hiplib):
+    """Host arrays are refused: the product path never computes on the CPU."""
+    import torch
+
+    rowptr, cols, vals = synth.random_csr(16, 16, 3, seed=1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    with pytest.raises(spmv_acc_amd.SpmvAccError):
+        spmv_acc_amd.csr_spmv(1.0, 1.0, 16, 16, int(rowptr[-1]), t(rowptr), t(cols), t(vals), torch.zeros(16, dtype=torch.float64),
+                              torch.zeros(16, dtype=torch.float64))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(spmv_acc_amd.SpmvAccError, match="no CPU fallback"):
+        spmv_acc_amd.load_library(str(tmp_path / "libspmv_acc.so"))
+
+
+def test_product_never_touches_oracle():
+    """Nothing under spmv_acc_amd/ or include/ may import, link or execute anything under oracle/."""
+    bad = []
+    for base in ("spmv_acc_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            if "build" in dirpath.split(os.sep):
+                continue
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", "Makefile")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    if re.search(r"oracle_lib|liboracle|libref_analyze|#include\s+\"[^\"]*oracle|import oracle|from oracle", text):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
