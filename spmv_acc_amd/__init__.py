@@ -55,6 +55,14 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
             f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C spmv_acc_amd/csrc`. There is no CPU fallback."
         )
+    # One HIP runtime per process: torch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64 and
+    # initialise it for device memory.  If libspmv_acc.so were loaded first, its NEEDED libamdhip64.so.7 would
+    # bring in /opt/rocm's copy, and the second runtime to initialise finds no device.  Importing torch first
+    # makes the soname resolve to the runtime torch already loaded (kernels + tensors then share one context).
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # C/C++ consumers link the library directly; Python without torch still works
+        pass
     lib = ctypes.CDLL(p)
     vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
     lib.sparse_spmv.argtypes = [ci, cd, cd, ci, ci, vp, vp, vp, vp, vp]
