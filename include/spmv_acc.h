@@ -149,6 +149,13 @@ int spmv_acc_time_spmv(int strategy, int iters, double alpha, double beta, int m
                        const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
                        const double *dx, double *dy, const double *d_y0, float *ms_out);
 
+/* ---- measurement switches (new) -------------------------------------------------------------------------------------
+ * A/B knobs for tools/kbench.py: "xcd_remap" (1), "rowblock_vec" (0 = auto), "rowblock_guard" (1).
+ * Defaults are the shipped configuration; unknown names return -1. */
+int spmv_acc_set_tunable(const char *name, int value);
+int spmv_acc_get_tunable(const char *name);
+void spmv_acc_reset_tunables(void);
+
 const char *spmv_acc_version(void);
 
 #ifdef __cplusplus

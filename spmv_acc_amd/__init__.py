@@ -34,7 +34,8 @@ C_ABI_SYMBOLS = (
     "spmv_acc_adaptive_plus_vec", "spmv_acc_adaptive_branch", "spmv_acc_partition_rows", "spmv_acc_stage_csr",
     "spmv_acc_free_device", "spmv_acc_release_plans", "spmv_acc_cached_plans", "spmv_acc_query_plan",
     "spmv_acc_set_stream", "spmv_acc_get_stream", "spmv_acc_last_error", "spmv_acc_last_error_string",
-    "spmv_acc_clear_error", "spmv_acc_time_spmv", "spmv_acc_version",
+    "spmv_acc_clear_error", "spmv_acc_time_spmv", "spmv_acc_version", "spmv_acc_set_tunable",
+    "spmv_acc_get_tunable", "spmv_acc_reset_tunables",
 )
 
 _lib = None
@@ -94,6 +95,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_clear_error.restype = None
     lib.spmv_acc_time_spmv.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.spmv_acc_version.restype = ctypes.c_char_p
+    lib.spmv_acc_set_tunable.argtypes = [ctypes.c_char_p, ci]
+    lib.spmv_acc_get_tunable.argtypes = [ctypes.c_char_p]
+    lib.spmv_acc_reset_tunables.restype = None
     if path is None:
         _lib = lib
     return lib

@@ -212,6 +212,10 @@ int spmv_acc_query_plan(const int *d_rowptr, int m, int *out) {
 void spmv_acc_set_stream(void *hip_stream) { set_stream(static_cast<hipStream_t>(hip_stream)); }
 void *spmv_acc_get_stream(void) { return static_cast<void *>(get_stream()); }
 
+int spmv_acc_set_tunable(const char *name, int value) { return name ? set_tunable(name, value) : -1; }
+int spmv_acc_get_tunable(const char *name) { return name ? get_tunable(name) : -1; }
+void spmv_acc_reset_tunables(void) { reset_tunables(); }
+
 int spmv_acc_last_error(void) { return last_error(); }
 const char *spmv_acc_last_error_string(void) { return last_error_string(); }
 void spmv_acc_clear_error(void) { clear_error(); }

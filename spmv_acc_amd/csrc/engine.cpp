@@ -50,6 +50,39 @@ void clear_error() {
 void set_stream(hipStream_t s) { g_stream = s; }
 hipStream_t get_stream() { return g_stream; }
 
+// ---- tunables (A/B switches for measurement; defaults are the shipped configuration) ----------------------
+namespace {
+struct Tunable {
+  const char *name;
+  int def;
+  int val;
+};
+Tunable g_tunables[] = {
+    {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
+    {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
+    {"rowblock_guard", 1, 1},  // imbalance probe + flat rescue for the row-block family
+    {"flat_npt", 8, 8},        // non-zeros per lane per flat tile: 4, 8 or 16 (tile = 256 lanes x this)
+};
+} // namespace
+
+int set_tunable(const char *name, int value) {
+  for (auto &t : g_tunables) {
+    if (std::strcmp(t.name, name) == 0) {
+      t.val = value;
+      return 0;
+    }
+  }
+  return -1;
+}
+int get_tunable(const char *name) {
+  for (auto &t : g_tunables)
+    if (std::strcmp(t.name, name) == 0) return t.val;
+  return -1;
+}
+void reset_tunables() {
+  for (auto &t : g_tunables) t.val = t.def;
+}
+
 // ---- strategy names -----------------------------------------------------------------------------------------
 static const char *const kNames[kStrategyCount] = {"default",   "adaptive",     "thread_row", "wf_row",
                                                    "block_row_ordinary", "light", "vector_row", "line_enhance",
@@ -212,11 +245,12 @@ struct Plan {
   CsrDev A;
   bool have_samples = false;
   RowptrSamples samples;
+  // row-block family: -1 unknown, 1 balanced, 0 some workgroup would need too many LDS rounds
+  int rowblock_ok = -1;
+  int max_block_nnz = 0;
   // flat
   int flat_tiles = -1;
-  int *d_bp = nullptr;
-  double *d_head = nullptr;
-  double *d_tail = nullptr;
+  FlatPlan flat;
   // row-block-plus
   int plus_blocks = -1;
   int plus_vec = 0;
@@ -225,15 +259,21 @@ struct Plan {
   double *d_ppartial = nullptr;
 
   void free_device() {
-    if (d_bp) (void)hipFree(d_bp);
-    if (d_head) (void)hipFree(d_head);
-    if (d_tail) (void)hipFree(d_tail);
+    free_flat();
     if (d_pbp) (void)hipFree(d_pbp);
     if (d_pfbr) (void)hipFree(d_pfbr);
     if (d_ppartial) (void)hipFree(d_ppartial);
-    d_bp = nullptr;
-    d_head = d_tail = d_ppartial = nullptr;
+    d_ppartial = nullptr;
     d_pbp = d_pfbr = nullptr;
+  }
+  void free_flat() {
+    if (flat.bp) (void)hipFree(flat.bp);
+    if (flat.head) (void)hipFree(flat.head);
+    if (flat.tail) (void)hipFree(flat.tail);
+    if (flat.tail_row) (void)hipFree(flat.tail_row);
+    if (flat.tail_end) (void)hipFree(flat.tail_end);
+    flat = FlatPlan();
+    flat_tiles = -1;
   }
 };
 
@@ -327,17 +367,22 @@ Plan *get_plan(int m, int n, int nnz, const int *h_rowptr, const int *rp, const 
 }
 
 bool ensure_flat(Plan &p, hipStream_t stream) {
-  if (p.flat_tiles >= 0) return true;
+  const int npt = get_tunable("flat_npt");
+  const int stride = kThreads * ((npt == 4 || npt == 16) ? npt : kNnzPerThread);
+  if (p.flat_tiles >= 0 && p.flat.stride == stride) return true;
+  p.free_flat();
   const int nnz = p.A.nnz;
-  const int tiles = nnz / kFlatStride + (nnz % kFlatStride ? 1 : 0);
-  const int bp_len = tiles + 1;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_bp), sizeof(int) * bp_len), "hipMalloc break points"))
-    return false;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_head), sizeof(double) * (tiles + 1)), "hipMalloc head carries"))
-    return false;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_tail), sizeof(double) * (tiles + 1)), "hipMalloc tail carries"))
-    return false;
-  launch_break_points(stream, p.A.rp, p.A.m, nnz, kFlatStride, p.d_bp, bp_len);
+  const int tiles = nnz / stride + (nnz % stride ? 1 : 0);
+  const size_t n1 = static_cast<size_t>(tiles) + 1;
+  FlatPlan &F = p.flat;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.bp), sizeof(int) * n1), "hipMalloc break points")) return false;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.head), sizeof(double) * n1), "hipMalloc head carries")) return false;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail), sizeof(double) * n1), "hipMalloc tail carries")) return false;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail_row), sizeof(int) * n1), "hipMalloc tail rows")) return false;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail_end), sizeof(int) * n1), "hipMalloc tail ends")) return false;
+  F.stride = stride;
+  F.ntiles = tiles;
+  launch_break_points(stream, p.A.rp, p.A.m, nnz, stride, F.bp, static_cast<int>(n1));
   p.flat_tiles = tiles;
   return true;
 }
@@ -372,14 +417,44 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
   return true;
 }
 
-void run_rowblock(hipStream_t st, const Plan &p, double alpha, double beta, const double *x, double *y) {
-  launch_rowblock_stream(st, p.A, pick_vec_width(p.A.m, p.A.nnz), /*xcd_remap=*/true, alpha, beta, x, y);
-}
-
 bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *x, double *y) {
   if (!ensure_flat(p, st)) return false;
-  launch_flat(st, p.A, p.d_bp, p.flat_tiles, p.d_head, p.d_tail, alpha, beta, x, y);
-  launch_flat_fixup(st, p.A, p.d_bp, p.flat_tiles, p.d_head, p.d_tail, alpha, beta, y);
+  launch_flat(st, p.A, p.flat, alpha, beta, x, y);
+  return true;
+}
+
+// Once per matrix: would any fixed row block have to stream more than kRowblockMaxRounds tiles?
+// (power-law matrices: R-MAT hub rows put millions of non-zeros into one workgroup.)
+bool probe_rowblock(Plan &p, int vec, hipStream_t st) {
+  if (p.rowblock_ok >= 0) return true;
+  int *d_max = nullptr;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d_max), sizeof(int)), "hipMalloc probe")) return false;
+  bool ok = hip_ok(hipMemsetAsync(d_max, 0, sizeof(int), st), "memset probe");
+  if (ok) {
+    launch_max_block_nnz(st, p.A.rp, p.A.m, kThreads / vec, d_max);
+    int h = 0;
+    ok = hip_ok(hipMemcpyAsync(&h, d_max, sizeof(int), hipMemcpyDeviceToHost, st), "read probe") &&
+         hip_ok(hipStreamSynchronize(st), "sync probe");
+    if (ok) {
+      p.max_block_nnz = h;
+      p.rowblock_ok = (h <= kRowblockMaxRounds * kTile) ? 1 : 0;
+    }
+  }
+  (void)hipFree(d_max);
+  return ok;
+}
+
+// line-enhance family with its imbalance rescue: fixed row blocks while every block stays within a
+// few LDS rounds, otherwise the same tile machinery cut by non-zeros (flat) so hub rows are shared
+// by many workgroups instead of serialising one.
+bool run_rowblock(hipStream_t st, Plan &p, double alpha, double beta, const double *x, double *y) {
+  const int forced = get_tunable("rowblock_vec");
+  const int vec = forced > 0 ? forced : pick_vec_width(p.A.m, p.A.nnz);
+  if (get_tunable("rowblock_guard")) {
+    if (!probe_rowblock(p, vec, st)) return false;
+    if (p.rowblock_ok == 0) return run_flat(st, p, alpha, beta, x, y);
+  }
+  launch_rowblock_stream(st, p.A, vec, get_tunable("xcd_remap") != 0, alpha, beta, x, y);
   return true;
 }
 
@@ -428,8 +503,6 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     launch_vector_row(st, p->A, m, 64, 1, alpha, beta, dx, dy);
     break;
   case kThreadRow:
-    launch_rowblock_stream(st, p->A, 1, true, alpha, beta, dx, dy);
-    break;
   case kLineEnhance:
   case kLine:
     run_rowblock(st, *p, alpha, beta, dx, dy);

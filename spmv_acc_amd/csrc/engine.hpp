@@ -49,6 +49,11 @@ int last_error();
 const char *last_error_string();
 void clear_error();
 
+// measurement switches (see engine.cpp g_tunables); -1 for an unknown name
+int set_tunable(const char *name, int value);
+int get_tunable(const char *name);
+void reset_tunables();
+
 void set_stream(hipStream_t s);
 hipStream_t get_stream();
 

@@ -55,24 +55,28 @@ __device__ __forceinline__ int tile_end_excl(const int *__restrict__ rp, const i
   return (e < m && rp[e] < t1) ? e + 1 : e;
 }
 
-template <bool ALIGNED>
+template <int NPT, bool ALIGNED>
 __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int ntiles, double alpha, double beta,
                                                              const int *__restrict__ rp, const int *__restrict__ bp,
                                                              const int *__restrict__ ci,
                                                              const double *__restrict__ v,
                                                              const double *__restrict__ x, double *__restrict__ y,
-                                                             double *__restrict__ head, double *__restrict__ tail) {
-  __shared__ double lds[kTile];
+                                                             double *__restrict__ head, double *__restrict__ tail,
+                                                             int *__restrict__ tail_row, int *__restrict__ tail_end) {
+  constexpr int STRIDE = kThreads * NPT;
+  __shared__ double lds[STRIDE];
   const int t = blockIdx.x;
-  const int t0 = t * kFlatStride; // host guarantees nnz + stride fits in int
-  const int t1 = (nnz - t0 > kFlatStride) ? t0 + kFlatStride : nnz;
+  const int t0 = t * STRIDE; // host guarantees nnz + stride fits in int
+  const int t1 = (nnz - t0 > STRIDE) ? t0 + STRIDE : nnz;
 
-  stage_products<kThreads, kNnzPerThread, ALIGNED>(lds, t0, t1, nnz, ci, v, x);
-
+  // the tile's row range first (scalar loads, independent of the stream) so it is known long before the
+  // products are
   int first = bp[t];
   first = first < m ? first : m;
   const int end_excl = tile_end_excl(rp, bp, t, ntiles, m, t1);
   const int nrows = end_excl - first;
+
+  stage_products<kThreads, NPT, ALIGNED>(lds, t0, t1, nnz, ci, v, x);
 
   // lanes per row for this tile: as many as the tile's row count leaves room for (wave-uniform)
   int w = 1;
@@ -104,34 +108,39 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
         head[t] = s; // row started in an earlier tile (it may also run past this one)
       } else {
         tail[t] = s; // row starts here and continues in the next tile
+        tail_row[t] = r;
+        tail_end[t] = b;
       }
     }
+  }
+  // a tile without a continuing row says so (the fix-up reads tail_row only)
+  if (threadIdx.x == 0) {
+    bool has_tail = false;
+    if (nrows > 0) {
+      const int r = end_excl - 1;
+      has_tail = (rp[r + 1] > t1) && (rp[r] >= t0);
+    }
+    if (!has_tail) tail_row[t] = -1;
   }
 }
 
 // One thread per tile that holds the START of a cut row: adds its tail carry and the head carries of
-// the following tiles in tile order, then applies alpha/beta once.
-__global__ __launch_bounds__(256) void flat_fixup_kernel(int m, int nnz, int ntiles, double alpha, double beta,
-                                                         const int *__restrict__ rp, const int *__restrict__ bp,
+// the following tiles in tile order, then applies alpha/beta once.  Everything it needs was written by
+// the tile kernel, so the dependent-load chain is one level deep.
+__global__ __launch_bounds__(256) void flat_fixup_kernel(int ntiles, int stride, double alpha, double beta,
                                                          const double *__restrict__ head,
-                                                         const double *__restrict__ tail, double *__restrict__ y) {
+                                                         const double *__restrict__ tail,
+                                                         const int *__restrict__ tail_row,
+                                                         const int *__restrict__ tail_end, double *__restrict__ y) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= ntiles - 1) return; // the last tile cannot have a row that continues
-  const int t0 = t * kFlatStride;
-  const int t1 = t0 + kFlatStride; // t < ntiles-1, so the tile is full
-  const int end_excl = tile_end_excl(rp, bp, t, ntiles, m, t1);
-  int first = bp[t];
-  first = first < m ? first : m;
-  if (end_excl <= first) return;
-  const int r = end_excl - 1;
-  const int a = rp[r];
-  const int b = rp[r + 1];
-  if (!(b > t1 && a >= t0)) return; // row r does not start in this tile, or ends in it
+  const int r = tail_row[t];
+  if (r < 0) return;
+  const int b = tail_end[t];
   double s = tail[t];
   for (int k = t + 1; k < ntiles; ++k) {
     s += head[k];
-    const long long k1 = static_cast<long long>(k + 1) * kFlatStride;
-    if (b <= k1) break;
+    if (b <= static_cast<long long>(k + 1) * stride) break;
   }
   store_y(y, r, alpha, beta, s);
 }
@@ -144,23 +153,32 @@ void launch_break_points(hipStream_t stream, const int *rp, int m, int nnz, int 
                      bp_len);
 }
 
-void launch_flat(hipStream_t stream, const CsrDev &A, const int *bp, int ntiles, double *head, double *tail,
-                 double alpha, double beta, const double *x, double *y) {
-  if (ntiles <= 0) return;
+namespace {
+template <int NPT>
+void launch_flat_npt(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
+                     double *y) {
   if (A.aligned16) {
-    hipLaunchKernelGGL((flat_tile_kernel<true>), dim3(ntiles), dim3(kThreads), 0, stream, A.m, A.nnz, ntiles, alpha,
-                       beta, A.rp, bp, A.ci, A.v, x, y, head, tail);
+    hipLaunchKernelGGL((flat_tile_kernel<NPT, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz, P.ntiles,
+                       alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end);
   } else {
-    hipLaunchKernelGGL((flat_tile_kernel<false>), dim3(ntiles), dim3(kThreads), 0, stream, A.m, A.nnz, ntiles, alpha,
-                       beta, A.rp, bp, A.ci, A.v, x, y, head, tail);
+    hipLaunchKernelGGL((flat_tile_kernel<NPT, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz, P.ntiles,
+                       alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end);
   }
 }
+} // namespace
 
-void launch_flat_fixup(hipStream_t stream, const CsrDev &A, const int *bp, int ntiles, const double *head,
-                       const double *tail, double alpha, double beta, double *y) {
-  if (ntiles <= 1) return;
-  hipLaunchKernelGGL(flat_fixup_kernel, dim3((ntiles - 1 + 255) / 256), dim3(256), 0, stream, A.m, A.nnz, ntiles,
-                     alpha, beta, A.rp, bp, head, tail, y);
+void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
+                 double *y) {
+  if (P.ntiles <= 0) return;
+  switch (P.stride / kThreads) {
+  case 4: launch_flat_npt<4>(stream, A, P, alpha, beta, x, y); break;
+  case 16: launch_flat_npt<16>(stream, A, P, alpha, beta, x, y); break;
+  default: launch_flat_npt<8>(stream, A, P, alpha, beta, x, y); break;
+  }
+  if (P.ntiles > 1) {
+    hipLaunchKernelGGL(flat_fixup_kernel, dim3((P.ntiles - 1 + 255) / 256), dim3(256), 0, stream, P.ntiles, P.stride,
+                       alpha, beta, P.head, P.tail, P.tail_row, P.tail_end, y);
+  }
 }
 
 } // namespace spmv_acc

@@ -69,6 +69,25 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   if (live && lane == 0) store_y(y, row, alpha, beta, acc);
 }
 
+// Largest number of non-zeros any workgroup of `rpb` consecutive rows would own (plan-time imbalance probe).
+__global__ __launch_bounds__(256) void max_block_nnz_kernel(const int *__restrict__ rp, int m, int rpb, int nblocks,
+                                                            int *__restrict__ out) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  int v = 0;
+  if (b < nblocks) {
+    const long long lo = static_cast<long long>(b) * rpb;
+    const long long hi = lo + rpb < m ? lo + rpb : m;
+    v = rp[hi] - rp[lo];
+  }
+  // wave max, then one atomic per wave
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int other = __shfl_xor(v, o, 64);
+    v = other > v ? other : v;
+  }
+  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(out, v);
+}
+
 template <int VEC>
 void launch_vec(hipStream_t stream, const CsrDev &A, bool xcd, double alpha, double beta, const double *x,
                 double *y) {
@@ -86,6 +105,13 @@ void launch_vec(hipStream_t stream, const CsrDev &A, bool xcd, double alpha, dou
 }
 
 } // namespace
+
+void launch_max_block_nnz(hipStream_t stream, const int *rp, int m, int rows_per_block, int *d_out) {
+  const int nblocks = static_cast<int>((static_cast<long long>(m) + rows_per_block - 1) / rows_per_block);
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(max_block_nnz_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, rp, m, rows_per_block,
+                     nblocks, d_out);
+}
 
 void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, bool xcd_remap, double alpha, double beta,
                             const double *x, double *y) {

@@ -41,16 +41,30 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
 void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, bool xcd_remap, double alpha, double beta,
                             const double *x, double *y);
 
+// plan-time imbalance probe for the row-block family: *d_out (pre-zeroed) = max non-zeros owned by any
+// workgroup of rows_per_block consecutive rows.
+void launch_max_block_nnz(hipStream_t stream, const int *rp, int m, int rows_per_block, int *d_out);
+// a row block is "balanced enough" while it needs at most this many LDS rounds
+constexpr int kRowblockMaxRounds = 8;
+
 // row-block preprocessing pass, device form: break points with the reference's exact semantics
 // (hip-flat/flat_imp.inl:108-131) computed by one binary search per entry; no memset needed.
 void launch_break_points(hipStream_t stream, const int *rp, int m, int nnz, int stride, int *bp, int bp_len);
 
-// flat family: one workgroup per kFlatStride non-zeros; complete rows are stored directly, the two
-// possible partial rows per tile go to head/tail carries that launch_flat_fixup folds into y.
-void launch_flat(hipStream_t stream, const CsrDev &A, const int *bp, int ntiles, double *head, double *tail,
-                 double alpha, double beta, const double *x, double *y);
-void launch_flat_fixup(hipStream_t stream, const CsrDev &A, const int *bp, int ntiles, const double *head,
-                       const double *tail, double alpha, double beta, double *y);
+// flat family: one workgroup per `stride` non-zeros (stride = kThreads * {4, 8, 16}); complete rows are
+// stored directly, the two possible partial rows per tile go to head/tail carries that a small second
+// kernel folds into y in tile order.
+struct FlatPlan {
+  int stride = 0;
+  int ntiles = 0;
+  int *bp = nullptr;        // ntiles + 1 break points (reference semantics)
+  double *head = nullptr;   // per tile: partial sum of the row that started in an earlier tile
+  double *tail = nullptr;   // per tile: partial sum of the row that continues in the next tile
+  int *tail_row = nullptr;  // per tile: that row, or -1
+  int *tail_end = nullptr;  // per tile: rowptr[row + 1] of that row
+};
+void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
+                 double *y);
 
 // row-block-plus family: row blocks from the adaptive-plus analysis (break_points + first_block_of_row).
 void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, int vec,
