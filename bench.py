@@ -105,6 +105,33 @@ def cpu_baseline(W, x, y0, seconds):
     }
 
 
+def pmc_traffic(workload, strategy):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), or None."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return table[f"{workload}|{strategy}"]["corrected_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def copy_ceiling_gbs(torch, device):
+    """Device copy ceiling measured in the same run: y.copy_(x) of 1 GiB (read + write bytes / time)."""
+    n = 1 << 27
+    a = torch.empty(n, dtype=torch.float64, device=device).normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = float("inf")
+    for _ in range(5):
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return 2.0 * 8 * n / (best * 1e-3) / 1e9
+
+
 def main():
     args = parse()
     import torch
@@ -121,12 +148,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal only: SPMV_ACC_BENCH_BACKEND=gloo lets several ranks share one GPU (RCCL needs one GPU per rank)
+    backend = os.environ.get("SPMV_ACC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     spmv_acc_amd.load_library()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     W = build_workload(args, torch, device, rank)
     m, n, nnz = W["m"], W["n"], W["nnz"]
@@ -194,12 +227,15 @@ def main():
                    "alpha": alpha, "beta": beta, "scale": args.scale,
                    "parallelism": "single GPU" if world == 1 else f"row-range shard x{world} + RCCL allgather(y)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": pmc_traffic(args.workload, strat) if args.scale == 1.0 else None,
                      "algorithmic_bytes_per_launch": b_alg, "launch_ms_mean": round(ev_ms, 6)},
         "ref_formula_gibps": round(synth.reference_bytes(m, nnz) / 2**30 / (ev_ms * 1e-3), 2),
         "gflops_kernel_only_per_gpu": round(2.0 * nnz / (ev_ms * 1e-3) / 1e9, 3),
     }
     result.update(out_extra)
+    if rank == 0:
+        result["copy_ceiling_gbs"] = round(copy_ceiling_gbs(torch, device), 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(W, x, y0, args.cpu_seconds)
     elif rank == 0:

@@ -7,11 +7,15 @@ p = argparse.ArgumentParser()
 p.add_argument("--workload", default="hardesty3")
 p.add_argument("--strategy", default="adaptive")
 p.add_argument("--iters", type=int, default=5)
+p.add_argument("--far", type=float, default=None)
 a = p.parse_args()
 import torch
 import spmv_acc_amd
 from spmv_acc_amd import synth
-if a.workload == "hardesty3":
+if a.workload == "hardesty3" and a.far is not None:
+    m, n, nnz = synth.LARGE_SET["Hardesty3"]
+    rp, ci, v = synth.structured_csr_torch(m, n, nnz, 0xC2, device="cuda", far_fraction=a.far)
+elif a.workload == "hardesty3":
     m, n, nnz, rp, ci, v = synth.hardesty3_like_torch(device="cuda")
 else:
     m, n, nnz, rp, ci, v = synth.large_set_like_torch(a.workload, device="cuda")
