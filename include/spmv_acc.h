@@ -149,6 +149,15 @@ int spmv_acc_time_spmv(int strategy, int iters, double alpha, double beta, int m
                        const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
                        const double *dx, double *dy, const double *d_y0, float *ms_out);
 
+/* One event pair around all `iters` back-to-back launches (no per-launch markers): *total_ms_out / iters is
+ * the average launch duration a solver loop sees. */
+int spmv_acc_time_spmv_total(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
+                             const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
+                             const double *dx, double *dy, float *total_ms_out);
+/* Streaming-copy ceiling (GB/s, read + write bytes) with the kernels' 16-B non-temporal access shape;
+ * replaces: the WITH_MEM_BANDWIDTH macros of src/acc/common/mem_bandwidth.hpp:13-38 as the yardstick. */
+double spmv_acc_copy_ceiling_gbs(void *d_dst, const void *d_src, long long bytes, int reps);
+
 /* ---- measurement switches (new) -------------------------------------------------------------------------------------
  * A/B knobs for tools/kbench.py: "xcd_remap" (1), "rowblock_vec" (0 = auto), "rowblock_guard" (1).
  * Defaults are the shipped configuration; unknown names return -1. */

@@ -35,7 +35,7 @@ C_ABI_SYMBOLS = (
     "spmv_acc_free_device", "spmv_acc_release_plans", "spmv_acc_cached_plans", "spmv_acc_query_plan",
     "spmv_acc_set_stream", "spmv_acc_get_stream", "spmv_acc_last_error", "spmv_acc_last_error_string",
     "spmv_acc_clear_error", "spmv_acc_time_spmv", "spmv_acc_version", "spmv_acc_set_tunable",
-    "spmv_acc_get_tunable", "spmv_acc_reset_tunables",
+    "spmv_acc_get_tunable", "spmv_acc_reset_tunables", "spmv_acc_time_spmv_total", "spmv_acc_copy_ceiling_gbs",
 )
 
 _lib = None
@@ -98,6 +98,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_set_tunable.argtypes = [ctypes.c_char_p, ci]
     lib.spmv_acc_get_tunable.argtypes = [ctypes.c_char_p]
     lib.spmv_acc_reset_tunables.restype = None
+    lib.spmv_acc_time_spmv_total.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+    lib.spmv_acc_copy_ceiling_gbs.argtypes = [vp, vp, ctypes.c_longlong, ci]
+    lib.spmv_acc_copy_ceiling_gbs.restype = cd
     if path is None:
         _lib = lib
     return lib
@@ -220,6 +223,27 @@ def time_spmv(strategy, iters: int, alpha: float, beta: float, m: int, n: int, n
         msg = lib.spmv_acc_last_error_string().decode()
         raise SpmvAccError(f"time_spmv failed ({rc}): {msg}")
     return list(out)
+
+
+def time_spmv_total(strategy, iters: int, alpha: float, beta: float, m: int, n: int, nnz: int, rowptr, colindex, value,
+                    x, y, h_rowptr=None) -> float:
+    """Total milliseconds of `iters` back-to-back SpMVs between ONE hipEvent pair on the library stream."""
+    lib = load_library()
+    _require_cuda(rowptr, colindex, value, x, y)
+    out = ctypes.c_float(0.0)
+    rc = lib.spmv_acc_time_spmv_total(strategy_id(strategy), iters, alpha, beta, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr),
+                                      _ptr(colindex), _ptr(value), _ptr(x), _ptr(y), ctypes.addressof(out))
+    if rc != 0:
+        raise SpmvAccError(f"time_spmv_total failed ({rc}): {lib.spmv_acc_last_error_string().decode()}")
+    return float(out.value)
+
+
+def copy_ceiling_gbs(dst, src, reps: int = 5) -> float:
+    """Streaming-copy ceiling in GB/s (read + write) for two equally sized GPU tensors."""
+    lib = load_library()
+    _require_cuda(dst, src)
+    nbytes = (src.numel() * src.element_size()) // 16 * 16
+    return float(lib.spmv_acc_copy_ceiling_gbs(_ptr(dst), _ptr(src), nbytes, reps))
 
 
 def release_plans(rowptr=None) -> None:

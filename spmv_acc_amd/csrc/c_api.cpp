@@ -253,4 +253,58 @@ int spmv_acc_time_spmv(int strategy, int iters, double alpha, double beta, int m
   return rc;
 }
 
+// Same protocol with ONE event pair around all `iters` launches: total_ms / iters is the average launch
+// duration including the back-to-back launch gaps (what a solver loop sees); no per-launch event markers
+// sit between the kernels.
+int spmv_acc_time_spmv_total(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
+                             const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
+                             const double *dx, double *dy, float *total_ms_out) {
+  if (iters <= 0 || !total_ms_out) {
+    set_error(kErrBadArgument, "spmv_acc_time_spmv_total: bad argument");
+    return kErrBadArgument;
+  }
+  hipStream_t st = get_stream();
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    set_error(kErrHip, "hipEventCreate failed");
+    return kErrHip;
+  }
+  clear_error();
+  (void)hipEventRecord(e0, st);
+  for (int i = 0; i < iters; ++i)
+    run_spmv(strategy, 0, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy);
+  (void)hipEventRecord(e1, st);
+  int rc = kOk;
+  if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(total_ms_out, e0, e1) != hipSuccess) rc = kErrHip;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != kOk) set_error(kErrHip, "spmv_acc_time_spmv_total: HIP failure while timing");
+  if (rc == kOk && last_error() != kOk) rc = last_error();
+  return rc;
+}
+
+// Streaming-copy ceiling of the device in this process: dst[i] = src[i] over `bytes` (multiple of 16) with the
+// same 16-B non-temporal loads the SpMV kernels use; returns GB/s counting read + write bytes, best of `reps`.
+double spmv_acc_copy_ceiling_gbs(void *dst, const void *src, long long bytes, int reps) {
+  if (!dst || !src || bytes < 16 || reps <= 0) return -1.0;
+  hipStream_t st = get_stream();
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+  float best = 1e30f;
+  for (int r = 0; r < reps + 1; ++r) {
+    (void)hipEventRecord(e0, st);
+    launch_stream_copy(st, dst, src, bytes);
+    (void)hipEventRecord(e1, st);
+    float ms = 0.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+      best = -1.f;
+      break;
+    }
+    if (r > 0 && ms < best) best = ms; // first repetition is a warm-up
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return best > 0.f ? 2.0 * static_cast<double>(bytes) / (best * 1e-3) / 1e9 : -1.0;
+}
+
 } // extern "C"

@@ -53,6 +53,23 @@ __global__ __launch_bounds__(kThreads) void scale_y_kernel(int m, double beta, d
   if (i < m) y[i] = (beta == 0.0) ? 0.0 : beta * y[i];
 }
 
+// streaming copy with the SpMV kernels' load shape (16 B per lane, non-temporal), 4 steps per lane
+__global__ __launch_bounds__(kThreads) void stream_copy_kernel(int4v *__restrict__ dst, const int4v *__restrict__ src,
+                                                               long long n16) {
+  const long long base = (static_cast<long long>(blockIdx.x) * kThreads * 4) + threadIdx.x;
+  int4v r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + static_cast<long long>(k) * kThreads;
+    if (i < n16) r[k] = __builtin_nontemporal_load(src + i);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + static_cast<long long>(k) * kThreads;
+    if (i < n16) __builtin_nontemporal_store(r[k], dst + i);
+  }
+}
+
 inline int ceil_div_ll(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }
 
 } // namespace
@@ -75,6 +92,13 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
   if (nb0 + nb1 == 0) return;
   hipLaunchKernelGGL(vector_row_kernel, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1,
                      alpha, beta, A.rp, A.ci, A.v, x, y);
+}
+
+void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes) {
+  const long long n16 = bytes / 16;
+  if (n16 <= 0) return;
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(ceil_div_ll(n16, kThreads * 4)), dim3(kThreads), 0, stream,
+                     static_cast<int4v *>(dst), static_cast<const int4v *>(src), n16);
 }
 
 void launch_scale_y(hipStream_t stream, int m, double beta, double *y) {

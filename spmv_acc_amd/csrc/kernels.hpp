@@ -72,6 +72,9 @@ void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *
 void launch_plus_fixup(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks,
                        const double *partial, double alpha, double beta, double *y);
 
+// dst = src over `bytes` (16-B granules) with the kernels' streaming load shape: the copy ceiling probe
+void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes);
+
 // y[i] = beta * y[i] (used for m > 0, nnz == 0 and as a building block)
 void launch_scale_y(hipStream_t stream, int m, double beta, double *y);
 
