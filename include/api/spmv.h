@@ -15,7 +15,9 @@ void sparse_csr_spmv(int trans, const double alpha, const double beta, const csr
 
 // Ten-argument form; all pointers are device pointers.  Unlike the reference (api/spmv_imp.cpp:14) it
 // never dereferences rowptr on the host.
+#ifndef SPMV_ACC_C_ABI_H // (spmv_acc.h, if included first, has declared the C-linkage twin of the same name)
 void sparse_spmv(int htrans, const double halpha, const double hbeta, int hm, int hn, const int *rowptr,
                  const int *colindex, const double *value, const double *x, double *y);
+#endif
 
 #endif // SPMV_ACC_AMD_API_SPMV_H

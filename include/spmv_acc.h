@@ -51,9 +51,13 @@ int spmv_acc_parse_strategy(const char *name); /* -1 if no match */
  *           ten arguments with C linkage here).
  * The reference reads rowptr[hm] on the HOST (spmv_imp.cpp:14), which needs host-visible device
  * memory; here nnz and the strategy pickers' rowptr samples are fetched from the device once per
- * matrix and cached, so plain hipMalloc memory works. */
+ * matrix and cached, so plain hipMalloc memory works.
+ * (A C++ translation unit that has already included api/spmv.h sees that header's C++-linkage declaration;
+ * the library exports both symbols, one name cannot carry two linkages in one TU.) */
+#ifndef SPMV_ACC_AMD_API_SPMV_H
 void sparse_spmv(int htrans, const double halpha, const double hbeta, int hm, int hn, const int *rowptr,
                  const int *colindex, const double *value, const double *x, double *y);
+#endif
 
 /* ---- descriptor entry, flattened to C --------------------------------------------------------------
  * replaces: void sparse_csr_spmv(int trans, const double alpha, const double beta,

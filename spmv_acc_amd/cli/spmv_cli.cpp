@@ -1,0 +1,337 @@
+// spmv_cli.cpp -- the reference's two drivers in one executable, on top of libspmv_acc.so:
+//   spmv-cli <matrix> -f csr|mtx|bin2               (cli/main.cpp:33-140: read, stage, 10 warm-ups, time, verify, print)
+//   spmv-cli <matrix> -f ... --benchmark             (benchmark/main.cpp:87-144 + csr_spmv.hpp:45-99: per strategy,
+//                                                     10 warm-ups, 3 timed runs, median, verify_y, PERFORMANCE CSV line)
+//   spmv-cli <matrix> -f ... --no-gpu                (BASELINE.json configs[0]: the CPU-side verification path alone --
+//                                                     reader + vectors + host_spmv + verify, no device needed)
+// Same command-line shape (positional matrix path, -f/--format), same vector generator and call order
+// (cli/utils.hpp:46-85), same verification thresholds and messages (cli/verification.cpp:15-78), same CSV columns
+// (benchmark/utils/statistics_logger.cpp:11-56).  The verification code here is the CLI's checker of the device
+// result -- it is not a compute fallback: the SpMV under test always comes from the library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/api/spmv.h"
+#include "../../include/spmv_acc.h"
+#include "../../include/spmv_acc_strategies.hpp"
+#include "matrix_io.hpp"
+
+using spmv_cli::HostCsr;
+
+#define HIP_CHECK(call)                                                                                                \
+  do {                                                                                                                 \
+    hipError_t err_ = (call);                                                                                          \
+    if (err_ != hipSuccess) {                                                                                          \
+      std::fprintf(stderr, "HIP error: '%s'(%d) at %s:%d\n", hipGetErrorString(err_), err_, __FILE__, __LINE__);        \
+      std::abort();                                                                                                    \
+    }                                                                                                                  \
+  } while (0)
+
+namespace {
+
+// ---- vectors: the reference's generator and call order (cli/utils.hpp:46-85) ------------------------------------------
+double rand_grid() { return -1.0 + 2.0 * static_cast<double>(std::rand() % 100) / 101.0; }
+
+struct HostVectors {
+  std::vector<double> x, y0, y_dev, y_ref;
+};
+
+HostVectors make_vectors(const HostCsr &A, bool keep_file_x) {
+  HostVectors v;
+  v.x.resize(A.cols);
+  v.y0.resize(A.rows);
+  v.y_dev.resize(A.rows);
+  v.y_ref.resize(A.rows);
+  for (auto &e : v.x) e = rand_grid();     // hX
+  for (auto &e : v.y0) e = rand_grid();    // temphY
+  for (auto &e : v.y_dev) e = rand_grid(); // hY   (drawn, then overwritten -- keeps the rand() stream aligned)
+  for (auto &e : v.y_ref) e = rand_grid(); // hhY
+  v.y_dev = v.y0;
+  v.y_ref = v.y0;
+  if (keep_file_x) v.x = A.x; // the .csr format carries x
+  return v;
+}
+
+// ---- verification path (cli/verification.cpp:56-66, 43-54, 15-38) ------------------------------------------------------
+void host_spmv(double alpha, double beta, const HostCsr &A, const double *x, double *y) {
+  for (int i = 0; i < A.rows; ++i) {
+    double acc = 0;
+    for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) acc += A.values[j] * x[A.colidx[j]];
+    y[i] = alpha * acc + beta * y[i];
+  }
+}
+
+bool verify(const double *dy, const double *hy, int n) {
+  int total_validation = 0;
+  for (int i = 0; i < n; ++i) {
+    if (std::fabs(dy[i] - hy[i]) / std::fabs(hy[i]) >= 1e-7) {
+      std::cout << std::fabs(dy[i] - hy[i]) << " i:" << i << " dy[i]:" << dy[i] << " hy[i]:" << hy[i] << std::endl;
+      std::cout << "Failed verification,please check your code\n" << std::endl;
+      return false;
+    }
+    total_validation = i;
+  }
+  std::cout << "Congratulation, pass " << total_validation + 1 << " validation!\n" << std::endl;
+  return true;
+}
+
+struct VerifyResult {
+  double max_error = 0.0;
+  int first_failed_at = -1;
+  int failed_count = 0;
+};
+
+VerifyResult verify_y(const double *dy, const double *hy, int n) {
+  VerifyResult r;
+  for (int i = 0; i < n; ++i) {
+    const double d = std::fabs(dy[i] - hy[i]);
+    r.max_error = std::max(r.max_error, d);
+    const bool fail = (std::fabs(hy[i]) <= 1e-12) ? (d >= 1e-14) : (d / std::fabs(hy[i]) >= 1e-7);
+    if (fail) {
+      if (r.failed_count == 0) r.first_failed_at = i;
+      ++r.failed_count;
+    }
+  }
+  return r;
+}
+
+struct Options {
+  std::string path, format = "csr", strategy;
+  bool no_gpu = false, benchmark = false, stats = false;
+  double alpha = 1.0, beta = 1.0; // cli/main.cpp:95-96
+};
+
+bool parse_args(int argc, char **argv, Options &o) {
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto need = [&](std::string &dst) {
+      if (i + 1 >= argc) return false;
+      dst = argv[++i];
+      return true;
+    };
+    if (a == "-f" || a == "--format") {
+      if (!need(o.format)) return false;
+    } else if (a == "--strategy") {
+      if (!need(o.strategy)) return false;
+    } else if (a == "--no-gpu") {
+      o.no_gpu = true;
+    } else if (a == "--benchmark") {
+      o.benchmark = true;
+    } else if (a == "--print-stats") {
+      o.stats = true;
+    } else if (a == "--alpha" || a == "--beta") {
+      std::string s;
+      if (!need(s)) return false;
+      (a == "--alpha" ? o.alpha : o.beta) = std::atof(s.c_str());
+    } else if (!a.empty() && a[0] == '-') {
+      return false;
+    } else {
+      o.path = a;
+    }
+  }
+  return !o.path.empty() && (o.format == "csr" || o.format == "mtx" || o.format == "bin2");
+}
+
+HostCsr load(const Options &o) {
+  if (o.format == "csr") return spmv_cli::read_csr_text(o.path);
+  if (o.format == "bin2") return spmv_cli::read_bin2(o.path);
+  return spmv_cli::read_matrix_market(o.path);
+}
+
+struct DeviceData {
+  var_csr_desc<int, double> csr;
+  double *x = nullptr, *y = nullptr;
+};
+
+DeviceData stage(const HostCsr &A, const HostVectors &v) {
+  DeviceData d;
+  d.csr.rows = A.rows;
+  d.csr.cols = A.cols;
+  d.csr.nnz = A.nnz;
+  if (spmv_acc_stage_csr(A.rows, A.cols, A.nnz, A.rowptr.data(), A.colidx.data(), A.values.data(), v.x.data(), v.y0.data(),
+                         &d.csr.row_ptr, &d.csr.col_index, &d.csr.values, &d.x, &d.y) != 0) {
+    std::fprintf(stderr, "staging failed: %s\n", spmv_acc_last_error_string());
+    std::abort();
+  }
+  return d;
+}
+
+void unstage(DeviceData &d) {
+  spmv_acc_release_plans(d.csr.row_ptr);
+  spmv_acc_free_device(d.y);
+  spmv_acc_free_device(d.x);
+  spmv_acc_free_device(d.csr.values);
+  spmv_acc_free_device(d.csr.col_index);
+  spmv_acc_free_device(d.csr.row_ptr);
+}
+
+var_csr_desc<int, double> host_desc(HostCsr &A) {
+  var_csr_desc<int, double> h;
+  h.rows = A.rows;
+  h.cols = A.cols;
+  h.nnz = A.nnz;
+  h.row_ptr = A.rowptr.data();
+  h.col_index = A.colidx.data();
+  h.values = A.values.data();
+  return h;
+}
+
+int run_cli(const Options &o, HostCsr &A, HostVectors &v) {
+  HIP_CHECK(hipSetDevice(0));
+  DeviceData d = stage(A, v);
+  var_csr_desc<int, double> h = host_desc(A);
+  if (!o.strategy.empty() && spmv_acc_set_strategy(o.strategy.c_str()) != 0) {
+    std::fprintf(stderr, "unknown strategy %s\n", o.strategy.c_str());
+    return 2;
+  }
+  const size_t ybytes = sizeof(double) * static_cast<size_t>(A.rows);
+  for (int i = 0; i < 10; ++i) { // warm up GPU (cli/main.cpp:99-103)
+    HIP_CHECK(hipMemcpy(d.y, v.y0.data(), ybytes, hipMemcpyHostToDevice));
+    sparse_csr_spmv(operation_none, o.alpha, o.beta, h.as_const(), d.csr.as_const(), d.x, d.y);
+  }
+  HIP_CHECK(hipDeviceSynchronize());
+  const auto t0 = std::chrono::steady_clock::now();
+  sparse_csr_spmv(operation_none, o.alpha, o.beta, h.as_const(), d.csr.as_const(), d.x, d.y);
+  HIP_CHECK(hipDeviceSynchronize());
+  const auto t1 = std::chrono::steady_clock::now();
+  // result run (cli/main.cpp:116-118)
+  HIP_CHECK(hipMemcpy(d.y, v.y0.data(), ybytes, hipMemcpyHostToDevice));
+  sparse_csr_spmv(operation_none, o.alpha, o.beta, h.as_const(), d.csr.as_const(), d.x, d.y);
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpy(v.y_dev.data(), d.y, ybytes, hipMemcpyDeviceToHost));
+  host_spmv(o.alpha, o.beta, A, v.x.data(), v.y_ref.data());
+  const bool ok = verify(v.y_dev.data(), v.y_ref.data(), A.rows);
+  const double us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+  std::cout << o.path << " elapsed time:" << us << "(us)" << std::endl;
+  unstage(d);
+  return ok ? 0 : 1;
+}
+
+// CPU-side verification path alone: the device result is replaced by a second host evaluation with a different
+// summation order (right-to-left), so reader + vectors + host_spmv + verify are exercised without a GPU.
+int run_no_gpu(const Options &o, HostCsr &A, HostVectors &v) {
+  for (int i = 0; i < A.rows; ++i) {
+    double acc = 0;
+    for (int j = A.rowptr[i + 1] - 1; j >= A.rowptr[i]; --j) acc += A.values[j] * v.x[A.colidx[j]];
+    v.y_dev[i] = o.alpha * acc + o.beta * v.y0[i];
+  }
+  host_spmv(o.alpha, o.beta, A, v.x.data(), v.y_ref.data());
+  const bool ok = verify(v.y_dev.data(), v.y_ref.data(), A.rows);
+  std::cout << o.path << " rows:" << A.rows << " cols:" << A.cols << " nnz:" << A.nnz << " (no-gpu verification path)" << std::endl;
+  return ok ? 0 : 1;
+}
+
+// ---- benchmark mode: the reference harness' protocol and CSV schema -------------------------------------------------------
+void print_header() {
+  std::cout << "PERFORMANCE,matrix name,strategy name,rows,cols,nnz,nnz/row,GB/s(calc_time),GFLOPS(calc_time),"
+               "GB/s(total_time),GFLOPS(total_time),mid pre cost,mid calc cost,mid fixup(calc2) cost,mid destroy cost,"
+               "mid total cost,first_failed_at,failed_count,max_error"
+            << std::endl;
+}
+
+int run_benchmark(const Options &o, HostCsr &A, HostVectors &v) {
+  HIP_CHECK(hipSetDevice(0));
+  DeviceData d = stage(A, v);
+  const size_t ybytes = sizeof(double) * static_cast<size_t>(A.rows);
+  std::vector<double> ref = v.y0;
+  host_spmv(o.alpha, o.beta, A, v.x.data(), ref.data());
+  std::vector<std::string> names = {"default", "adaptive", "line", "vector_row", "line_enhance", "flat", "adaptive_plus"};
+  if (!o.strategy.empty()) names = {o.strategy};
+  print_header();
+  std::string mtx = o.path.substr(o.path.find_last_of('/') == std::string::npos ? 0 : o.path.find_last_of('/') + 1);
+  int rc = 0;
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  for (const auto &name : names) {
+    const int s = spmv_acc_parse_strategy(name.c_str());
+    if (s < 0) continue;
+    auto call = [&]() {
+      spmv_acc_csr_spmv_strategy(s, operation_none, o.alpha, o.beta, A.rows, A.cols, A.nnz, A.rowptr.data(), d.csr.row_ptr,
+                                 d.csr.col_index, d.csr.values, d.x, d.y);
+    };
+    // one-time plan cost (this library caches what the reference recomputes on every call)
+    spmv_acc_release_plans(d.csr.row_ptr);
+    HIP_CHECK(hipMemcpy(d.y, v.y0.data(), ybytes, hipMemcpyHostToDevice));
+    const auto p0 = std::chrono::steady_clock::now();
+    call();
+    HIP_CHECK(hipDeviceSynchronize());
+    const double first_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - p0).count();
+    for (int i = 0; i < 10; ++i) { // csr_spmv.hpp:49-63
+      HIP_CHECK(hipMemcpy(d.y, v.y0.data(), ybytes, hipMemcpyHostToDevice));
+      call();
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    double t[3];
+    for (int k = 0; k < 3; ++k) { // BENCHMARK_ARRAY_SIZE = 3, csr_spmv.hpp:67-74
+      HIP_CHECK(hipMemcpy(d.y, v.y0.data(), ybytes, hipMemcpyHostToDevice));
+      HIP_CHECK(hipEventRecord(e0, nullptr));
+      call();
+      HIP_CHECK(hipEventRecord(e1, nullptr));
+      HIP_CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      t[k] = 1000.0 * ms;
+    }
+    std::sort(t, t + 3);
+    const double calc = t[1], pre = 0.0, calc2 = 0.0, destroy = 0.0, total = pre + calc + calc2 + destroy;
+    HIP_CHECK(hipMemcpy(d.y, v.y0.data(), ybytes, hipMemcpyHostToDevice));
+    call();
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(v.y_dev.data(), d.y, ybytes, hipMemcpyDeviceToHost));
+    const VerifyResult vr = verify_y(v.y_dev.data(), ref.data(), A.rows);
+    if (vr.failed_count) rc = 1;
+    const double mem_bytes = 8.0 * (2.0 * A.rows + A.nnz) + 4.0 * (A.rows + 1.0 + A.nnz); // statistics_logger.cpp:43
+    const double gib = 1024.0 * 1024.0 * 1024.0;
+    std::cout << "PERFORMANCE," << mtx << "," << name << "," << A.rows << "," << A.cols << "," << A.nnz << ","
+              << (A.nnz + 0.0) / A.rows << "," << mem_bytes / gib / (calc / 1e6) << "," << 2.0 * A.nnz / calc / 1e3 << ","
+              << mem_bytes / gib / (total / 1e6) << "," << 2.0 * A.nnz / total / 1e3 << "," << pre << "," << calc << ","
+              << calc2 << "," << destroy << "," << total << "," << vr.first_failed_at << "," << vr.failed_count << ","
+              << vr.max_error << std::endl;
+    std::cout << "PLAN," << mtx << "," << name << ",first_call_us," << first_us << std::endl;
+  }
+  HIP_CHECK(hipEventDestroy(e0));
+  HIP_CHECK(hipEventDestroy(e1));
+  unstage(d);
+  return rc;
+}
+
+} // namespace
+
+int main(int argc, char **argv) {
+  Options o;
+  if (!parse_args(argc, argv, o)) {
+    std::cerr << "usage: spmv-cli <mtx_path> [-f|--format csr|mtx|bin2] [--strategy NAME] [--benchmark] [--no-gpu] [--print-stats] "
+                 "[--alpha A] [--beta B]\n";
+    return 2;
+  }
+  try {
+    HostCsr A = load(o);
+    if (o.stats) { // reader check: what was parsed, as exact sums
+      long long sc = 0, sr = 0;
+      long double sv = 0, sx = 0;
+      for (int c : A.colidx) sc += c;
+      for (int r : A.rowptr) sr += r;
+      for (double t : A.values) sv += t;
+      for (double t : A.x) sx += t;
+      std::printf("STATS rows=%d cols=%d nnz=%d sum_colidx=%lld sum_rowptr=%lld sum_values=%.17Lg sum_x=%.17Lg x_len=%zu\n", A.rows,
+                  A.cols, A.nnz, sc, sr, sv, sx, A.x.size());
+      return 0;
+    }
+    HostVectors v = make_vectors(A, o.format == "csr");
+    if (o.no_gpu) return run_no_gpu(o, A, v);
+    if (o.benchmark) return run_benchmark(o, A, v);
+    return run_cli(o, A, v);
+  } catch (const std::exception &e) {
+    std::cerr << "spmv-cli: " << e.what() << std::endl;
+    return 3;
+  }
+}

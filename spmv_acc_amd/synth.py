@@ -80,7 +80,7 @@ def rajat03_like(seed=0xC1):
     rng = np.random.default_rng(seed)
     m = n = 7602
     lens = 1 + rng.integers(1, 6, size=m)
-    lens[rng.integers(0, m, size=12)] = rng.integers(200, 1500, size=12)
+    lens[rng.integers(0, m, size=6)] = rng.integers(150, 600, size=6)  # total ~32.6 k nnz like rajat03
     rowptr, cols, vals = csr_from_row_lengths(lens, n, rng, locality=40, far_fraction=0.15)
     cols[rowptr[:-1]] = np.arange(m, dtype=np.int32)  # first entry of every row is the diagonal
     return rowptr, cols, vals

@@ -1,0 +1,151 @@
+"""CLI + matrix readers (SURVEY.md 8f 'next', rank 2-3): .csr text, bin2, MatrixMarket through spmv-cli.
+CPU tests use --print-stats / --no-gpu (BASELINE.json configs[0]: the CPU-side verification path);
+the GPU tests run the reference's CLI and benchmark protocols on the device."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from spmv_acc_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "spmv_acc_amd", "bin", "spmv-cli")
+
+
+@pytest.fixture(scope="module")
+def cli(hiplib):
+    if not os.path.exists(CLI):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return CLI
+
+
+def write_csr_text(path, rowptr, cols, vals, x, header="synthetic"):
+    with open(path, "w") as f:
+        f.write(header + "\n")
+        f.write(" ".join(repr(float(t)) for t in vals) + "\n")
+        f.write(" ".join(str(int(t)) for t in cols) + "\n")
+        f.write(" ".join(str(int(t)) for t in rowptr) + "\n")
+        f.write(" ".join(repr(float(t)) for t in x) + "\n")
+
+
+def write_bin2(path, rows, cols_n, rowptr, cols, vals, valtype=3):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<6i", 0x20211015, 2, valtype, rows, cols_n, len(cols)))
+        np.asarray(rowptr, dtype="<i4").tofile(f)
+        np.asarray(cols, dtype="<i4").tofile(f)
+        if valtype == 2:
+            np.asarray(vals, dtype="<i4").tofile(f)
+        elif valtype in (3, 4):
+            np.asarray(vals, dtype="<f8").tofile(f)
+
+
+def stats(cli, path, fmt):
+    r = subprocess.run([cli, path, "-f", fmt, "--print-stats"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    kv = dict(t.split("=") for t in r.stdout.split()[1:])
+    return {k: float(v) for k, v in kv.items()}
+
+
+def test_csr_text_reader(cli, tmp_path):
+    rowptr, cols, vals = synth.random_csr(300, 280, 6, seed=3, kind="powerlaw")
+    x = np.random.default_rng(1).standard_normal(280)
+    p = str(tmp_path / "a.csr")
+    write_csr_text(p, rowptr, cols, vals, x, header="any free-form text 1 2 3")
+    s = stats(cli, p, "csr")
+    assert (s["rows"], s["cols"], s["nnz"], s["x_len"]) == (300, 280, len(vals), 280)
+    assert s["sum_colidx"] == cols.astype(np.int64).sum() and s["sum_rowptr"] == rowptr.astype(np.int64).sum()
+    assert abs(s["sum_values"] - float(np.sum(vals.astype(np.longdouble)))) < 1e-9
+    assert abs(s["sum_x"] - float(np.sum(x.astype(np.longdouble)))) < 1e-9
+
+
+def test_bin2_reader_all_value_types(cli, tmp_path):
+    rowptr, cols, vals = synth.random_csr(200, 250, 5, seed=4)
+    for valtype, v, want in ((3, vals, vals.sum()), (2, np.arange(len(cols)) % 7 - 3, float((np.arange(len(cols)) % 7 - 3).sum())),
+                             (1, None, float(len(cols)))):
+        p = str(tmp_path / f"a{valtype}.bin2")
+        write_bin2(p, 200, 250, rowptr, cols, v, valtype)
+        s = stats(cli, p, "bin2")
+        assert (s["rows"], s["cols"], s["nnz"]) == (200, 250, len(cols))
+        assert s["sum_colidx"] == cols.astype(np.int64).sum()
+        assert abs(s["sum_values"] - want) < 1e-9, valtype
+    bad = str(tmp_path / "bad.bin2")
+    with open(bad, "wb") as f:
+        f.write(struct.pack("<6i", 0x12345678, 2, 3, 1, 1, 0))
+    r = subprocess.run([cli, bad, "-f", "bin2", "--print-stats"], capture_output=True, text=True)
+    assert r.returncode == 3 and "magic" in r.stderr  # fails loudly (the reference returns an empty matrix)
+
+
+def test_matrix_market_reader(cli, tmp_path):
+    p = str(tmp_path / "g.mtx")
+    with open(p, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n% comment\n3 4 5\n3 1 1.5\n1 2 -2.0\n1 1 4.0\n2 4 0.25\n3 3 7\n")
+    s = stats(cli, p, "mtx")
+    assert (s["rows"], s["cols"], s["nnz"]) == (3, 4, 5)
+    assert s["sum_rowptr"] == 0 + 2 + 3 + 5 and s["sum_colidx"] == 0 + 1 + 3 + 0 + 2 and s["sum_values"] == 10.75
+    p = str(tmp_path / "s.mtx")
+    with open(p, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n3 3 4\n1 1 2\n2 1 3\n3 1 -1\n3 3 5\n")
+    s = stats(cli, p, "mtx")  # off-diagonals mirrored: 4 + 2 entries
+    assert (s["nnz"], s["sum_values"]) == (6, 2 + 3 + 3 - 1 - 1 + 5)
+    p = str(tmp_path / "p.mtx")
+    with open(p, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate pattern general\n2 2 3\n1 1\n1 2\n2 2\n")
+    s = stats(cli, p, "mtx")
+    assert (s["nnz"], s["sum_values"]) == (3, 3.0)
+    r = subprocess.run([cli, p, "-f", "mtx", "--no-gpu"], capture_output=True, text=True)
+    assert r.returncode == 0 and "pass 2 validation" in r.stdout
+
+
+def test_config0_rajat03_like_cpu_verification_path(cli, tmp_path):
+    """BASELINE.json configs[0]: a rajat03-sized .csr file through spmv-cli's CPU-side verification path."""
+    rowptr, cols, vals = synth.rajat03_like()
+    x = synth.reference_rand_grid(7602, np.random.default_rng(0xC1))
+    p = str(tmp_path / "rajat03_like.csr")
+    write_csr_text(p, rowptr, cols, vals, x, header="rajat03-like 7602 7602")
+    r = subprocess.run([cli, p, "-f", "csr", "--no-gpu"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Congratulation, pass 7602 validation!" in r.stdout
+
+
+def test_cli_usage_errors(cli):
+    assert subprocess.run([cli], capture_output=True).returncode == 2
+    assert subprocess.run([cli, "/nonexistent.csr", "-f", "csr", "--no-gpu"], capture_output=True).returncode == 3
+    assert subprocess.run([cli, "x", "-f", "coo"], capture_output=True).returncode == 2
+
+
+@pytest.mark.gpu
+def test_cli_on_gpu_all_formats(cli, tmp_path):
+    """cli/main.cpp's protocol on the device: 10 warm-ups, timed run, verify against host_spmv."""
+    rowptr, cols, vals = synth.rajat03_like()
+    x = synth.reference_rand_grid(7602, np.random.default_rng(0xC1))
+    pc = str(tmp_path / "r.csr")
+    write_csr_text(pc, rowptr, cols, vals, x)
+    pb = str(tmp_path / "r.bin2")
+    write_bin2(pb, 7602, 7602, rowptr, cols, vals)
+    for path, fmt in ((pc, "csr"), (pb, "bin2")):
+        for strat in ("adaptive", "flat", "line_enhance", "default"):
+            r = subprocess.run([cli, path, "-f", fmt, "--strategy", strat], capture_output=True, text=True)
+            assert r.returncode == 0, (fmt, strat, r.stdout, r.stderr)
+            assert "Congratulation, pass 7602 validation!" in r.stdout and "elapsed time:" in r.stdout
+
+
+@pytest.mark.gpu
+def test_benchmark_mode_csv(cli, tmp_path):
+    rowptr, cols, vals = synth.random_csr(60000, 60000, 9, seed=8, kind="powerlaw")
+    p = str(tmp_path / "b.bin2")
+    write_bin2(p, 60000, 60000, rowptr, cols, vals)
+    r = subprocess.run([cli, p, "-f", "bin2", "--benchmark"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("PERFORMANCE,")]
+    header = lines[0].split(",")
+    assert header[:7] == ["PERFORMANCE", "matrix name", "strategy name", "rows", "cols", "nnz", "nnz/row"]
+    assert header[-3:] == ["first_failed_at", "failed_count", "max_error"] and len(header) == 19
+    rows = [l.split(",") for l in lines[1:]]
+    assert {r_[2] for r_ in rows} >= {"default", "adaptive", "flat", "line_enhance"}
+    for r_ in rows:
+        assert len(r_) == 19 and int(r_[3]) == 60000 and int(r_[5]) == len(cols)
+        assert int(r_[-2]) == 0 and int(r_[-3]) == -1 and float(r_[12]) > 0  # verified, timed
