@@ -61,6 +61,7 @@ Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
     {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
     {"rowblock_guard", 1, 1},  // imbalance probe + flat rescue for the row-block family
+    {"plus_ref_vec", 0, 0},    // 1: row-block-plus analysis with the reference's VEC_SIZE pick
     {"flat_npt", 8, 8},        // non-zeros per lane per flat tile: 4, 8 or 16 (tile = 256 lanes x this)
 };
 } // namespace
@@ -196,6 +197,13 @@ int plus_pick_vec(int m, int nnz) {
   return v;
 }
 
+int plus_pick_vec_tuned(int m, int nnz) {
+  const long long avg = (m > 0) ? static_cast<long long>(nnz) / m : 0;
+  int v = 1;
+  while (v < 64 && static_cast<long long>(v) * 2 * 5 <= avg) v <<= 1; // largest pow2 <= avg/5: cap*avg >= 1.25*MIN_NNZ
+  return v;
+}
+
 // Host form of the row-block preprocessing pass.  Written as "where does the block that starts at
 // row s end" so the device form can later replace the scan by searches; the emitted tables are
 // bit-identical to the reference's single-pass loop (tests pin this against oracle/_ref).
@@ -254,15 +262,19 @@ struct Plan {
   // row-block-plus
   int plus_blocks = -1;
   int plus_vec = 0;
+  bool plus_has_long = false;
   int *d_pbp = nullptr;
   int *d_pfbr = nullptr;
   double *d_ppartial = nullptr;
+  void *d_pblk = nullptr;
 
   void free_device() {
     free_flat();
     if (d_pbp) (void)hipFree(d_pbp);
     if (d_pfbr) (void)hipFree(d_pfbr);
     if (d_ppartial) (void)hipFree(d_ppartial);
+    if (d_pblk) (void)hipFree(d_pblk);
+    d_pblk = nullptr;
     d_ppartial = nullptr;
     d_pbp = d_pfbr = nullptr;
   }
@@ -388,7 +400,18 @@ bool ensure_flat(Plan &p, hipStream_t stream) {
 }
 
 bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
-  if (p.plus_blocks >= 0) return true;
+  const int want_vec = get_tunable("plus_ref_vec") ? plus_pick_vec(p.A.m, p.A.nnz) : plus_pick_vec_tuned(p.A.m, p.A.nnz);
+  if (p.plus_blocks >= 0 && p.plus_vec == want_vec) return true;
+  if (p.plus_blocks >= 0) { // analysis parameters changed (measurement switch): rebuild
+    if (p.d_pbp) (void)hipFree(p.d_pbp);
+    if (p.d_pfbr) (void)hipFree(p.d_pfbr);
+    if (p.d_ppartial) (void)hipFree(p.d_ppartial);
+    if (p.d_pblk) (void)hipFree(p.d_pblk);
+    p.d_pblk = nullptr;
+    p.d_pbp = p.d_pfbr = nullptr;
+    p.d_ppartial = nullptr;
+    p.plus_blocks = -1;
+  }
   const int m = p.A.m;
   std::vector<int> staged;
   const int *hrp = host_view(h_rowptr);
@@ -399,9 +422,15 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
       return false;
     hrp = staged.data();
   }
-  const int vec = plus_pick_vec(m, p.A.nnz);
+  // The reference picks VEC_SIZE = pow2 >= avg/2 (plus_pick_vec), which caps a block at 512/VEC rows and closes
+  // most blocks far below MIN_NNZ_PER_BLOCK (avg 98 -> 8 rows, ~800 nnz per 512-lane block).  The analysis is
+  // the same function; only its row cap is chosen so that cap * avg >= 1.25 * MIN_NNZ (blocks then close on nnz).
+  const int tuned = get_tunable("plus_ref_vec") ? plus_pick_vec(m, p.A.nnz) : plus_pick_vec_tuned(m, p.A.nnz);
+  const int vec = tuned;
   std::vector<int> bp, fbr;
   const int blocks = plus_analyze_host(m, kPlusMinNnz, kPlusThreads, vec, hrp, bp, fbr);
+  bool has_long = false;
+  for (int f : fbr) has_long = has_long || (f & 1);
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pbp), sizeof(int) * bp.size()), "hipMalloc plus bp")) return false;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pfbr), sizeof(int) * fbr.size()), "hipMalloc plus fbr"))
     return false;
@@ -411,9 +440,11 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
   if (!hip_ok(hipMemcpy(p.d_pbp, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice), "copy plus bp")) return false;
   if (!hip_ok(hipMemcpy(p.d_pfbr, fbr.data(), sizeof(int) * fbr.size(), hipMemcpyHostToDevice), "copy plus fbr"))
     return false;
-  (void)stream;
+  if (!hip_ok(hipMalloc(&p.d_pblk, 16 * (static_cast<size_t>(blocks) + 1)), "hipMalloc plus digest")) return false;
+  launch_plus_digest(stream, p.A, p.d_pbp, p.d_pfbr, blocks, p.d_pblk);
   p.plus_vec = vec;
   p.plus_blocks = blocks;
+  p.plus_has_long = has_long;
   return true;
 }
 
@@ -531,8 +562,8 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   }
   case kAdaptivePlus:
     if (!ensure_plus(*p, h_rowptr, st)) return;
-    launch_plus(st, p->A, p->d_pbp, p->d_pfbr, p->plus_blocks, p->plus_vec, p->d_ppartial, alpha, beta, dx, dy);
-    launch_plus_fixup(st, p->A, p->d_pbp, p->d_pfbr, p->plus_blocks, p->d_ppartial, alpha, beta, dy);
+    launch_plus(st, p->A, p->d_pbp, p->d_pfbr, p->d_pblk, p->plus_blocks, p->plus_has_long, p->d_ppartial, alpha, beta, dx,
+                dy);
     break;
   default:
     set_error(kErrUnknownStrategy, "unknown strategy id");

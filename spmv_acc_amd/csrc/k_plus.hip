@@ -8,10 +8,14 @@
 //   * :123-205 (line_enhance_plus): normal block = line-enhance body on the block's rows.
 //   * :55-121 (line_enhance_plus_shared_block): long-row block = block-wide sum + atomicAdd(y, alpha*s)
 //     with beta dropped (the comment at :112-116 says so).
-// Differences here: general beta; long-row slices write one partial per block and a fix-up kernel
-// adds them in block order (deterministic, no atomics); the slice index is derived from the
-// break-point table itself, so a long row that shares its first block with leading empty rows keeps
-// its first slice (the reference computes the slice from first_block_of_row alone and skips it).
+// Differences here: general beta; the analysis runs with the reference's (THREADS 256, R 2, MIN_NNZ 1024) instance
+// so a block has at most 256 rows and -- typically -- 1024 + one row of non-zeros: one 2048-product round with one
+// vector of lanes per row, the lanes-per-row chosen per block from its row count; a plan-time 16-B digest per
+// block replaces the kernel's dependent bp -> first_block_of_row -> rowptr loads;
+// long-row slices write one partial per block and a fix-up kernel adds them in block order (deterministic, no
+// atomics); the slice index is derived from the break-point table itself, so a long row that shares its
+// first block with leading empty rows keeps its first slice (the reference computes the slice from
+// first_block_of_row alone and skips it).
 #include "device_utils.hpp"
 #include "kernels.hpp"
 #include "tile_stage.hpp"
@@ -21,8 +25,9 @@ namespace {
 
 using namespace dev;
 
-constexpr int kPlusNpt = 8;
-constexpr int kPlusTile = kPlusThreads * kPlusNpt; // 4096 products = 32 KB
+constexpr int kPlusNpt = kNnzPerThread;       // 2048-product tile: a typical block (MIN_NNZ 1024 + one row) needs ONE round
+constexpr int kPlusTile = kThreads * kPlusNpt;
+constexpr int kPlusMaxRows = kPlusThreads;     // the analysis never gives a block more rows than this (= kThreads)
 
 // first block whose break point is row r, given the analysis' first_block_of_row entry for r
 __device__ __forceinline__ int first_block_at_row(const int *__restrict__ bp, int fbr_r, int r) {
@@ -30,62 +35,92 @@ __device__ __forceinline__ int first_block_at_row(const int *__restrict__ bp, in
   return (bp[f] == r) ? f : f + 1;
 }
 
-template <int VEC, bool ALIGNED>
-__global__ __launch_bounds__(kPlusThreads) void plus_kernel(int m, int nnz, double alpha, double beta,
-                                                            const int *__restrict__ bp, const int *__restrict__ fbr,
-                                                            const int *__restrict__ rp, const int *__restrict__ ci,
-                                                            const double *__restrict__ v,
-                                                            const double *__restrict__ x, double *__restrict__ y,
-                                                            double *__restrict__ partial) {
-  __shared__ double lds[kPlusTile];
-  const int g = blockIdx.x;
+// Plan-time digest of (break_points, first_block_of_row, rowptr): one 16-B record per block so the SpMV
+// kernel starts streaming after ONE scalar load instead of the bp -> first_block_of_row -> rowptr chain.
+//   normal block : {row_begin, row_end, nnz_begin, nnz_end}
+//   long-row slice: {row, -1, slice_begin, slice_end}
+__global__ __launch_bounds__(256) void plus_digest_kernel(int m, int nblocks, const int *__restrict__ bp,
+                                                          const int *__restrict__ fbr, const int *__restrict__ rp,
+                                                          int4v *__restrict__ blk) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nblocks) return;
   const int row_begin = bp[g];
   int row_end = bp[g + 1];
   row_end = row_end < m ? row_end : m;
   const int flag = fbr[row_begin];
-
+  int4v rec;
   if ((flag & 1) == 0) {
-    // ---- normal block: rows [row_begin, row_end), at most kPlusThreads / VEC of them ----
-    const int s0 = rp[row_begin];
-    const int s1 = rp[row_end];
-    const int lane = threadIdx.x % VEC;
-    const int row = row_begin + threadIdx.x / VEC;
-    const bool live = row < row_end;
+    rec.x = row_begin;
+    rec.y = row_end;
+    rec.z = rp[row_begin];
+    rec.w = rp[row_end];
+  } else {
+    const int r = row_begin;
+    const int idx = g - first_block_at_row(bp, flag, r);
+    const int c0 = rp[r] + idx * kPlusLongChunk;
+    const bool last = bp[g + 1] != r;
+    rec.x = r;
+    rec.y = -1;
+    rec.z = c0;
+    rec.w = last ? rp[r + 1] : c0 + kPlusLongChunk;
+  }
+  blk[g] = rec;
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, double alpha, double beta,
+                                                        const int4v *__restrict__ blk, const int *__restrict__ rp,
+                                                        const int *__restrict__ ci, const double *__restrict__ v,
+                                                        const double *__restrict__ x, double *__restrict__ y,
+                                                        double *__restrict__ partial) {
+  __shared__ double lds[kPlusTile];
+  __shared__ double row_acc[kPlusMaxRows];
+  const int g = blockIdx.x;
+  const int4v rec = blk[g]; // wave-uniform: one scalar 16-B load
+  const int row_begin = rec.x;
+
+  if (rec.y >= 0) {
+    // ---- normal block: rows [row_begin, row_end), at most kThreads of them ----
+    const int nrows = rec.y - row_begin;
+    const int s0 = rec.z;
+    const int s1 = rec.w;
+    const int a0 = s0 & ~3;
+    int w = 64; // lanes per row: as many as the block's row count leaves room for
+    while (w > 1 && nrows * w > kThreads) w >>= 1;
+    const int lane = threadIdx.x & (w - 1);
+    const int vec_id = threadIdx.x / w;
+    const int row = row_begin + vec_id;
+    const bool live = vec_id < nrows;
     int r0 = 0, r1 = 0;
     if (live) {
       r0 = rp[row];
       r1 = rp[row + 1];
     }
     double acc = 0.0;
-    for (int off = s0 & ~3; off < s1; off += kPlusTile) {
-      stage_products<kPlusThreads, kPlusNpt, ALIGNED>(lds, off, s1, nnz, ci, v, x);
+    for (int off = a0; off < s1; off += kPlusTile) {
+      stage_products<kThreads, kPlusNpt, ALIGNED>(lds, off, s1, nnz, ci, v, x);
       __syncthreads();
       const int lo = (r0 > off ? r0 : off) - off;
       const int hi = (r1 < off + kPlusTile ? r1 : off + kPlusTile) - off;
-      for (int j = lo + lane; j < hi; j += VEC) acc += lds[j];
-      if (off + kPlusTile < s1) __syncthreads();
+      for (int j = lo + lane; j < hi; j += w) acc += lds[j];
+      if (off + kPlusTile < s1) __syncthreads(); // the next round overwrites the tile
     }
-    acc = group_sum<VEC>(acc);
+    acc = group_sum_dyn(acc, w);
     if (live && lane == 0) store_y(y, row, alpha, beta, acc);
   } else {
-    // ---- slice of the long row `row_begin` ----
-    const int r = row_begin;
-    const int idx = g - first_block_at_row(bp, flag, r);
-    const int c0 = rp[r] + idx * kPlusLongChunk;
-    const bool last = bp[g + 1] != r;
-    const int c1 = last ? rp[r + 1] : c0 + kPlusLongChunk;
+    // ---- slice [rec.z, rec.w) of the long row `row_begin` ----
     double s = 0.0;
-    for (int j = c0 + threadIdx.x; j < c1; j += kPlusThreads) {
+    for (int j = rec.z + threadIdx.x; j < rec.w; j += kThreads) {
       s += load_stream(v + j) * x[load_stream(ci + j)];
     }
     s = group_sum<64>(s);
-    constexpr int kWaves = kPlusThreads / kWave;
-    if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x / kWave] = s;
+    constexpr int kWaves = kThreads / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) row_acc[threadIdx.x / kWave] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
       double total = 0.0;
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w) total += lds[w];
+      for (int i = 0; i < kWaves; ++i) total += row_acc[i];
       partial[g] = total;
     }
   }
@@ -108,39 +143,28 @@ __global__ __launch_bounds__(256) void plus_fixup_kernel(int m, int nblocks, dou
   store_y(y, r, alpha, beta, s);
 }
 
-template <int VEC>
-void launch_vec(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, double *partial,
-                double alpha, double beta, const double *x, double *y) {
-  if (A.aligned16) {
-    hipLaunchKernelGGL((plus_kernel<VEC, true>), dim3(nblocks), dim3(kPlusThreads), 0, stream, A.m, A.nnz, alpha, beta,
-                       bp, fbr, A.rp, A.ci, A.v, x, y, partial);
-  } else {
-    hipLaunchKernelGGL((plus_kernel<VEC, false>), dim3(nblocks), dim3(kPlusThreads), 0, stream, A.m, A.nnz, alpha,
-                       beta, bp, fbr, A.rp, A.ci, A.v, x, y, partial);
-  }
-}
-
 } // namespace
 
-void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, int vec,
-                 double *partial, double alpha, double beta, const double *x, double *y) {
+void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, void *blk) {
   if (nblocks <= 0) return;
-  switch (vec) {
-  case 1: launch_vec<1>(stream, A, bp, fbr, nblocks, partial, alpha, beta, x, y); break;
-  case 2: launch_vec<2>(stream, A, bp, fbr, nblocks, partial, alpha, beta, x, y); break;
-  case 4: launch_vec<4>(stream, A, bp, fbr, nblocks, partial, alpha, beta, x, y); break;
-  case 8: launch_vec<8>(stream, A, bp, fbr, nblocks, partial, alpha, beta, x, y); break;
-  case 16: launch_vec<16>(stream, A, bp, fbr, nblocks, partial, alpha, beta, x, y); break;
-  case 32: launch_vec<32>(stream, A, bp, fbr, nblocks, partial, alpha, beta, x, y); break;
-  default: launch_vec<64>(stream, A, bp, fbr, nblocks, partial, alpha, beta, x, y); break;
-  }
+  hipLaunchKernelGGL(plus_digest_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, A.m, nblocks, bp, fbr, A.rp,
+                     static_cast<int4v *>(blk));
 }
 
-void launch_plus_fixup(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks,
-                       const double *partial, double alpha, double beta, double *y) {
+void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, const void *blk, int nblocks,
+                 bool has_long_rows, double *partial, double alpha, double beta, const double *x, double *y) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(plus_fixup_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, A.m, nblocks, alpha, beta,
-                     bp, fbr, partial, y);
+  if (A.aligned16) {
+    hipLaunchKernelGGL((plus_kernel<true>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, alpha, beta,
+                       static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial);
+  } else {
+    hipLaunchKernelGGL((plus_kernel<false>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, alpha, beta,
+                       static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial);
+  }
+  if (has_long_rows) {
+    hipLaunchKernelGGL(plus_fixup_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, A.m, nblocks, alpha, beta,
+                       bp, fbr, partial, y);
+  }
 }
 
 } // namespace spmv_acc

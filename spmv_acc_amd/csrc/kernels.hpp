@@ -23,9 +23,9 @@ constexpr int kThreads = 256;             // 4 waves per workgroup
 constexpr int kNnzPerThread = 8;          // two 4-wide steps per lane per round
 constexpr int kTile = kThreads * kNnzPerThread; // 2048 products = 16 KB of LDS per workgroup
 constexpr int kFlatStride = kTile;        // nnz per flat block (the reference uses R*THREADS = 1024)
-constexpr int kPlusThreads = 512;         // row-block-plus geometry mirrors the reference's analysis
-constexpr int kPlusR = 2;                 // (csr_adaptive_plus_spmv.cpp:135-138): THREADS 512, R 2,
-constexpr int kPlusMinNnz = 2 * kPlusR * kPlusThreads; // MIN_NNZ_PER_BLOCK 2048
+constexpr int kPlusThreads = 256;         // row-block-plus ANALYSIS geometry: the reference's (THREADS 256, R 2,
+constexpr int kPlusR = 2;                 // MIN_NNZ 1024) instance (csr_adaptive_plus_spmv.cpp:195-202)
+constexpr int kPlusMinNnz = 2 * kPlusR * kPlusThreads; // MIN_NNZ_PER_BLOCK 1024
 constexpr int kPlusLongChunk = 2 * kPlusMinNnz;        // NN_EI * MIN_NNZ_PER_BLOCK non-zeros per long-row block
 
 // Smallest power of two >= avg/8, clamped to [1, 64]: lanes cooperating on one row.
@@ -66,11 +66,12 @@ struct FlatPlan {
 void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                  double *y);
 
-// row-block-plus family: row blocks from the adaptive-plus analysis (break_points + first_block_of_row).
-void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, int vec,
-                 double *partial, double alpha, double beta, const double *x, double *y);
-void launch_plus_fixup(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks,
-                       const double *partial, double alpha, double beta, double *y);
+// row-block-plus family: row blocks from the adaptive-plus analysis (break_points + first_block_of_row,
+// made with threads_per_block = kPlusThreads).  launch_plus_digest (once per plan) packs one 16-B record per
+// block into blk (nblocks * 16 bytes); the long-row fix-up runs only when the analysis found long rows.
+void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, void *blk);
+void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, const void *blk, int nblocks,
+                 bool has_long_rows, double *partial, double alpha, double beta, const double *x, double *y);
 
 // dst = src over `bytes` (16-B granules) with the kernels' streaming load shape: the copy ceiling probe
 void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes);

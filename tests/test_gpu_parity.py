@@ -352,3 +352,39 @@ def test_cxx_api_driver(torch_dev, oracle, tmp_path):
     assert ys.shape[0] >= 8
     for k, y in enumerate(ys):
         check(oracle, y, 1.0, 1.0, rowptr, cols, vals, x, y0, ("cxx", k))
+
+
+# ---- streams and graphs ---------------------------------------------------------------------------------------------------
+def test_stream_and_hipgraph_capture(torch_dev, oracle, hiplib):
+    """Steady-state calls are launches only: they run on a caller-chosen stream and capture into a hipGraph
+    (plan built beforehand); replays reproduce the eager result bit for bit."""
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(50000, 50000, 11, seed=31, kind="powerlaw")
+    m = n = 50000
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(2)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+    side = torch.cuda.Stream()
+    try:
+        hiplib.spmv_acc_set_stream(side.cuda_stream)
+        for strat in ("adaptive", "flat", "line_enhance", "adaptive_plus"):
+            dy = dy0.clone()
+            with torch.cuda.stream(side):
+                spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat, h_rowptr=rowptr)  # builds the plan
+            side.synchronize()
+            eager = dy.cpu().numpy()
+            assert oracle.scaled_error(eager, ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, strat
+            static_y = dy0.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, static_y, strategy=strat, h_rowptr=rowptr)
+            for _ in range(3):
+                static_y.copy_(dy0)
+                g.replay()
+                torch.cuda.synchronize()
+                assert np.array_equal(static_y.cpu().numpy(), eager), strat
+    finally:
+        hiplib.spmv_acc_set_stream(None)
+        spmv_acc_amd.release_plans(drp)
