@@ -96,6 +96,12 @@ int spmv_acc_break_points_len(int nnz, int stride); /* flat.cpp:35-38: ceil(nnz/
 int spmv_acc_adaptive_plus_analyze(int m, int min_nnz_per_block, int threads_per_block, int vec_size,
                                    const int *h_rowptr, int *h_break_points, int bp_cap,
                                    int *h_first_block_of_row);
+/* The same analysis on the DEVICE (new): next-block search per row + pointer jumping + scan; bit-identical tables,
+ * no host rowptr and no PCIe traffic.  d_break_points: device, bp_cap ints; d_first_block_of_row: device, m + 1 ints.
+ * Returns the number of row blocks, -1 if bp_cap is too small, -2 on error.  Synchronises the library stream. */
+int spmv_acc_adaptive_plus_analyze_device(int m, int min_nnz_per_block, int threads_per_block, int vec_size,
+                                          const int *d_rowptr, int *d_break_points, int bp_cap,
+                                          int *d_first_block_of_row);
 int spmv_acc_adaptive_plus_vec(int m, int nnz); /* csr_adaptive_plus_spmv.cpp:139-165 */
 
 /* ---- strategy pickers (host logic, no GPU needed) --------------------------------------------------------------

@@ -35,7 +35,7 @@ C_ABI_SYMBOLS = (
     "spmv_acc_free_device", "spmv_acc_release_plans", "spmv_acc_cached_plans", "spmv_acc_query_plan",
     "spmv_acc_set_stream", "spmv_acc_get_stream", "spmv_acc_last_error", "spmv_acc_last_error_string",
     "spmv_acc_clear_error", "spmv_acc_time_spmv", "spmv_acc_version", "spmv_acc_set_tunable",
-    "spmv_acc_get_tunable", "spmv_acc_reset_tunables", "spmv_acc_time_spmv_total", "spmv_acc_copy_ceiling_gbs",
+    "spmv_acc_get_tunable", "spmv_acc_reset_tunables", "spmv_acc_time_spmv_total", "spmv_acc_copy_ceiling_gbs", "spmv_acc_adaptive_plus_analyze_device",
 )
 
 _lib = None
@@ -81,6 +81,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_break_points_len.argtypes = [ci, ci]
     lib.spmv_acc_adaptive_plus_analyze.argtypes = [ci, ci, ci, ci, vp, vp, ci, vp]
     lib.spmv_acc_adaptive_plus_vec.argtypes = [ci, ci]
+    lib.spmv_acc_adaptive_plus_analyze_device.argtypes = [ci, ci, ci, ci, vp, vp, ci, vp]
     lib.spmv_acc_adaptive_branch.argtypes = [ci, ci, ci, ci, ci]
     lib.spmv_acc_partition_rows.argtypes = [ci, ci, ci, vp, vp]
     lib.spmv_acc_stage_csr.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp] + [ctypes.POINTER(vp)] * 5
@@ -189,6 +190,24 @@ def adaptive_plus_analyze(h_rowptr, m: int, min_nnz_per_block: int = 2048, threa
     if blocks < 0:
         raise SpmvAccError(f"adaptive_plus_analyze failed ({blocks})")
     return blocks, bp[: blocks + 1].copy(), fbr
+
+
+def adaptive_plus_analyze_device(rowptr, m: int, nnz: int, min_nnz_per_block: int = 1024, threads_per_block: int = 256,
+                                 vec_size: int = 1):
+    """Device form of the same pass (GPU int32 rowptr).  Returns (blocks, break_points, first_block_of_row) as GPU tensors."""
+    import torch
+
+    lib = load_library()
+    _require_cuda(rowptr)
+    cap = m + 2 + nnz // (2 * min_nnz_per_block)
+    bp = torch.empty(cap, dtype=torch.int32, device=rowptr.device)
+    fbr = torch.empty(m + 1, dtype=torch.int32, device=rowptr.device)
+    blocks = lib.spmv_acc_adaptive_plus_analyze_device(m, min_nnz_per_block, threads_per_block, vec_size, _ptr(rowptr),
+                                                       _ptr(bp), cap, _ptr(fbr))
+    if blocks < 0:
+        _check(lib)
+        raise SpmvAccError(f"adaptive_plus_analyze_device failed ({blocks})")
+    return blocks, bp[: blocks + 1], fbr
 
 
 def adaptive_branch(m: int, h_rowptr) -> int:

@@ -130,6 +130,18 @@ int spmv_acc_adaptive_plus_analyze(int m, int min_nnz_per_block, int threads_per
   return blocks;
 }
 
+int spmv_acc_adaptive_plus_analyze_device(int m, int min_nnz_per_block, int threads_per_block, int vec_size,
+                                          const int *d_rowptr, int *d_break_points, int bp_cap,
+                                          int *d_first_block_of_row) {
+  if (m < 0 || !d_rowptr || !d_break_points || !d_first_block_of_row || min_nnz_per_block <= 0 || vec_size <= 0 ||
+      threads_per_block < vec_size || bp_cap < 1) {
+    set_error(kErrBadArgument, "spmv_acc_adaptive_plus_analyze_device: bad argument");
+    return -2;
+  }
+  return plus_analyze_device(m, min_nnz_per_block, threads_per_block, vec_size, d_rowptr, d_break_points, bp_cap,
+                             d_first_block_of_row);
+}
+
 int spmv_acc_adaptive_plus_vec(int m, int nnz) { return plus_pick_vec(m, nnz); }
 
 int spmv_acc_adaptive_branch(int m, int rp_quarter, int rp_half, int rp_three_quarter, int rp_last) {

@@ -61,7 +61,8 @@ Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
     {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
     {"rowblock_guard", 1, 1},  // imbalance probe + flat rescue for the row-block family
-    {"plus_ref_vec", 0, 0},    // 1: row-block-plus analysis with the reference's VEC_SIZE pick
+    {"plus_ref_vec", 0, 0},
+    {"plus_host_analysis", 0, 0}, // 1: run the row-block analysis on the host (the reference's form)    // 1: row-block-plus analysis with the reference's VEC_SIZE pick
     {"flat_npt", 8, 8},        // non-zeros per lane per flat tile: 4, 8 or 16 (tile = 256 lanes x this)
 };
 } // namespace
@@ -399,6 +400,65 @@ bool ensure_flat(Plan &p, hipStream_t stream) {
   return true;
 }
 
+// Device form of the analysis into freshly allocated tables.  Returns the block count, or -1.
+int analyze_on_device(hipStream_t stream, const int *d_rp, int m, int min_nnz, int threads, int vec, int **d_bp_out,
+                      int **d_fbr_out) {
+  void *ws = nullptr;
+  int *d_total = nullptr;
+  int blocks = -1;
+  *d_bp_out = *d_fbr_out = nullptr;
+  if (!hip_ok(hipMalloc(&ws, plus_analyze_device_workspace_bytes(m)), "hipMalloc analysis workspace")) return -1;
+  if (hip_ok(hipMalloc(reinterpret_cast<void **>(&d_total), sizeof(int)), "hipMalloc analysis total")) {
+    if (!plus_analyze_device_count(stream, d_rp, m, min_nnz, threads, vec, ws, d_total)) {
+      set_error(kErrHip, "device row-block analysis: scan failed");
+    } else {
+      int total = 0;
+      if (hip_ok(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, stream), "read block count") &&
+          hip_ok(hipStreamSynchronize(stream), "sync analysis") &&
+          hip_ok(hipMalloc(reinterpret_cast<void **>(d_bp_out), sizeof(int) * (static_cast<size_t>(total) + 1)),
+                 "hipMalloc plus bp") &&
+          hip_ok(hipMalloc(reinterpret_cast<void **>(d_fbr_out), sizeof(int) * (static_cast<size_t>(m) + 1)),
+                 "hipMalloc plus fbr")) {
+        plus_analyze_device_emit(stream, d_rp, m, min_nnz, ws, *d_bp_out, *d_fbr_out);
+        if (hip_ok(hipStreamSynchronize(stream), "sync analysis emit")) blocks = total; // ws is freed below
+      }
+    }
+    (void)hipFree(d_total);
+  }
+  (void)hipFree(ws);
+  if (blocks < 0) {
+    if (*d_bp_out) (void)hipFree(*d_bp_out);
+    if (*d_fbr_out) (void)hipFree(*d_fbr_out);
+    *d_bp_out = *d_fbr_out = nullptr;
+  }
+  return blocks;
+}
+
+} // namespace
+
+int plus_analyze_device(int m, int min_nnz, int threads, int vec, const int *d_rowptr, int *d_bp, int bp_cap,
+                        int *d_fbr) {
+  int *tbp = nullptr, *tfbr = nullptr;
+  hipStream_t st = get_stream();
+  const int blocks = analyze_on_device(st, d_rowptr, m, min_nnz, threads, vec, &tbp, &tfbr);
+  if (blocks < 0) return -2;
+  int rc = blocks;
+  if (blocks + 1 > bp_cap) {
+    rc = -1;
+  } else if (!hip_ok(hipMemcpyAsync(d_bp, tbp, sizeof(int) * (static_cast<size_t>(blocks) + 1), hipMemcpyDeviceToDevice, st),
+                     "copy bp") ||
+             !hip_ok(hipMemcpyAsync(d_fbr, tfbr, sizeof(int) * (static_cast<size_t>(m) + 1), hipMemcpyDeviceToDevice, st),
+                     "copy fbr") ||
+             !hip_ok(hipStreamSynchronize(st), "sync")) {
+    rc = -2;
+  }
+  (void)hipFree(tbp);
+  (void)hipFree(tfbr);
+  return rc;
+}
+
+namespace {
+
 bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
   const int want_vec = get_tunable("plus_ref_vec") ? plus_pick_vec(p.A.m, p.A.nnz) : plus_pick_vec_tuned(p.A.m, p.A.nnz);
   if (p.plus_blocks >= 0 && p.plus_vec == want_vec) return true;
@@ -412,39 +472,55 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
     p.d_ppartial = nullptr;
     p.plus_blocks = -1;
   }
+  // The reference picks VEC_SIZE = pow2 >= avg/2 (plus_pick_vec), which caps a block at THREADS/VEC rows and closes
+  // most blocks far below MIN_NNZ_PER_BLOCK.  The analysis is the same function; only its row cap is chosen so
+  // that cap * avg >= 1.25 * MIN_NNZ (blocks then close on their non-zero count).
   const int m = p.A.m;
-  std::vector<int> staged;
-  const int *hrp = host_view(h_rowptr);
-  if (!hrp) {
-    staged.resize(static_cast<size_t>(m) + 1);
-    if (!hip_ok(hipMemcpy(staged.data(), p.A.rp, sizeof(int) * (static_cast<size_t>(m) + 1), hipMemcpyDeviceToHost),
-                "stage rowptr for analysis"))
+  const int vec = want_vec;
+  int blocks = -1;
+  if (get_tunable("plus_host_analysis")) {
+    // host form (the reference's): needs rowptr on the host
+    std::vector<int> staged;
+    const int *hrp = host_view(h_rowptr);
+    if (!hrp) {
+      staged.resize(static_cast<size_t>(m) + 1);
+      if (!hip_ok(hipMemcpy(staged.data(), p.A.rp, sizeof(int) * (static_cast<size_t>(m) + 1), hipMemcpyDeviceToHost),
+                  "stage rowptr for analysis"))
+        return false;
+      hrp = staged.data();
+    }
+    std::vector<int> bp, fbr;
+    blocks = plus_analyze_host(m, kPlusMinNnz, kPlusThreads, vec, hrp, bp, fbr);
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pbp), sizeof(int) * bp.size()), "hipMalloc plus bp")) return false;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pfbr), sizeof(int) * fbr.size()), "hipMalloc plus fbr"))
       return false;
-    hrp = staged.data();
+    // blocking copies: the host vectors die at scope exit (this runs once per matrix)
+    if (!hip_ok(hipMemcpy(p.d_pbp, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice), "copy plus bp")) return false;
+    if (!hip_ok(hipMemcpy(p.d_pfbr, fbr.data(), sizeof(int) * fbr.size(), hipMemcpyHostToDevice), "copy plus fbr"))
+      return false;
+  } else {
+    // device form: no host rowptr, no PCIe traffic beyond one int
+    blocks = analyze_on_device(stream, p.A.rp, m, kPlusMinNnz, kPlusThreads, vec, &p.d_pbp, &p.d_pfbr);
+    if (blocks < 0) return false;
   }
-  // The reference picks VEC_SIZE = pow2 >= avg/2 (plus_pick_vec), which caps a block at 512/VEC rows and closes
-  // most blocks far below MIN_NNZ_PER_BLOCK (avg 98 -> 8 rows, ~800 nnz per 512-lane block).  The analysis is
-  // the same function; only its row cap is chosen so that cap * avg >= 1.25 * MIN_NNZ (blocks then close on nnz).
-  const int tuned = get_tunable("plus_ref_vec") ? plus_pick_vec(m, p.A.nnz) : plus_pick_vec_tuned(m, p.A.nnz);
-  const int vec = tuned;
-  std::vector<int> bp, fbr;
-  const int blocks = plus_analyze_host(m, kPlusMinNnz, kPlusThreads, vec, hrp, bp, fbr);
-  bool has_long = false;
-  for (int f : fbr) has_long = has_long || (f & 1);
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pbp), sizeof(int) * bp.size()), "hipMalloc plus bp")) return false;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pfbr), sizeof(int) * fbr.size()), "hipMalloc plus fbr"))
-    return false;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_ppartial), sizeof(double) * (blocks + 1)), "hipMalloc plus partial"))
-    return false;
-  // blocking copies: the host vectors die at scope exit (this runs once per matrix)
-  if (!hip_ok(hipMemcpy(p.d_pbp, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice), "copy plus bp")) return false;
-  if (!hip_ok(hipMemcpy(p.d_pfbr, fbr.data(), sizeof(int) * fbr.size(), hipMemcpyHostToDevice), "copy plus fbr"))
+  int *d_flag = nullptr;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_ppartial), sizeof(double) * (static_cast<size_t>(blocks) + 1)),
+              "hipMalloc plus partial"))
     return false;
   if (!hip_ok(hipMalloc(&p.d_pblk, 16 * (static_cast<size_t>(blocks) + 1)), "hipMalloc plus digest")) return false;
-  launch_plus_digest(stream, p.A, p.d_pbp, p.d_pfbr, blocks, p.d_pblk);
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d_flag), sizeof(int)), "hipMalloc plus flag")) return false;
+  int has_long = 0;
+  bool ok = hip_ok(hipMemsetAsync(d_flag, 0, sizeof(int), stream), "memset plus flag");
+  if (ok) {
+    launch_plus_digest(stream, p.A, p.d_pbp, p.d_pfbr, blocks, p.d_pblk, d_flag);
+    ok = hip_ok(hipMemcpyAsync(&has_long, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream), "read plus flag") &&
+         hip_ok(hipStreamSynchronize(stream), "sync plus digest");
+  }
+  (void)hipFree(d_flag);
+  if (!ok) return false;
   p.plus_vec = vec;
   p.plus_blocks = blocks;
-  p.plus_has_long = has_long;
+  p.plus_has_long = has_long != 0;
   return true;
 }
 

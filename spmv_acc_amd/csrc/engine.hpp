@@ -80,6 +80,10 @@ int adaptive_branch(int m, const RowptrSamples &s);
 // break_points gets blocks+1 entries, first_block_of_row m+1 entries.  Returns the block count.
 int plus_analyze_host(int m, int min_nnz_per_block, int threads_per_block, int vec_size, const int *host_row_ptr,
                       std::vector<int> &break_points, std::vector<int> &first_block_of_row);
+// Device form of the same analysis into caller-provided device tables (d_bp: bp_cap entries, d_fbr: m + 1).
+// Returns the block count, -1 if bp_cap is too small, -2 on a HIP error.  Synchronises the library stream.
+int plus_analyze_device(int m, int min_nnz_per_block, int threads_per_block, int vec_size, const int *d_rowptr,
+                        int *d_break_points, int bp_cap, int *d_first_block_of_row);
 int plus_pick_vec(int m, int nnz);       // csr_adaptive_plus_spmv.cpp:139-165
 int plus_pick_vec_tuned(int m, int nnz); // row cap chosen so blocks close on MIN_NNZ_PER_BLOCK, not on the cap
 

@@ -41,7 +41,7 @@ __device__ __forceinline__ int first_block_at_row(const int *__restrict__ bp, in
 //   long-row slice: {row, -1, slice_begin, slice_end}
 __global__ __launch_bounds__(256) void plus_digest_kernel(int m, int nblocks, const int *__restrict__ bp,
                                                           const int *__restrict__ fbr, const int *__restrict__ rp,
-                                                          int4v *__restrict__ blk) {
+                                                          int4v *__restrict__ blk, int *__restrict__ has_long) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= nblocks) return;
   const int row_begin = bp[g];
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void plus_digest_kernel(int m, int nblocks, co
     rec.y = -1;
     rec.z = c0;
     rec.w = last ? rp[r + 1] : c0 + kPlusLongChunk;
+    *has_long = 1; // idempotent store
   }
   blk[g] = rec;
 }
@@ -145,10 +146,11 @@ __global__ __launch_bounds__(256) void plus_fixup_kernel(int m, int nblocks, dou
 
 } // namespace
 
-void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, void *blk) {
+void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, void *blk,
+                        int *d_has_long) {
   if (nblocks <= 0) return;
   hipLaunchKernelGGL(plus_digest_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, A.m, nblocks, bp, fbr, A.rp,
-                     static_cast<int4v *>(blk));
+                     static_cast<int4v *>(blk), d_has_long);
 }
 
 void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, const void *blk, int nblocks,

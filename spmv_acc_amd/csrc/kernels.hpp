@@ -69,9 +69,19 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
 // row-block-plus family: row blocks from the adaptive-plus analysis (break_points + first_block_of_row,
 // made with threads_per_block = kPlusThreads).  launch_plus_digest (once per plan) packs one 16-B record per
 // block into blk (nblocks * 16 bytes); the long-row fix-up runs only when the analysis found long rows.
-void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, void *blk);
+// *d_has_long (pre-zeroed) is set to 1 if any block is a long-row slice.
+void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, void *blk,
+                        int *d_has_long);
 void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, const void *blk, int nblocks,
                  bool has_long_rows, double *partial, double alpha, double beta, const double *x, double *y);
+
+// Device form of the row-block analysis (k_analyze.hip).  count: enqueue steps 1-3, d_total[0] = block count once
+// the stream has run; emit: write break_points (total + 1 entries) and first_block_of_row (m + 1 entries).
+size_t plus_analyze_device_workspace_bytes(int m);
+bool plus_analyze_device_count(hipStream_t stream, const int *rp, int m, int min_nnz, int threads_per_block,
+                               int vec_size, void *workspace, int *d_total);
+void plus_analyze_device_emit(hipStream_t stream, const int *rp, int m, int min_nnz, const void *workspace, int *d_bp,
+                              int *d_fbr);
 
 // dst = src over `bytes` (16-B granules) with the kernels' streaming load shape: the copy ceiling probe
 void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes);

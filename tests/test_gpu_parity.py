@@ -388,3 +388,59 @@ def test_stream_and_hipgraph_capture(torch_dev, oracle, hiplib):
     finally:
         hiplib.spmv_acc_set_stream(None)
         spmv_acc_amd.release_plans(drp)
+
+
+# ---- device form of the row-block analysis -----------------------------------------------------------------------------------
+def test_device_analysis_matches_reference_goldens(torch_dev):
+    """k_analyze.hip against tables produced by the REFERENCE's own csr_adaptive_plus_analyze.cpp (bit-exact)."""
+    torch = torch_dev
+    g = np.load(os.path.join(GOLD, "analysis_cases.npz"))
+    for name in g["names"]:
+        rp = g[f"{name}__rowptr"]
+        m, nnz = rp.size - 1, int(rp[-1])
+        drp = dev(torch, rp)
+        for k, (threads, vec, min_nnz) in enumerate(g["params"]):
+            blocks, bp, fbr = spmv_acc_amd.adaptive_plus_analyze_device(drp, m, nnz, int(min_nnz), int(threads), int(vec))
+            assert np.array_equal(bp.cpu().numpy(), g[f"{name}__{k}__bp"]), (name, k)
+            assert np.array_equal(fbr.cpu().numpy(), g[f"{name}__{k}__fbr"]), (name, k)
+            assert blocks == g[f"{name}__{k}__bp"].size - 1
+
+
+def test_device_analysis_matches_host_form_random(torch_dev, oracle):
+    torch = torch_dev
+    rng = np.random.default_rng(17)
+    for trial in range(60):
+        m = int(rng.integers(1, 60000))
+        kind = trial % 5
+        if kind == 0:
+            lens = rng.integers(0, 12, m)
+        elif kind == 1:
+            lens = np.minimum((rng.pareto(1.2, m) * 3).astype(np.int64), 30000)
+        elif kind == 2:
+            lens = rng.integers(0, 3, m)
+            lens[rng.integers(0, m, 5)] = rng.integers(2000, 40000, 5)
+        elif kind == 3:
+            lens = rng.integers(0, 700, min(m, 5000))
+        else:
+            lens = np.zeros(m, dtype=np.int64)
+            lens[rng.integers(0, m, max(1, m // 50))] = rng.integers(1, 9000, max(1, m // 50))
+        m = lens.size
+        rp = np.zeros(m + 1, dtype=np.int32)
+        np.cumsum(lens, out=rp[1:])
+        drp = dev(torch, rp)
+        for threads, vec, min_nnz in ((256, 1, 1024), (256, 4, 1024), (512, 16, 2048), (1024, 64, 4096)):
+            want = oracle.adaptive_plus_analyze(rp, min_nnz, threads, vec)
+            blocks, bp, fbr = spmv_acc_amd.adaptive_plus_analyze_device(drp, m, int(rp[-1]), min_nnz, threads, vec)
+            assert blocks == want[0], (trial, threads, vec)
+            assert np.array_equal(bp.cpu().numpy(), want[1]), (trial, threads, vec)
+            assert np.array_equal(fbr.cpu().numpy(), want[2]), (trial, threads, vec)
+
+
+def test_device_analysis_full_size(torch_dev, oracle, hardesty):
+    """8.2 M rows: device tables against the host form."""
+    H = hardesty
+    rp = H["rp"].cpu().numpy()
+    want = oracle.adaptive_plus_analyze(rp, 1024, 256, 1)
+    blocks, bp, fbr = spmv_acc_amd.adaptive_plus_analyze_device(H["rp"], H["m"], H["nnz"], 1024, 256, 1)
+    assert blocks == want[0]
+    assert np.array_equal(bp.cpu().numpy(), want[1]) and np.array_equal(fbr.cpu().numpy(), want[2])
