@@ -48,6 +48,70 @@ __global__ __launch_bounds__(kThreads) void vector_row_kernel(int m, int row_spl
   if (live && lane == 0) store_y(y, row, alpha, beta, s);
 }
 
+// One 64-lane wavefront per row, for rows of hundreds of non-zeros (reference role: hip-wf-row/, KERNEL_STRATEGY
+// WF_ROW -- src/acc/hip-wf-row/spmv_hip.cpp:18-34, one 4/8-byte load per lane per step there).  A lane owns 4
+// consecutive non-zeros per step (one 16-B colindex load, two 16-B value loads) and two steps are in flight, so a
+// wave keeps 512 non-zeros = 6 KB of stream + 512 gathers outstanding; the row start is aligned down to a multiple
+// of 4 and the (at most 3 + 3) foreign elements at the row's ends are masked out of the sum.
+template <bool ALIGNED>
+__global__ __launch_bounds__(kThreads) void wave_row_kernel(int m, int nnz, double alpha, double beta,
+                                                            const int *__restrict__ rp, const int *__restrict__ ci,
+                                                            const double *__restrict__ v,
+                                                            const double *__restrict__ x, double *__restrict__ y) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long row_ll = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave;
+  const bool live = row_ll < m; // wave-uniform
+  const int row = static_cast<int>(row_ll);
+  double s = 0.0;
+  if (live) {
+    const int j0 = rp[row];
+    const int j1 = rp[row + 1];
+    if (ALIGNED) {
+      for (int base = (j0 & ~3) + 4 * lane; base < j1; base += 2 * 4 * kWave) {
+        const int ia = base, ib = base + 4 * kWave;
+        const bool fa = ia + 4 <= nnz;             // whole 16-B group inside the arrays
+        const bool fb = ib < j1 && ib + 4 <= nnz;
+        int4v ca, cb;
+        double2v a0, a1, b0, b1;
+        if (fa) {
+          ca = load_stream_i4(ci + ia);
+          a0 = load_stream_d2(v + ia);
+          a1 = load_stream_d2(v + ia + 2);
+        }
+        if (fb) {
+          cb = load_stream_i4(ci + ib);
+          b0 = load_stream_d2(v + ib);
+          b1 = load_stream_d2(v + ib + 2);
+        }
+        if (fa) {
+          const double p0 = a0.x * x[ca.x], p1 = a0.y * x[ca.y], p2 = a1.x * x[ca.z], p3 = a1.y * x[ca.w];
+          s += (ia + 0 >= j0 && ia + 0 < j1) ? p0 : 0.0;
+          s += (ia + 1 >= j0 && ia + 1 < j1) ? p1 : 0.0;
+          s += (ia + 2 >= j0 && ia + 2 < j1) ? p2 : 0.0;
+          s += (ia + 3 >= j0 && ia + 3 < j1) ? p3 : 0.0;
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (ia + e >= j0 && ia + e < j1) s += v[ia + e] * x[ci[ia + e]];
+        }
+        if (fb) {
+          const double p0 = b0.x * x[cb.x], p1 = b0.y * x[cb.y], p2 = b1.x * x[cb.z], p3 = b1.y * x[cb.w];
+          s += (ib + 0 < j1) ? p0 : 0.0;
+          s += (ib + 1 < j1) ? p1 : 0.0;
+          s += (ib + 2 < j1) ? p2 : 0.0;
+          s += (ib + 3 < j1) ? p3 : 0.0;
+        } else if (ib < j1) {
+          for (int e = 0; e < 4; ++e)
+            if (ib + e < j1) s += v[ib + e] * x[ci[ib + e]];
+        }
+      }
+    } else {
+      for (int j = j0 + lane; j < j1; j += kWave) s += load_stream(v + j) * x[load_stream(ci + j)];
+    }
+  }
+  s = group_sum<64>(s);
+  if (live && lane == 0) store_y(y, row, alpha, beta, s);
+}
+
 __global__ __launch_bounds__(kThreads) void scale_y_kernel(int m, double beta, double *__restrict__ y) {
   const long long i = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
   if (i < m) y[i] = (beta == 0.0) ? 0.0 : beta * y[i];
@@ -92,6 +156,18 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
   if (nb0 + nb1 == 0) return;
   hipLaunchKernelGGL(vector_row_kernel, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1,
                      alpha, beta, A.rp, A.ci, A.v, x, y);
+}
+
+void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y) {
+  if (A.m <= 0) return;
+  const int grid = ceil_div_ll(A.m, kThreads / kWave);
+  if (A.aligned16) {
+    hipLaunchKernelGGL((wave_row_kernel<true>), dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci,
+                       A.v, x, y);
+  } else {
+    hipLaunchKernelGGL((wave_row_kernel<false>), dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp,
+                       A.ci, A.v, x, y);
+  }
 }
 
 void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes) {

@@ -22,7 +22,6 @@ struct CsrDev {
 constexpr int kThreads = 256;             // 4 waves per workgroup
 constexpr int kNnzPerThread = 8;          // two 4-wide steps per lane per round
 constexpr int kTile = kThreads * kNnzPerThread; // 2048 products = 16 KB of LDS per workgroup
-constexpr int kFlatStride = kTile;        // nnz per flat block (the reference uses R*THREADS = 1024)
 constexpr int kPlusThreads = 256;         // row-block-plus ANALYSIS geometry: the reference's (THREADS 256, R 2,
 constexpr int kPlusR = 2;                 // MIN_NNZ 1024) instance (csr_adaptive_plus_spmv.cpp:195-202)
 constexpr int kPlusMinNnz = 2 * kPlusR * kPlusThreads; // MIN_NNZ_PER_BLOCK 1024
@@ -35,6 +34,9 @@ int pick_vec_width(int m, int nnz);
 // Rows [0, row_split) use width w0, rows [row_split, m) use width w1 (row_split = m: one width).
 void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w0, int w1, double alpha, double beta,
                        const double *x, double *y);
+
+// wavefront-per-row for long rows: 4 consecutive non-zeros per lane per step (16-B loads), two steps in flight.
+void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y);
 
 // line-enhance family: THREADS/vec consecutive rows per workgroup, non-zeros streamed through an
 // LDS tile in rounds.  vec in {1,2,4,8,16,32,64}.
