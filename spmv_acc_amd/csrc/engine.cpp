@@ -60,6 +60,7 @@ struct Tunable {
 Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
     {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
+    {"rowblock_target", 1900, 1900}, // products a row block should bring to its 2048-product tile
     {"rowblock_guard", 1, 1},  // imbalance probe + flat rescue for the row-block family
     {"plus_ref_vec", 0, 0},
     {"plus_host_analysis", 0, 0}, // 1: run the row-block analysis on the host (the reference's form)    // 1: row-block-plus analysis with the reference's VEC_SIZE pick
@@ -256,6 +257,7 @@ struct Plan {
   RowptrSamples samples;
   // row-block family: -1 unknown, 1 balanced, 0 some workgroup would need too many LDS rounds
   int rowblock_ok = -1;
+  int rowblock_rpb = 0;
   int max_block_nnz = 0;
   // flat
   int flat_tiles = -1;
@@ -532,13 +534,14 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
 
 // Once per matrix: would any fixed row block have to stream more than kRowblockMaxRounds tiles?
 // (power-law matrices: R-MAT hub rows put millions of non-zeros into one workgroup.)
-bool probe_rowblock(Plan &p, int vec, hipStream_t st) {
-  if (p.rowblock_ok >= 0) return true;
+bool probe_rowblock(Plan &p, int rpb, hipStream_t st) {
+  if (p.rowblock_ok >= 0 && p.rowblock_rpb == rpb) return true;
+  p.rowblock_rpb = rpb;
   int *d_max = nullptr;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d_max), sizeof(int)), "hipMalloc probe")) return false;
   bool ok = hip_ok(hipMemsetAsync(d_max, 0, sizeof(int), st), "memset probe");
   if (ok) {
-    launch_max_block_nnz(st, p.A.rp, p.A.m, kThreads / vec, d_max);
+    launch_max_block_nnz(st, p.A.rp, p.A.m, rpb, d_max);
     int h = 0;
     ok = hip_ok(hipMemcpyAsync(&h, d_max, sizeof(int), hipMemcpyDeviceToHost, st), "read probe") &&
          hip_ok(hipStreamSynchronize(st), "sync probe");
@@ -546,7 +549,7 @@ bool probe_rowblock(Plan &p, int vec, hipStream_t st) {
       p.max_block_nnz = h;
       // balanced enough = the heaviest block needs few LDS rounds AND is not far above the average block
       // (a block that fits one tile is always fine)
-      const long long nblocks = (static_cast<long long>(p.A.m) + kThreads / vec - 1) / (kThreads / vec);
+      const long long nblocks = (static_cast<long long>(p.A.m) + rpb - 1) / rpb;
       const long long avg_block = nblocks > 0 ? p.A.nnz / nblocks : 0;
       const bool few_rounds = h <= kRowblockMaxRounds * kTile;
       const bool near_avg = h <= kTile || h <= 4 * avg_block;
@@ -561,13 +564,18 @@ bool probe_rowblock(Plan &p, int vec, hipStream_t st) {
 // few LDS rounds, otherwise the same tile machinery cut by non-zeros (flat) so hub rows are shared
 // by many workgroups instead of serialising one.
 bool run_rowblock(hipStream_t st, Plan &p, double alpha, double beta, const double *x, double *y) {
+  int vec = 1, rpb = kThreads;
+  pick_rowblock_shape(p.A.m, p.A.nnz, get_tunable("rowblock_target"), &vec, &rpb);
   const int forced = get_tunable("rowblock_vec");
-  const int vec = forced > 0 ? forced : pick_vec_width(p.A.m, p.A.nnz);
+  if (forced > 0) {
+    vec = forced;
+    rpb = kThreads / forced;
+  }
   if (get_tunable("rowblock_guard")) {
-    if (!probe_rowblock(p, vec, st)) return false;
+    if (!probe_rowblock(p, rpb, st)) return false;
     if (p.rowblock_ok == 0) return run_flat(st, p, alpha, beta, x, y);
   }
-  launch_rowblock_stream(st, p.A, vec, get_tunable("xcd_remap") != 0, alpha, beta, x, y);
+  launch_rowblock_stream(st, p.A, vec, rpb, get_tunable("xcd_remap") != 0, alpha, beta, x, y);
   return true;
 }
 

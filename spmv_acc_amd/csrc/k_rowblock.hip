@@ -26,29 +26,30 @@ namespace {
 using namespace dev;
 
 template <int VEC, bool ALIGNED>
-__global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nnz, int nblocks, int xcd_remap,
+__global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nnz, int nblocks, int rpb, int xcd_remap,
                                                                    double alpha, double beta,
                                                                    const int *__restrict__ rp,
                                                                    const int *__restrict__ ci,
                                                                    const double *__restrict__ v,
                                                                    const double *__restrict__ x,
                                                                    double *__restrict__ y) {
-  constexpr int RPB = kThreads / VEC;
+  // rpb rows per workgroup, rpb <= kThreads / VEC (not necessarily a power of two: it is chosen so that
+  // rpb * average row length fills most of one LDS tile)
   __shared__ double lds[kTile];
 
   int b = blockIdx.x;
   if (xcd_remap) b = xcd_contiguous_block(b, nblocks);
 
-  const long long base_ll = static_cast<long long>(b) * RPB;
+  const long long base_ll = static_cast<long long>(b) * rpb;
   const int row_base = static_cast<int>(base_ll);
-  const int row_end = (base_ll + RPB < m) ? row_base + RPB : m;
+  const int row_end = (base_ll + rpb < m) ? row_base + rpb : m;
   // wave-uniform: the non-zero range of the whole block
   const int s0 = rp[row_base];
   const int s1 = rp[row_end];
 
   const int lane = threadIdx.x % VEC;
   const int row = row_base + threadIdx.x / VEC;
-  const bool live = row < row_end;
+  const bool live = row < row_end; // lanes beyond rpb * VEC only help staging
   int r0 = 0, r1 = 0;
   if (live) {
     r0 = rp[row];
@@ -89,18 +90,18 @@ __global__ __launch_bounds__(256) void max_block_nnz_kernel(const int *__restric
 }
 
 template <int VEC>
-void launch_vec(hipStream_t stream, const CsrDev &A, bool xcd, double alpha, double beta, const double *x,
+void launch_vec(hipStream_t stream, const CsrDev &A, int rpb, bool xcd, double alpha, double beta, const double *x,
                 double *y) {
-  constexpr int RPB = kThreads / VEC;
-  const int nblocks = static_cast<int>((static_cast<long long>(A.m) + RPB - 1) / RPB);
+  if (rpb < 1 || rpb > kThreads / VEC) rpb = kThreads / VEC;
+  const int nblocks = static_cast<int>((static_cast<long long>(A.m) + rpb - 1) / rpb);
   if (nblocks == 0) return;
   const int remap = (xcd && nblocks >= 64) ? 1 : 0;
   if (A.aligned16) {
     hipLaunchKernelGGL((rowblock_stream_kernel<VEC, true>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,
-                       nblocks, remap, alpha, beta, A.rp, A.ci, A.v, x, y);
+                       nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y);
   } else {
     hipLaunchKernelGGL((rowblock_stream_kernel<VEC, false>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,
-                       nblocks, remap, alpha, beta, A.rp, A.ci, A.v, x, y);
+                       nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y);
   }
 }
 
@@ -113,17 +114,30 @@ void launch_max_block_nnz(hipStream_t stream, const int *rp, int m, int rows_per
                      nblocks, d_out);
 }
 
-void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, bool xcd_remap, double alpha, double beta,
-                            const double *x, double *y) {
+void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, int rows_per_block, bool xcd_remap,
+                            double alpha, double beta, const double *x, double *y) {
   switch (vec) {
-  case 1: launch_vec<1>(stream, A, xcd_remap, alpha, beta, x, y); break;
-  case 2: launch_vec<2>(stream, A, xcd_remap, alpha, beta, x, y); break;
-  case 4: launch_vec<4>(stream, A, xcd_remap, alpha, beta, x, y); break;
-  case 8: launch_vec<8>(stream, A, xcd_remap, alpha, beta, x, y); break;
-  case 16: launch_vec<16>(stream, A, xcd_remap, alpha, beta, x, y); break;
-  case 32: launch_vec<32>(stream, A, xcd_remap, alpha, beta, x, y); break;
-  default: launch_vec<64>(stream, A, xcd_remap, alpha, beta, x, y); break;
+  case 1: launch_vec<1>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  case 2: launch_vec<2>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  case 4: launch_vec<4>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  case 8: launch_vec<8>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  case 16: launch_vec<16>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  case 32: launch_vec<32>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  default: launch_vec<64>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
   }
+}
+
+// rows per workgroup so that rows * (nnz/m) ~ target products, and the widest lane group that still gives
+// every row of the workgroup its own vector
+void pick_rowblock_shape(int m, int nnz, int target, int *vec, int *rows_per_block) {
+  const double avg = m > 0 ? static_cast<double>(nnz) / m : 0.0;
+  long long rpb = avg > 0.0 ? static_cast<long long>(target / avg) : kThreads;
+  if (rpb < 1) rpb = 1;
+  if (rpb > kThreads) rpb = kThreads;
+  int v = 1;
+  while (v < 64 && static_cast<long long>(v) * 2 * rpb <= kThreads) v <<= 1;
+  *vec = v;
+  *rows_per_block = static_cast<int>(rpb);
 }
 
 } // namespace spmv_acc

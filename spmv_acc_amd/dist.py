@@ -75,16 +75,16 @@ class RowShardedSpmv:
                               strategy=self.strategy, h_rowptr=self.h_rowptr)
 
     def step(self, alpha: float, beta: float, x, y_prev=None, group=None, overlap: bool = True):
-        """One sharded SpMV.  ``y_prev`` (m_local values) is this rank's slice of the old y when beta != 0.
+        """One sharded SpMV.  ``y_prev`` (m_local values) is this rank's slice of the old y when beta != 0
+        (None: iterate in place on the step's y buffer, see ``set_y``).
         With ``overlap`` the allgather is left in flight; call ``wait()`` (or the next ``step``) to retire it."""
         import torch.distributed as dist
 
         buf = self.y_local[self._k & 1]
         self._k += 1
-        if beta != 0.0:
-            if y_prev is None:
-                raise ValueError("beta != 0 needs this rank's slice of y")
+        if beta != 0.0 and y_prev is not None:
             buf[: self.m_local].copy_(y_prev[: self.m_local])
+        # beta != 0 with y_prev None: the buffer's current content is the old y slice (in-place iteration)
         if self.m_local > 0:
             self.local_spmv(alpha, beta, x, buf)
         self.wait()  # at most one allgather in flight: y_full is written by it
@@ -96,6 +96,11 @@ class RowShardedSpmv:
         if not overlap:
             self.wait()
         return work
+
+    def set_y(self, y_slice):
+        """Seed both y buffers with this rank's slice of y (for in-place iteration with beta != 0)."""
+        for b in self.y_local:
+            b[: self.m_local].copy_(y_slice[: self.m_local])
 
     def wait(self):
         if self._pending is not None:
