@@ -61,6 +61,7 @@ Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
     {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
     {"rowblock_target", 1900, 1900}, // products a row block should bring to its 2048-product tile
+    {"early_y", 1, 1},         // row-block kernel: load the old y before the tile instead of after it
     {"rowblock_guard", 1, 1},  // imbalance probe + flat rescue for the row-block family
     {"plus_ref_vec", 0, 0},
     {"plus_host_analysis", 0, 0}, // 1: run the row-block analysis on the host (the reference's form)    // 1: row-block-plus analysis with the reference's VEC_SIZE pick
@@ -575,7 +576,8 @@ bool run_rowblock(hipStream_t st, Plan &p, double alpha, double beta, const doub
     if (!probe_rowblock(p, rpb, st)) return false;
     if (p.rowblock_ok == 0) return run_flat(st, p, alpha, beta, x, y);
   }
-  launch_rowblock_stream(st, p.A, vec, rpb, get_tunable("xcd_remap") != 0, alpha, beta, x, y);
+  launch_rowblock_stream(st, p.A, vec, rpb, (get_tunable("xcd_remap") ? 1 : 0) | (get_tunable("early_y") ? 2 : 0), alpha, beta,
+                         x, y);
   return true;
 }
 
@@ -614,8 +616,6 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   switch (strategy) {
   case kDefault:
   case kLight:
-    launch_vector_row(st, p->A, m, pick_vec_width(m, p->A.nnz), 1, alpha, beta, dx, dy);
-    break;
   case kVectorRow:
     launch_vector_row(st, p->A, m, classic_vec(avg), 1, alpha, beta, dx, dy);
     break;

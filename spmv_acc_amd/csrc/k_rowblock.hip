@@ -26,7 +26,7 @@ namespace {
 using namespace dev;
 
 template <int VEC, bool ALIGNED>
-__global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nnz, int nblocks, int rpb, int xcd_remap,
+__global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nnz, int nblocks, int rpb, int flags,
                                                                    double alpha, double beta,
                                                                    const int *__restrict__ rp,
                                                                    const int *__restrict__ ci,
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   __shared__ double lds[kTile];
 
   int b = blockIdx.x;
-  if (xcd_remap) b = xcd_contiguous_block(b, nblocks);
+  if (flags & 1) b = xcd_contiguous_block(b, nblocks);
 
   const long long base_ll = static_cast<long long>(b) * rpb;
   const int row_base = static_cast<int>(base_ll);
@@ -55,6 +55,11 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
     r0 = rp[row];
     r1 = rp[row + 1];
   }
+  // the old y is needed only at the very end: ask for it now so its latency hides behind the whole tile
+  const bool writer = live && lane == 0;
+  double y_old = 0.0;
+  const bool early_y = (flags & 2) && beta != 0.0;
+  if (early_y && writer) y_old = y[row];
 
   double acc = 0.0;
   // tile origin aligned down so 16-B loads stay aligned; the (at most 3) extra leading products are never read
@@ -67,7 +72,10 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
     if (off + kTile < s1) __syncthreads(); // next round overwrites the tile
   }
   acc = group_sum<VEC>(acc);
-  if (live && lane == 0) store_y(y, row, alpha, beta, acc);
+  if (writer) {
+    if (early_y) y[row] = alpha * acc + beta * y_old;
+    else store_y(y, row, alpha, beta, acc);
+  }
 }
 
 // Largest number of non-zeros any workgroup of `rpb` consecutive rows would own (plan-time imbalance probe).
@@ -90,12 +98,12 @@ __global__ __launch_bounds__(256) void max_block_nnz_kernel(const int *__restric
 }
 
 template <int VEC>
-void launch_vec(hipStream_t stream, const CsrDev &A, int rpb, bool xcd, double alpha, double beta, const double *x,
+void launch_vec(hipStream_t stream, const CsrDev &A, int rpb, int xcd, double alpha, double beta, const double *x,
                 double *y) {
   if (rpb < 1 || rpb > kThreads / VEC) rpb = kThreads / VEC;
   const int nblocks = static_cast<int>((static_cast<long long>(A.m) + rpb - 1) / rpb);
   if (nblocks == 0) return;
-  const int remap = (xcd && nblocks >= 64) ? 1 : 0;
+  const int remap = ((xcd & 1) && nblocks >= 64 ? 1 : 0) | (xcd & 2);
   if (A.aligned16) {
     hipLaunchKernelGGL((rowblock_stream_kernel<VEC, true>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,
                        nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y);
@@ -114,7 +122,7 @@ void launch_max_block_nnz(hipStream_t stream, const int *rp, int m, int rows_per
                      nblocks, d_out);
 }
 
-void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, int rows_per_block, bool xcd_remap,
+void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, int rows_per_block, int xcd_remap,
                             double alpha, double beta, const double *x, double *y) {
   switch (vec) {
   case 1: launch_vec<1>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;

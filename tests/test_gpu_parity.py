@@ -444,3 +444,68 @@ def test_device_analysis_full_size(torch_dev, oracle, hardesty):
     blocks, bp, fbr = spmv_acc_amd.adaptive_plus_analyze_device(H["rp"], H["m"], H["nnz"], 1024, 256, 1)
     assert blocks == want[0]
     assert np.array_equal(bp.cpu().numpy(), want[1]) and np.array_equal(fbr.cpu().numpy(), want[2])
+
+
+# ---- the other BASELINE workload families --------------------------------------------------------------------------------------
+def test_rmat_power_law_parity(torch_dev, oracle):
+    """configs[3] family at a size the oracle finishes in a second: R-MAT scale 18 (hub rows of tens of thousands of
+    non-zeros, empty rows), every hot strategy against the oracle."""
+    torch = torch_dev
+    m, n, nnz, rp, ci, v = synth.rmat_torch(18, device="cuda", seed=0xC4)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    x = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    y0 = torch.rand(m, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    hrp, hci, hv, hx, hy0 = (t.cpu().numpy() for t in (rp, ci, v, x, y0))
+    assert np.diff(hrp).max() > 10_000 and np.diff(hrp).min() == 0
+    ref = oracle.host_spmv(1.0, 1.0, hrp, hci, hv, hx, hy0)
+    for strat in spmv_acc_amd.HOT_STRATEGIES:
+        y = y0.clone()
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
+        torch.cuda.synchronize()
+        err = oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 1.0, hrp, hci, hv, hx, hy0)
+        assert err <= SCALED_TOL, (strat, err)
+        assert oracle.verify_y(y.cpu().numpy(), ref)[2] == 0, strat
+    info = spmv_acc_amd.query_plan(rp, m)
+    assert info["flat_tiles"] > 0  # the balance probe sent line_enhance / adaptive to the nnz-cut tiles
+    spmv_acc_amd.release_plans(rp)
+
+
+def test_banded_shard_closed_form(torch_dev):
+    """configs[4] family: a 4 M-row shard of the banded matrix in the middle of a 32 M-row problem (global column
+    ids).  With x = 1 every interior row sums to sum_off sign/(1+|off|), known in closed form."""
+    torch = torch_dev
+    rows, total, first = 4_000_000, 32_000_000, 12_000_000
+    rp, ci, v = synth.banded_torch(rows, first_row=first, total_rows=total, device="cuda")
+    nnz = int(rp[-1].item())
+    assert nnz == 8 * rows and int(ci.max().item()) == first + rows - 1 + 3
+    x = torch.ones(total, dtype=torch.float64, device="cuda")
+    offs = np.arange(-4, 4)
+    r = np.arange(first, first + 8)
+    want8 = np.array([np.sum(np.where((ri + offs) % 2 == 0, 1.0, -1.0) / (1.0 + np.abs(offs))) for ri in r])
+    for strat in ("adaptive", "flat", "line_enhance", "adaptive_plus"):
+        y = torch.zeros(rows, dtype=torch.float64, device="cuda")
+        spmv_acc_amd.csr_spmv(1.0, 0.0, rows, total, nnz, rp, ci, v, x, y, strategy=strat)
+        torch.cuda.synchronize()
+        got = y.cpu().numpy()
+        assert np.allclose(got[:8], want8, rtol=0, atol=1e-14), strat
+        # rows alternate between two values (row parity): check the whole shard against the period-2 pattern
+        assert np.allclose(got[0::2], want8[0], rtol=0, atol=1e-14) and np.allclose(got[1::2], want8[1], rtol=0, atol=1e-14), strat
+    spmv_acc_amd.release_plans(rp)
+
+
+def test_bench_contract_small(torch_dev):
+    """bench.py prints ONE JSON line with the driver's keys + roofline + cpu_baseline (reduced scale for speed)."""
+    import json
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--scale", "0.02",
+                          "--cpu-seconds", "1"], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    d = json.loads(out[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["bound"] == "hbm"
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+    assert "workload" in d["config"] and d["value"] > 0
