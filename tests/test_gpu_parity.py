@@ -509,3 +509,67 @@ def test_bench_contract_small(torch_dev):
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["bound"] == "hbm"
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and d["value"] > 0
+
+
+# ---- error paths and plan cache ---------------------------------------------------------------------------------------------------
+def test_error_codes_and_degenerate_shapes(torch_dev, hiplib, oracle):
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(100, 100, 4, seed=2)
+    nnz = int(rowptr[-1])
+    drp, dci, dv = dev(torch, rowptr), dev(torch, cols), dev(torch, vals)
+    dx = torch.ones(100, dtype=torch.float64, device="cuda")
+    dy = torch.ones(100, dtype=torch.float64, device="cuda")
+    L = hiplib
+    L.spmv_acc_clear_error()
+    # m <= 0: nothing to do, no error (the reference would launch an empty grid)
+    L.spmv_acc_csr_spmv_strategy(9, 0, 1.0, 1.0, 0, 100, 0, None, drp.data_ptr(), dci.data_ptr(), dv.data_ptr(), dx.data_ptr(), dy.data_ptr())
+    assert L.spmv_acc_last_error() == 0
+    # null y / unknown strategy / null colindex with nnz > 0 are reported, nothing is launched
+    L.spmv_acc_csr_spmv_strategy(9, 0, 1.0, 1.0, 100, 100, nnz, None, drp.data_ptr(), dci.data_ptr(), dv.data_ptr(), dx.data_ptr(), None)
+    assert L.spmv_acc_last_error() == 2
+    L.spmv_acc_clear_error()
+    L.spmv_acc_csr_spmv_strategy(99, 0, 1.0, 1.0, 100, 100, nnz, None, drp.data_ptr(), dci.data_ptr(), dv.data_ptr(), dx.data_ptr(), dy.data_ptr())
+    assert L.spmv_acc_last_error() == 5
+    L.spmv_acc_clear_error()
+    L.spmv_acc_csr_spmv_strategy(9, 0, 1.0, 1.0, 100, 100, nnz, None, drp.data_ptr(), None, dv.data_ptr(), dx.data_ptr(), dy.data_ptr())
+    assert L.spmv_acc_last_error() == 2
+    L.spmv_acc_clear_error()
+    assert L.spmv_acc_break_points(None, 10, 10, 1024, None, 2) == 2
+    L.spmv_acc_clear_error()
+    torch.cuda.synchronize()
+    assert torch.all(dy == 1.0)  # untouched by the refused calls
+    spmv_acc_amd.release_plans()
+    # n == 0 columns with an all-empty matrix: y = beta * y
+    rp0 = torch.zeros(51, dtype=torch.int32, device="cuda")
+    y = torch.full((50,), 3.0, dtype=torch.float64, device="cuda")
+    spmv_acc_amd.csr_spmv(2.0, 0.5, 50, 0, 0, rp0, None, None, None, y, strategy="adaptive")
+    torch.cuda.synchronize()
+    assert torch.all(y == 1.5)
+    spmv_acc_amd.release_plans()
+
+
+def test_plan_cache_lifecycle(torch_dev, hiplib, oracle):
+    torch = torch_dev
+    spmv_acc_amd.release_plans()
+    assert hiplib.spmv_acc_cached_plans() == 0
+    rowptr, cols, vals = synth.random_csr(5000, 5000, 6, seed=4)
+    rng = np.random.default_rng(0)
+    x, y0 = rng.standard_normal(5000), rng.standard_normal(5000)
+    drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+    nnz = int(rowptr[-1])
+    for strat in ("flat", "adaptive_plus", "adaptive"):
+        dy = dev(torch, y0)
+        spmv_acc_amd.csr_spmv(1.0, 1.0, 5000, 5000, nnz, drp, dci, dv, dx, dy, strategy=strat)
+    torch.cuda.synchronize()
+    assert hiplib.spmv_acc_cached_plans() == 1  # one matrix, one plan shared by the strategies
+    info = spmv_acc_amd.query_plan(drp, 5000)
+    assert info["flat_tiles"] == -(-nnz // 2048) and info["plus_blocks"] > 0 and info["adaptive_branch"] in (2, 3)
+    # the values may change freely under a plan (only the structure is cached)
+    dv.mul_(2.0)
+    dy = dev(torch, y0)
+    spmv_acc_amd.csr_spmv(1.0, 1.0, 5000, 5000, nnz, drp, dci, dv, dx, dy, strategy="flat")
+    torch.cuda.synchronize()
+    ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, 2.0 * vals, x, y0)
+    assert oracle.scaled_error(dy.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, 2.0 * vals, x, y0) <= SCALED_TOL
+    spmv_acc_amd.release_plans(drp)
+    assert hiplib.spmv_acc_cached_plans() == 0 and spmv_acc_amd.query_plan(drp, 5000) is None
