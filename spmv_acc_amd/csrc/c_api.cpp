@@ -12,30 +12,43 @@
 
 using namespace spmv_acc;
 
-// ---- pinned, double-buffered host -> device staging ----------------------------------------------------
+// ---- pinned host -> device staging -----------------------------------------------------------------------
+// The caller's arrays are pinned IN PLACE (hipHostRegister) and sent with hipMemcpyAsync on a private copy
+// stream, all five transfers in flight together; arrays that cannot be registered (e.g. read-only mappings) go
+// through a pinned double buffer instead.  One synchronisation at the end.
 namespace {
 struct Stager {
-  static constexpr size_t kChunk = 32u << 20; // 32 MiB per pinned bounce buffer
+  static constexpr size_t kChunk = 32u << 20; // 32 MiB per pinned bounce buffer (fallback path only)
   void *pinned[2] = {nullptr, nullptr};
   hipEvent_t done[2] = {nullptr, nullptr};
   hipStream_t copy = nullptr;
+  std::vector<void *> registered;
   bool ok = true;
-  Stager() {
-    ok = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; ok && i < 2; ++i) {
-      ok = hipHostMalloc(&pinned[i], kChunk, hipHostMallocDefault) == hipSuccess &&
-           hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
-    }
-  }
+  Stager() { ok = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) == hipSuccess; }
   ~Stager() {
+    for (void *p : registered) (void)hipHostUnregister(p);
     for (int i = 0; i < 2; ++i) {
       if (done[i]) (void)hipEventDestroy(done[i]);
       if (pinned[i]) (void)hipHostFree(pinned[i]);
     }
     if (copy) (void)hipStreamDestroy(copy);
   }
-  // memcpy into one pinned buffer while the other one is in flight on the copy stream
+  bool ensure_bounce() {
+    for (int i = 0; i < 2; ++i) {
+      if (!pinned[i] && (hipHostMalloc(&pinned[i], kChunk, hipHostMallocDefault) != hipSuccess ||
+                         hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess))
+        return false;
+    }
+    return true;
+  }
   bool upload(void *dst, const void *src, size_t bytes) {
+    if (hipHostRegister(const_cast<void *>(src), bytes, hipHostRegisterDefault) == hipSuccess) {
+      registered.push_back(const_cast<void *>(src));
+      return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, copy) == hipSuccess;
+    }
+    (void)hipGetLastError();
+    // fallback: memcpy into one pinned buffer while the other one is in flight
+    if (!ensure_bounce()) return false;
     size_t off = 0;
     int slot = 0;
     while (off < bytes) {
