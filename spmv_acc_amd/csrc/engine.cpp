@@ -683,7 +683,9 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       const Plan &p = *kv.second;
       out->nnz = p.A.nnz;
       out->adaptive_branch = p.have_samples ? adaptive_branch(m, p.samples) : 0;
-      out->vec = pick_vec_width(m, p.A.nnz);
+      int rb_vec = 1, rb_rows = kThreads;
+      pick_rowblock_shape(m, p.A.nnz, get_tunable("rowblock_target"), &rb_vec, &rb_rows);
+      out->vec = rb_vec; // lanes per row of the row-block family for this matrix
       out->flat_tiles = p.flat_tiles;
       out->plus_blocks = p.plus_blocks;
       out->aligned16 = p.A.aligned16 ? 1 : 0;

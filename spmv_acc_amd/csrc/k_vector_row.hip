@@ -138,14 +138,6 @@ inline int ceil_div_ll(long long a, long long b) { return static_cast<int>((a + 
 
 } // namespace
 
-int pick_vec_width(int m, int nnz) {
-  if (m <= 0) return 1;
-  const long long avg = static_cast<long long>(nnz) / m;
-  int w = 1;
-  while (w < 64 && static_cast<long long>(w) * 8 < avg) w <<= 1;
-  return w;
-}
-
 void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w0, int w1, double alpha, double beta,
                        const double *x, double *y) {
   if (A.m <= 0) return;

@@ -27,9 +27,6 @@ constexpr int kPlusR = 2;                 // MIN_NNZ 1024) instance (csr_adaptiv
 constexpr int kPlusMinNnz = 2 * kPlusR * kPlusThreads; // MIN_NNZ_PER_BLOCK 1024
 constexpr int kPlusLongChunk = 2 * kPlusMinNnz;        // NN_EI * MIN_NNZ_PER_BLOCK non-zeros per long-row block
 
-// Smallest power of two >= avg/8, clamped to [1, 64]: lanes cooperating on one row.
-int pick_vec_width(int m, int nnz);
-
 // default / vector-row family: `w` lanes per row straight from global memory.
 // Rows [0, row_split) use width w0, rows [row_split, m) use width w1 (row_split = m: one width).
 void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w0, int w1, double alpha, double beta,
