@@ -104,7 +104,7 @@ VerifyResult verify_y(const double *dy, const double *hy, int n) {
 }
 
 struct Options {
-  std::string path, format = "csr", strategy;
+  std::string path, format = "csr", strategy, dump;
   bool no_gpu = false, benchmark = false, stats = false;
   double alpha = 1.0, beta = 1.0; // cli/main.cpp:95-96
 };
@@ -127,6 +127,8 @@ bool parse_args(int argc, char **argv, Options &o) {
       o.benchmark = true;
     } else if (a == "--print-stats") {
       o.stats = true;
+    } else if (a == "--dump-bin") {
+      if (!need(o.dump)) return false;
     } else if (a == "--alpha" || a == "--beta") {
       std::string s;
       if (!need(s)) return false;
@@ -309,12 +311,24 @@ int run_benchmark(const Options &o, HostCsr &A, HostVectors &v) {
 int main(int argc, char **argv) {
   Options o;
   if (!parse_args(argc, argv, o)) {
-    std::cerr << "usage: spmv-cli <mtx_path> [-f|--format csr|mtx|bin2] [--strategy NAME] [--benchmark] [--no-gpu] [--print-stats] "
+    std::cerr << "usage: spmv-cli <mtx_path> [-f|--format csr|mtx|bin2] [--strategy NAME] [--benchmark] [--no-gpu] [--print-stats] [--dump-bin OUT] "
                  "[--alpha A] [--beta B]\n";
     return 2;
   }
   try {
     HostCsr A = load(o);
+    if (!o.dump.empty()) { // reader check: the parsed matrix, raw (int32 rows, cols, nnz, x_len; rowptr; colindex; values; x)
+      FILE *f = std::fopen(o.dump.c_str(), "wb");
+      if (!f) throw std::runtime_error("cannot write " + o.dump);
+      const int32_t hdr[4] = {A.rows, A.cols, A.nnz, static_cast<int32_t>(A.x.size())};
+      std::fwrite(hdr, sizeof(int32_t), 4, f);
+      std::fwrite(A.rowptr.data(), sizeof(int), A.rowptr.size(), f);
+      std::fwrite(A.colidx.data(), sizeof(int), A.colidx.size(), f);
+      std::fwrite(A.values.data(), sizeof(double), A.values.size(), f);
+      std::fwrite(A.x.data(), sizeof(double), A.x.size(), f);
+      std::fclose(f);
+      return 0;
+    }
     if (o.stats) { // reader check: what was parsed, as exact sums
       long long sc = 0, sr = 0;
       long double sv = 0, sx = 0;

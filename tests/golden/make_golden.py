@@ -127,3 +127,78 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "breakpoint_cases.npz"), **breakpoint_cases())
     for f in ("spmv_cases.npz", "analysis_cases.npz", "breakpoint_cases.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+# ---- reader fixtures: input FILES + what the REFERENCE's own readers parse from them --------------------------------------
+def reader_case_files(tmpdir):
+    """Small matrix files in the three formats of cli/main.cpp:36-40 (written here, not taken from the reference)."""
+    import struct
+
+    files = {}
+    rowptr, cols, vals = synth.random_csr(60, 50, 4, seed=77, kind="powerlaw")
+    x = synth.reference_rand_grid(50, np.random.default_rng(5))
+    p = os.path.join(tmpdir, "small.csr")
+    with open(p, "w") as f:
+        f.write("% any header text 60 50\n")
+        f.write(" ".join(repr(float(t)) for t in vals) + "\n")
+        f.write(" ".join(str(int(t)) for t in cols) + "\n")
+        f.write(" ".join(str(int(t)) for t in rowptr) + "\n")
+        f.write(" ".join(repr(float(t)) for t in x) + "\n")
+    files["small.csr"] = "csr"
+    for name, valtype in (("real.bin2", 3), ("pattern.bin2", 1)):
+        p = os.path.join(tmpdir, name)
+        with open(p, "wb") as f:
+            f.write(struct.pack("<6i", 0x20211015, 2, valtype, 60, 50, len(cols)))
+            rowptr.astype("<i4").tofile(f)
+            cols.astype("<i4").tofile(f)
+            if valtype == 3:
+                vals.astype("<f8").tofile(f)
+        files[name] = "bin2"
+    rng = np.random.default_rng(9)
+    ent = sorted({(int(r), int(c)) for r, c in zip(rng.integers(1, 41, 150), rng.integers(1, 31, 150))})  # no duplicates
+    with open(os.path.join(tmpdir, "general.mtx"), "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%% comment line\n40 30 %d\n" % len(ent))
+        order = rng.permutation(len(ent))
+        for k in order:
+            f.write("%d %d %.17g\n" % (ent[k][0], ent[k][1], rng.standard_normal()))
+    files["general.mtx"] = "mtx"
+    low = sorted({(max(r, c), min(r, c)) for r, c in zip(rng.integers(1, 36, 120), rng.integers(1, 36, 120))})
+    with open(os.path.join(tmpdir, "symmetric.mtx"), "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real symmetric\n35 35 %d\n" % len(low))
+        for r, c in low:
+            f.write("%d %d %.17g\n" % (r, c, rng.standard_normal()))
+    files["symmetric.mtx"] = "mtx"
+    with open(os.path.join(tmpdir, "pattern.mtx"), "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate pattern general\n40 30 %d\n" % len(ent))
+        for r, c in ent:
+            f.write("%d %d\n" % (r, c))
+    files["pattern.mtx"] = "mtx"
+    with open(os.path.join(tmpdir, "integer.mtx"), "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate integer general\n40 30 %d\n" % len(ent))
+        for k, (r, c) in enumerate(ent):
+            f.write("%d %d %d\n" % (r, c, (k % 9) - 4))
+    files["integer.mtx"] = "mtx"
+    return files
+
+
+def reader_cases():
+    import tempfile
+
+    assert oracle_lib.ref_readers() is not None, "oracle/_ref/libref_readers.so not built"
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        files = reader_case_files(d)
+        out["names"] = np.array(list(files))
+        out["formats"] = np.array([files[n] for n in files])
+        for name, fmt in files.items():
+            path = os.path.join(d, name)
+            out[f"{name}__file"] = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+            rows, cols, nnz, rp, ci, v, x = oracle_lib.ref_read_matrix(path, fmt)
+            out[f"{name}__dims"] = np.array([rows, cols, nnz], dtype=np.int64)
+            out[f"{name}__rowptr"], out[f"{name}__colidx"], out[f"{name}__values"], out[f"{name}__x"] = rp, ci, v, x
+    return out
+
+
+if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "reader_cases.npz"), **reader_cases())
+    print("reader_cases.npz", os.path.getsize(os.path.join(HERE, "reader_cases.npz")), "bytes")

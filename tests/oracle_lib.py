@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_analyze.so")
+REF_READERS_SO = os.path.join(ORACLE_DIR, "_ref", "libref_readers.so")
 
 _ip = ctypes.POINTER(ctypes.c_int)
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -82,6 +83,39 @@ def ref():
         R.ref_adaptive_plus_analyze.argtypes = [ci, ci, ci, ci, ci, _ip, _ip, ci, _ip]
         _ref = R
     return _ref
+
+
+_ref_readers = None
+
+
+def ref_readers():
+    """The reference's own matrix readers (None when oracle/_ref was not built)."""
+    global _ref_readers
+    if _ref_readers is None and os.path.exists(REF_READERS_SO):
+        R = ctypes.CDLL(REF_READERS_SO)
+        R.ref_read_matrix.argtypes = [ctypes.c_char_p, ctypes.c_int, _ip, _ip, _ip, ctypes.POINTER(_ip), ctypes.POINTER(_ip),
+                                      ctypes.POINTER(_dp), ctypes.POINTER(_dp), _ip]
+        R.ref_free.argtypes = [ctypes.c_void_p]
+        _ref_readers = R
+    return _ref_readers
+
+
+def ref_read_matrix(path, fmt):
+    """(rows, cols, nnz, rowptr, colidx, values, x) as the REFERENCE's reader parses `path` (fmt: csr | bin2 | mtx)."""
+    R = ref_readers()
+    rows, cols, nnz, xlen = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    rp, ci, v, x = _ip(), _ip(), _dp(), _dp()
+    rc = R.ref_read_matrix(path.encode(), {"csr": 0, "bin2": 1, "mtx": 2}[fmt], ctypes.byref(rows), ctypes.byref(cols),
+                           ctypes.byref(nnz), ctypes.byref(rp), ctypes.byref(ci), ctypes.byref(v), ctypes.byref(x),
+                           ctypes.byref(xlen))
+    assert rc == 0, "reference reader raised"
+    out = (rows.value, cols.value, nnz.value, np.ctypeslib.as_array(rp, (rows.value + 1,)).copy(),
+           np.ctypeslib.as_array(ci, (max(nnz.value, 1),))[: nnz.value].copy(),
+           np.ctypeslib.as_array(v, (max(nnz.value, 1),))[: nnz.value].copy(),
+           np.ctypeslib.as_array(x, (xlen.value,)).copy() if xlen.value else np.zeros(0))
+    for p in (rp, ci, v, x):
+        R.ref_free(ctypes.cast(p, ctypes.c_void_p))
+    return out
 
 
 def _c(a, dtype):

@@ -149,3 +149,70 @@ def test_benchmark_mode_csv(cli, tmp_path):
     for r_ in rows:
         assert len(r_) == 19 and int(r_[3]) == 60000 and int(r_[5]) == len(cols)
         assert int(r_[-2]) == 0 and int(r_[-3]) == -1 and float(r_[12]) > 0  # verified, timed
+
+
+# ---- readers pinned against the REFERENCE's own readers ----------------------------------------------------------------------------
+def _read_dump(path):
+    with open(path, "rb") as f:
+        rows, cols, nnz, xlen = np.fromfile(f, dtype=np.int32, count=4)
+        rp = np.fromfile(f, dtype=np.int32, count=rows + 1)
+        ci = np.fromfile(f, dtype=np.int32, count=nnz)
+        v = np.fromfile(f, dtype=np.float64, count=nnz)
+        x = np.fromfile(f, dtype=np.float64, count=xlen)
+    return int(rows), int(cols), int(nnz), rp, ci, v, x
+
+
+def test_readers_match_reference_goldens(cli, tmp_path):
+    """tests/golden/reader_cases.npz holds small input files and what the REFERENCE's readers (cli/csr_mtx_reader.hpp,
+    csr_binary_reader.hpp, matrix_market_reader.hpp + sparse_format.h::to_csr) parsed from them; our readers must
+    produce the same CSR bit for bit."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reader_cases.npz"))
+    for name, fmt in zip(g["names"], g["formats"]):
+        p = str(tmp_path / str(name))
+        g[f"{name}__file"].tofile(p)
+        out = str(tmp_path / (str(name) + ".dump"))
+        r = subprocess.run([cli, p, "-f", str(fmt), "--dump-bin", out], capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stderr)
+        rows, cols, nnz, rp, ci, v, x = _read_dump(out)
+        want_rows, want_cols, want_nnz = (int(t) for t in g[f"{name}__dims"])
+        assert (rows, cols, nnz) == (want_rows, want_cols, want_nnz), name
+        assert np.array_equal(rp, g[f"{name}__rowptr"]) and np.array_equal(ci, g[f"{name}__colidx"]), name
+        assert np.array_equal(v, g[f"{name}__values"]), name  # same decimal -> same double
+        if fmt == "csr":
+            assert np.array_equal(x, g[f"{name}__x"]), name
+
+
+def test_readers_match_compiled_reference_random(cli, tmp_path, oracle):
+    if oracle.ref_readers() is None:
+        pytest.skip("oracle/_ref/libref_readers.so not built (no /root/reference on this machine)")
+    rng = np.random.default_rng(123)
+    for trial in range(6):
+        m, n = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        rowptr, cols, vals = synth.random_csr(m, n, int(rng.integers(1, 9)), seed=500 + trial,
+                                              kind=["uniform", "powerlaw", "empty_rows"][trial % 3])
+        x = rng.standard_normal(n)
+        pc = str(tmp_path / f"t{trial}.csr")
+        write_csr_text(pc, rowptr, cols, vals, x)
+        pb = str(tmp_path / f"t{trial}.bin2")
+        write_bin2(pb, m, n, rowptr, cols, vals)
+        pm = str(tmp_path / f"t{trial}.mtx")
+        A = {}
+        for r in range(m):
+            for j in range(rowptr[r], rowptr[r + 1]):
+                A[(r + 1, int(cols[j]) + 1)] = float(vals[j])  # duplicates collapse: MatrixMarket entries are unique
+        with open(pm, "w") as f:
+            f.write("%%MatrixMarket matrix coordinate real general\n")
+            f.write("%d %d %d\n" % (m, n, len(A)))
+            for (r, c), val in A.items():
+                f.write("%d %d %.17g\n" % (r, c, val))
+        for path, fmt in ((pc, "csr"), (pb, "bin2"), (pm, "mtx")):
+            want = oracle.ref_read_matrix(path, fmt)
+            out = path + ".dump"
+            rr = subprocess.run([cli, path, "-f", fmt, "--dump-bin", out], capture_output=True, text=True)
+            assert rr.returncode == 0, rr.stderr
+            got = _read_dump(out)
+            assert got[:3] == want[:3], (trial, fmt)
+            for a, b in zip(got[3:6], want[3:6]):
+                assert np.array_equal(a, b), (trial, fmt)
+            if fmt == "csr":
+                assert np.array_equal(got[6], want[6])
