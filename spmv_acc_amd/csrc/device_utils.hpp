@@ -86,6 +86,19 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblocks) {
   return xcd * q + (xcd < rem ? xcd : rem) + idx;
 }
 
+// Chunked variant: the 8 XCDs walk the grid together in super-chunks of 8*C blocks, each XCD taking C consecutive
+// logical blocks of the super-chunk.  Neighbouring row blocks (shared x[] lines at their common edge) then hit the same
+// L2 inside a chunk, while all XCDs stay within the same few MB of the streamed arrays (DRAM pages stay hot, which
+// the fully contiguous split above gives up).  Bijective; the ragged tail of the grid keeps the identity order.
+__device__ __forceinline__ int xcd_chunked_block(int b, int nblocks, int chunk) {
+  const int super = kXcds * chunk;
+  const int full = (nblocks / super) * super;
+  if (b >= full) return b;
+  const int s = b / super;
+  const int r = b - s * super;
+  return s * super + (r % kXcds) * chunk + r / kXcds;
+}
+
 // y update with the documented semantics y = alpha*A*x + beta*y (api/spmv.h:14).  beta == 0 does
 // not read y (BLAS convention; for finite y it equals the reference's alpha*s + 0*y).
 __device__ __forceinline__ void store_y(double *y, int row, double alpha, double beta, double s) {

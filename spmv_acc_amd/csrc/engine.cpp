@@ -59,6 +59,7 @@ struct Tunable {
 };
 Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
+    {"xcd_chunk", 16, 16},     // row-block family: each XCD takes this many consecutive blocks per super-chunk (0 = off)
     {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
     {"rowblock_target", 1900, 1900}, // products a row block should bring to its 2048-product tile
     {"early_y", 1, 1},         // row-block kernel: load the old y before the tile instead of after it
@@ -576,8 +577,9 @@ bool run_rowblock(hipStream_t st, Plan &p, double alpha, double beta, const doub
     if (!probe_rowblock(p, rpb, st)) return false;
     if (p.rowblock_ok == 0) return run_flat(st, p, alpha, beta, x, y);
   }
-  launch_rowblock_stream(st, p.A, vec, rpb, (get_tunable("xcd_remap") ? 1 : 0) | (get_tunable("early_y") ? 2 : 0), alpha, beta,
-                         x, y);
+  const int chunk = get_tunable("xcd_chunk");
+  const int flags = (get_tunable("xcd_remap") ? 1 : 0) | (get_tunable("early_y") ? 2 : 0) | (chunk > 0 ? (4 | (chunk << 8)) : 0);
+  launch_rowblock_stream(st, p.A, vec, rpb, flags, alpha, beta, x, y);
   return true;
 }
 

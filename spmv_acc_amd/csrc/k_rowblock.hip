@@ -39,6 +39,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
 
   int b = blockIdx.x;
   if (flags & 1) b = xcd_contiguous_block(b, nblocks);
+  if (flags & 4) b = xcd_chunked_block(b, nblocks, flags >> 8);
 
   const long long base_ll = static_cast<long long>(b) * rpb;
   const int row_base = static_cast<int>(base_ll);
@@ -103,7 +104,7 @@ void launch_vec(hipStream_t stream, const CsrDev &A, int rpb, int xcd, double al
   if (rpb < 1 || rpb > kThreads / VEC) rpb = kThreads / VEC;
   const int nblocks = static_cast<int>((static_cast<long long>(A.m) + rpb - 1) / rpb);
   if (nblocks == 0) return;
-  const int remap = ((xcd & 1) && nblocks >= 64 ? 1 : 0) | (xcd & 2);
+  const int remap = ((xcd & 1) && nblocks >= 64 ? 1 : 0) | (xcd & ~1);
   if (A.aligned16) {
     hipLaunchKernelGGL((rowblock_stream_kernel<VEC, true>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,
                        nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y);

@@ -38,7 +38,7 @@ void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double b
 // line-enhance family: THREADS/vec consecutive rows per workgroup, non-zeros streamed through an
 // LDS tile in rounds.  vec in {1,2,4,8,16,32,64}.
 // rows_per_block <= kThreads / vec (0 = kThreads / vec).  flags: bit 0 XCD-contiguous block order, bit 1 read the
-// old y at kernel start instead of at the end.
+// old y at kernel start instead of at the end, bit 2 XCD-chunked block order with chunk = flags >> 8.
 void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, int rows_per_block, int flags,
                             double alpha, double beta, const double *x, double *y);
 void pick_rowblock_shape(int m, int nnz, int target_products, int *vec, int *rows_per_block);
