@@ -60,6 +60,7 @@ struct Tunable {
 Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
     {"xcd_chunk", 16, 16},     // row-block family: each XCD takes this many consecutive blocks per super-chunk (0 = off)
+    {"xcd_chunk_tiles", 0, 0}, // same order for the flat / row-block-plus grids (A/B: -4 % .. +3 % time, mixed: off)
     {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
     {"rowblock_target", 1900, 1900}, // products a row block should bring to its 2048-product tile
     {"early_y", 1, 1},         // row-block kernel: load the old y before the tile instead of after it
@@ -530,6 +531,7 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
 
 bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *x, double *y) {
   if (!ensure_flat(p, st)) return false;
+  p.flat.xcd_chunk = get_tunable("xcd_chunk_tiles");
   launch_flat(st, p.A, p.flat, alpha, beta, x, y);
   return true;
 }
@@ -656,8 +658,8 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   }
   case kAdaptivePlus:
     if (!ensure_plus(*p, h_rowptr, st)) return;
-    launch_plus(st, p->A, p->d_pbp, p->d_pfbr, p->d_pblk, p->plus_blocks, p->plus_has_long, p->d_ppartial, alpha, beta, dx,
-                dy);
+    launch_plus(st, p->A, p->d_pbp, p->d_pfbr, p->d_pblk, p->plus_blocks, p->plus_has_long, get_tunable("xcd_chunk_tiles"),
+                p->d_ppartial, alpha, beta, dx, dy);
     break;
   default:
     set_error(kErrUnknownStrategy, "unknown strategy id");

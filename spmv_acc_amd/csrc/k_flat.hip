@@ -62,10 +62,11 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
                                                              const double *__restrict__ v,
                                                              const double *__restrict__ x, double *__restrict__ y,
                                                              double *__restrict__ head, double *__restrict__ tail,
-                                                             int *__restrict__ tail_row, int *__restrict__ tail_end) {
+                                                             int *__restrict__ tail_row, int *__restrict__ tail_end,
+                                                             int xcd_chunk) {
   constexpr int STRIDE = kThreads * NPT;
   __shared__ double lds[STRIDE];
-  const int t = blockIdx.x;
+  const int t = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, ntiles, xcd_chunk) : static_cast<int>(blockIdx.x);
   const int t0 = t * STRIDE; // host guarantees nnz + stride fits in int
   const int t1 = (nnz - t0 > STRIDE) ? t0 + STRIDE : nnz;
 
@@ -159,10 +160,10 @@ void launch_flat_npt(hipStream_t stream, const CsrDev &A, const FlatPlan &P, dou
                      double *y) {
   if (A.aligned16) {
     hipLaunchKernelGGL((flat_tile_kernel<NPT, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz, P.ntiles,
-                       alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end);
+                       alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end, P.xcd_chunk);
   } else {
     hipLaunchKernelGGL((flat_tile_kernel<NPT, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz, P.ntiles,
-                       alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end);
+                       alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end, P.xcd_chunk);
   }
 }
 } // namespace

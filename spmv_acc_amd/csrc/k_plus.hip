@@ -69,14 +69,14 @@ __global__ __launch_bounds__(256) void plus_digest_kernel(int m, int nblocks, co
 }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, double alpha, double beta,
+__global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, int xcd_chunk, double alpha, double beta,
                                                         const int4v *__restrict__ blk, const int *__restrict__ rp,
                                                         const int *__restrict__ ci, const double *__restrict__ v,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         double *__restrict__ partial) {
   __shared__ double lds[kPlusTile];
   __shared__ double row_acc[kPlusMaxRows];
-  const int g = blockIdx.x;
+  const int g = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, nblocks, xcd_chunk) : static_cast<int>(blockIdx.x);
   const int4v rec = blk[g]; // wave-uniform: one scalar 16-B load
   const int row_begin = rec.x;
 
@@ -154,13 +154,14 @@ void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, cons
 }
 
 void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, const void *blk, int nblocks,
-                 bool has_long_rows, double *partial, double alpha, double beta, const double *x, double *y) {
+                 bool has_long_rows, int xcd_chunk, double *partial, double alpha, double beta, const double *x,
+                 double *y) {
   if (nblocks <= 0) return;
   if (A.aligned16) {
-    hipLaunchKernelGGL((plus_kernel<true>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, alpha, beta,
+    hipLaunchKernelGGL((plus_kernel<true>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk, alpha, beta,
                        static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial);
   } else {
-    hipLaunchKernelGGL((plus_kernel<false>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, alpha, beta,
+    hipLaunchKernelGGL((plus_kernel<false>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk, alpha, beta,
                        static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial);
   }
   if (has_long_rows) {

@@ -64,6 +64,7 @@ struct FlatPlan {
   double *tail = nullptr;   // per tile: partial sum of the row that continues in the next tile
   int *tail_row = nullptr;  // per tile: that row, or -1
   int *tail_end = nullptr;  // per tile: rowptr[row + 1] of that row
+  int xcd_chunk = 0;        // > 0: XCD-chunked tile order (device_utils.hpp::xcd_chunked_block)
 };
 void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                  double *y);
@@ -75,7 +76,7 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
 void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, void *blk,
                         int *d_has_long);
 void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, const void *blk, int nblocks,
-                 bool has_long_rows, double *partial, double alpha, double beta, const double *x, double *y);
+                 bool has_long_rows, int xcd_chunk, double *partial, double alpha, double beta, const double *x, double *y);
 
 // Device form of the row-block analysis (k_analyze.hip).  count: enqueue steps 1-3, d_total[0] = block count once
 // the stream has run; emit: write break_points (total + 1 entries) and first_block_of_row (m + 1 entries).
