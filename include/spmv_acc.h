@@ -117,8 +117,9 @@ int spmv_acc_adaptive_branch(int m, int rp_quarter, int rp_half, int rp_three_qu
 int spmv_acc_partition_rows(int m, int parts, int mode, const int *h_rowptr, int *row_begin);
 
 /* ---- host staging (new; replaces the pageable blocking hipMemcpy of cli/utils.hpp:94-117) ----------------------------
- * Copies host CSR arrays + vectors to freshly hipMalloc'ed device buffers through a pinned bounce
- * buffer with hipMemcpyAsync on a private copy stream (double-buffered).  Any of the host pointers
+ * Copies host CSR arrays + vectors to freshly hipMalloc'ed device buffers: the caller's arrays are pinned in place
+ * (hipHostRegister) and sent with hipMemcpyAsync on a private copy stream, all transfers in flight together; an
+ * array that cannot be pinned goes through a pinned double buffer.  Any of the host pointers
  * may be NULL to skip that array.  Free with spmv_acc_free_device. */
 int spmv_acc_stage_csr(int m, int n, int nnz, const int *h_rowptr, const int *h_colindex, const double *h_value,
                        const double *h_x, const double *h_y, int **d_rowptr, int **d_colindex, double **d_value,

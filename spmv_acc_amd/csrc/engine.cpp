@@ -63,6 +63,7 @@ Tunable g_tunables[] = {
     {"xcd_chunk_tiles", 0, 0}, // same order for the flat / row-block-plus grids (A/B: -4 % .. +3 % time, mixed: off)
     {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
     {"rowblock_target", 1900, 1900}, // products a row block should bring to its 2048-product tile
+    {"stage_fast", 1, 1},      // tile staging: wave-skip + branch-free form (0: per-lane predicated loads)
     {"early_y", 1, 1},         // row-block kernel: load the old y before the tile instead of after it
     {"rowblock_guard", 1, 1},  // imbalance probe + flat rescue for the row-block family
     {"plus_ref_vec", 0, 0},
@@ -531,7 +532,7 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
 
 bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *x, double *y) {
   if (!ensure_flat(p, st)) return false;
-  p.flat.xcd_chunk = get_tunable("xcd_chunk_tiles");
+  p.flat.xcd_chunk = get_tunable("stage_fast") ? get_tunable("xcd_chunk_tiles") : -1; // -1: per-lane predicated staging (A/B)
   launch_flat(st, p.A, p.flat, alpha, beta, x, y);
   return true;
 }
@@ -580,7 +581,8 @@ bool run_rowblock(hipStream_t st, Plan &p, double alpha, double beta, const doub
     if (p.rowblock_ok == 0) return run_flat(st, p, alpha, beta, x, y);
   }
   const int chunk = get_tunable("xcd_chunk");
-  const int flags = (get_tunable("xcd_remap") ? 1 : 0) | (get_tunable("early_y") ? 2 : 0) | (chunk > 0 ? (4 | (chunk << 8)) : 0);
+  const int flags = (get_tunable("xcd_remap") ? 1 : 0) | (get_tunable("early_y") ? 2 : 0) | (chunk > 0 ? (4 | (chunk << 8)) : 0) |
+                    (get_tunable("stage_fast") ? 0 : 8);
   launch_rowblock_stream(st, p.A, vec, rpb, flags, alpha, beta, x, y);
   return true;
 }

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
                                                              int *__restrict__ tail_row, int *__restrict__ tail_end,
                                                              int xcd_chunk) {
   constexpr int STRIDE = kThreads * NPT;
-  __shared__ double lds[STRIDE];
+  __shared__ __attribute__((aligned(16))) double lds[STRIDE]; // written 16 B at a time
   const int t = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, ntiles, xcd_chunk) : static_cast<int>(blockIdx.x);
   const int t0 = t * STRIDE; // host guarantees nnz + stride fits in int
   const int t1 = (nnz - t0 > STRIDE) ? t0 + STRIDE : nnz;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
   const int end_excl = tile_end_excl(rp, bp, t, ntiles, m, t1);
   const int nrows = end_excl - first;
 
-  stage_products<kThreads, NPT, ALIGNED>(lds, t0, t1, nnz, ci, v, x);
+  stage_products<kThreads, NPT, ALIGNED>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
 
   // lanes per row for this tile: as many as the tile's row count leaves room for (wave-uniform)
   int w = 1;

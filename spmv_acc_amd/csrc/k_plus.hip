@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
                                                         const int *__restrict__ ci, const double *__restrict__ v,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         double *__restrict__ partial) {
-  __shared__ double lds[kPlusTile];
+  __shared__ __attribute__((aligned(16))) double lds[kPlusTile]; // written 16 B at a time
   __shared__ double row_acc[kPlusMaxRows];
   const int g = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, nblocks, xcd_chunk) : static_cast<int>(blockIdx.x);
   const int4v rec = blk[g]; // wave-uniform: one scalar 16-B load

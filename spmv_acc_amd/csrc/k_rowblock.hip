@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
                                                                    double *__restrict__ y) {
   // rpb rows per workgroup, rpb <= kThreads / VEC (not necessarily a power of two: it is chosen so that
   // rpb * average row length fills most of one LDS tile)
-  __shared__ double lds[kTile];
+  __shared__ __attribute__((aligned(16))) double lds[kTile]; // written 16 B at a time
 
   int b = blockIdx.x;
   if (flags & 1) b = xcd_contiguous_block(b, nblocks);
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   double acc = 0.0;
   // tile origin aligned down so 16-B loads stay aligned; the (at most 3) extra leading products are never read
   for (int off = s0 & ~3; off < s1; off += kTile) {
-    stage_products<kThreads, kNnzPerThread, ALIGNED>(lds, off, s1, nnz, ci, v, x);
+    stage_products<kThreads, kNnzPerThread, ALIGNED>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0);
     __syncthreads();
     const int lo = (r0 > off ? r0 : off) - off;
     const int hi = (r1 < off + kTile ? r1 : off + kTile) - off;

@@ -23,9 +23,59 @@ namespace dev {
 template <int THREADS, int NPT, bool ALIGNED>
 __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0, int hi, int nnz,
                                                const int *__restrict__ ci, const double *__restrict__ v,
-                                               const double *__restrict__ x) {
+                                               const double *__restrict__ x, bool allow_fast = true) {
   static_assert(NPT % 4 == 0, "NPT must be a multiple of 4");
   constexpr int K = NPT / 4;
+  // Branch-free form (wave-uniform test): a0 is a multiple of 4, so the last 4-group that starts below `hi` ends at
+  // round_up(hi, 4); when that is still inside the arrays every group a lane may load is in bounds (the elements
+  // between hi and round_up(hi, 4) belong to the next rows: valid entries, valid columns).  Work is skipped per WAVE
+  // (scalar branches on a wave-uniform test); inside the one wave that straddles `hi`, lanes past it re-load the
+  // tile's first group instead of being masked off (an L1 hit, no extra memory request).  No per-lane branches remain,
+  // so hipcc places exact s_waitcnt counts: all stream loads of the wave, then all its gathers in flight.  (With
+  // per-lane branches it waited for half of the first step's gathers before issuing the second step's.)  Products of
+  // re-loaded groups land in slots >= hi - a0 that no reader touches.
+  if (ALIGNED && allow_fast && ((hi + 3) & ~3) <= nnz) {
+    int4v c[K];
+    double2v va[K], vb[K];
+    bool wave_has[K]; // wave-uniform: does any lane of this wave have a group below hi in step k?
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int wave_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + k * THREADS));
+      wave_has[k] = wave_j < hi;
+      if (wave_has[k]) {
+        const int j = a0 + 4 * (threadIdx.x + k * THREADS);
+        const int jc = (j < hi) ? j : a0; // lanes past hi in the boundary wave re-read the tile's first group (L1 hit)
+        c[k] = load_stream_i4(ci + jc);
+        va[k] = load_stream_d2(v + jc);
+        vb[k] = load_stream_d2(v + jc + 2);
+      }
+    }
+    double xg[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (wave_has[k]) {
+        xg[k][0] = x[c[k].x];
+        xg[k][1] = x[c[k].y];
+        xg[k][2] = x[c[k].z];
+        xg[k][3] = x[c[k].w];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (wave_has[k]) {
+        const int g = threadIdx.x + k * THREADS;
+        double2v p0, p1;
+        p0.x = va[k].x * xg[k][0];
+        p0.y = va[k].y * xg[k][1];
+        p1.x = vb[k].x * xg[k][2];
+        p1.y = vb[k].y * xg[k][3];
+        double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
+        dst[0] = p0;
+        dst[1] = p1;
+      }
+    }
+    return;
+  }
   if (ALIGNED) {
     int4v c[K];
     double2v va[K], vb[K];

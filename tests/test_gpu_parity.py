@@ -573,3 +573,25 @@ def test_plan_cache_lifecycle(torch_dev, hiplib, oracle):
     assert oracle.scaled_error(dy.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, 2.0 * vals, x, y0) <= SCALED_TOL
     spmv_acc_amd.release_plans(drp)
     assert hiplib.spmv_acc_cached_plans() == 0 and spmv_acc_amd.query_plan(drp, 5000) is None
+
+
+def test_ragged_array_end_every_residue(torch_dev, oracle):
+    """nnz mod 4 = 0..3 with the last row block / tile ending exactly at nnz: the wide-load fast path must hand the
+    ragged end to the guarded path (tile_stage.hpp: round_up(hi, 4) <= nnz) and results stay in parity."""
+    torch = torch_dev
+    rng = np.random.default_rng(77)
+    for extra in range(8):
+        lens = np.full(700, 5, dtype=np.int64)
+        lens[-1] = 5 + extra  # nnz = 3500 + extra
+        rowptr, cols, vals = synth.csr_from_row_lengths(lens, 700, rng)
+        nnz = int(rowptr[-1])
+        x, y0 = rng.standard_normal(700), rng.standard_normal(700)
+        drp, dci, dv, dx = dev(torch, rowptr), dev(torch, cols), dev(torch, vals), dev(torch, x)
+        for strat in spmv_acc_amd.HOT_STRATEGIES:
+            dy = dev(torch, y0)
+            spmv_acc_amd.csr_spmv(1.0, 1.0, 700, 700, nnz, drp, dci, dv, dx, dy, strategy=strat)
+            torch.cuda.synchronize()
+            ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+            err = oracle.scaled_error(dy.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, vals, x, y0)
+            assert err <= SCALED_TOL, (strat, extra, err)
+        spmv_acc_amd.release_plans(drp)
