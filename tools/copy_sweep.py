@@ -3,7 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, spmv_acc_amd
-for mb in (128, 512, 1024, 2048, 4096, 8192):
+for mb in (8, 16, 32, 64, 128, 512, 1024, 2048, 4096, 8192):
     n = mb * (1 << 20) // 8
     a = torch.empty(n, dtype=torch.float64, device="cuda").normal_()
     b = torch.empty_like(a)
