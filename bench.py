@@ -63,7 +63,7 @@ def build_workload(args, torch, device, rank):
         m, n, nnz, rp, ci, v = synth.rmat_torch(scale, device=device, seed=0xC4 + rank)
         return dict(name=f"R-MAT scale {scale} edge factor 16", m=m, n=n, nnz=nnz, rp=rp, ci=ci, v=v,
                     strategy=args.strategy or "line_enhance")
-    if w in synth.LARGE_SET:
+    if w in synth.LARGE_SET or w in synth.LARGE_SET_EXTRA:
         m, n, nnz, rp, ci, v = synth.large_set_like_torch(w, device=device, seed=0xC300 + rank, scale=args.scale)
         return dict(name=f"{w}-like (synthetic stand-in)", m=m, n=n, nnz=nnz, rp=rp, ci=ci, v=v,
                     strategy=args.strategy or "flat")

@@ -318,7 +318,7 @@ double spmv_acc_copy_ceiling_gbs(void *dst, const void *src, long long bytes, in
   float best = 1e30f;
   for (int r = 0; r < reps + 1; ++r) {
     (void)hipEventRecord(e0, st);
-    launch_stream_copy(st, dst, src, bytes);
+    launch_stream_copy(st, dst, src, bytes, get_tunable("copy_nt") != 0);
     (void)hipEventRecord(e1, st);
     float ms = 0.f;
     if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {

@@ -73,6 +73,13 @@ __device__ __forceinline__ double2v load_stream_d2(const double *p) {
 }
 __device__ __forceinline__ int load_stream(const int *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ double load_stream(const double *p) { return __builtin_nontemporal_load(p); }
+// NT = false: default cache policy, for matrices small enough to stay in the 256 MB Infinity Cache between SpMVs
+template <bool NT> __device__ __forceinline__ int4v load_stream_i4(const int *p) {
+  return NT ? __builtin_nontemporal_load(reinterpret_cast<const int4v *>(p)) : *reinterpret_cast<const int4v *>(p);
+}
+template <bool NT> __device__ __forceinline__ double2v load_stream_d2(const double *p) {
+  return NT ? __builtin_nontemporal_load(reinterpret_cast<const double2v *>(p)) : *reinterpret_cast<const double2v *>(p);
+}
 
 // ---- XCD-aware block remap ------------------------------------------------------------------------
 // Hardware deals block b to XCD (b mod 8).  Neighbouring row blocks share x[] lines, so give each

@@ -63,6 +63,8 @@ Tunable g_tunables[] = {
     {"xcd_chunk_tiles", 0, 0}, // same order for the flat / row-block-plus grids (A/B: -4 % .. +3 % time, mixed: off)
     {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
     {"rowblock_target", 1900, 1900}, // products a row block should bring to its 2048-product tile
+    {"stream_plain", -1, -1},  // stream-load cache policy: -1 = timed once per matrix; 0 nt, 1 default, 2 index default, 3 value default
+    {"copy_nt", 1, 1},         // copy-ceiling probe: non-temporal loads/stores (0 = default cache policy)
     {"stage_fast", 1, 1},      // tile staging: wave-skip + branch-free form (0: per-lane predicated loads)
     {"early_y", 1, 1},         // row-block kernel: load the old y before the tile instead of after it
     {"rowblock_guard", 1, 1},  // imbalance probe + flat rescue for the row-block family
@@ -259,6 +261,8 @@ struct Plan {
   CsrDev A;
   bool have_samples = false;
   RowptrSamples samples;
+  // cache policy of the stream loads (kStreamPolicy*), timed once per matrix; -1 = not tuned yet
+  int stream_policy = -1;
   // row-block family: -1 unknown, 1 balanced, 0 some workgroup would need too many LDS rounds
   int rowblock_ok = -1;
   int rowblock_rpb = 0;
@@ -530,10 +534,58 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
   return true;
 }
 
+int policy_for(const Plan &p) {
+  const int forced = get_tunable("stream_plain");
+  if (forced >= 0) return forced & 3;
+  return p.stream_policy >= 0 ? p.stream_policy : kStreamPolicyNt;
+}
+
+// Time the stream-load cache policies on THIS matrix with the kernel family that will run it (scratch y, beta = 0:
+// no side effects on the caller's y) and keep the fastest.  Three launches per candidate, the first one warms the
+// caches the way a solver loop would find them; ~1-2 ms once per matrix.
+template <typename Launch> bool autotune_policy(Plan &p, hipStream_t st, Launch &&launch) {
+  if (p.stream_policy >= 0 || get_tunable("stream_plain") >= 0 || !p.A.aligned16) {
+    if (p.stream_policy < 0) p.stream_policy = kStreamPolicyNt;
+    return true;
+  }
+  double *scratch = nullptr;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
+    return false;
+  hipEvent_t e0, e1;
+  bool ok = hip_ok(hipEventCreate(&e0), "event") && hip_ok(hipEventCreate(&e1), "event");
+  const int candidates[3] = {kStreamPolicyNt, kStreamPolicyDefault, kStreamPolicyValueDefault};
+  float best = 1e30f;
+  int best_policy = kStreamPolicyNt;
+  for (int c = 0; ok && c < 3; ++c) {
+    launch(candidates[c], scratch); // warm-up in this policy
+    (void)hipEventRecord(e0, st);
+    launch(candidates[c], scratch);
+    launch(candidates[c], scratch);
+    (void)hipEventRecord(e1, st);
+    float ms = 0.f;
+    ok = hip_ok(hipEventSynchronize(e1), "sync tune") && hip_ok(hipEventElapsedTime(&ms, e0, e1), "elapsed tune");
+    if (ok && ms < best) {
+      best = ms;
+      best_policy = candidates[c];
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(scratch);
+  if (ok) p.stream_policy = best_policy;
+  return ok;
+}
+
+void launch_flat_with(hipStream_t st, Plan &p, int policy, double alpha, double beta, const double *x, double *y) {
+  p.flat.xcd_chunk = get_tunable("stage_fast") ? get_tunable("xcd_chunk_tiles") : -1; // -1: per-lane predicated staging (A/B)
+  p.flat.stream_policy = policy;
+  launch_flat(st, p.A, p.flat, alpha, beta, x, y);
+}
+
 bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *x, double *y) {
   if (!ensure_flat(p, st)) return false;
-  p.flat.xcd_chunk = get_tunable("stage_fast") ? get_tunable("xcd_chunk_tiles") : -1; // -1: per-lane predicated staging (A/B)
-  launch_flat(st, p.A, p.flat, alpha, beta, x, y);
+  if (!autotune_policy(p, st, [&](int pol, double *ys) { launch_flat_with(st, p, pol, 1.0, 0.0, x, ys); })) return false;
+  launch_flat_with(st, p, policy_for(p), alpha, beta, x, y);
   return true;
 }
 
@@ -581,9 +633,13 @@ bool run_rowblock(hipStream_t st, Plan &p, double alpha, double beta, const doub
     if (p.rowblock_ok == 0) return run_flat(st, p, alpha, beta, x, y);
   }
   const int chunk = get_tunable("xcd_chunk");
-  const int flags = (get_tunable("xcd_remap") ? 1 : 0) | (get_tunable("early_y") ? 2 : 0) | (chunk > 0 ? (4 | (chunk << 8)) : 0) |
-                    (get_tunable("stage_fast") ? 0 : 8);
-  launch_rowblock_stream(st, p.A, vec, rpb, flags, alpha, beta, x, y);
+  const int base_flags = (get_tunable("xcd_remap") ? 1 : 0) | (get_tunable("early_y") ? 2 : 0) |
+                         (chunk > 0 ? (4 | (chunk << 8)) : 0) | (get_tunable("stage_fast") ? 0 : 8);
+  if (!autotune_policy(p, st, [&](int pol, double *ys) {
+        launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (pol << 4), 1.0, 0.0, x, ys);
+      }))
+    return false;
+  launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p) << 4), alpha, beta, x, y);
   return true;
 }
 
@@ -660,8 +716,13 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   }
   case kAdaptivePlus:
     if (!ensure_plus(*p, h_rowptr, st)) return;
+    if (!autotune_policy(*p, st, [&](int pol, double *ys) {
+          launch_plus(st, p->A, p->d_pbp, p->d_pfbr, p->d_pblk, p->plus_blocks, p->plus_has_long,
+                      get_tunable("xcd_chunk_tiles"), pol, p->d_ppartial, 1.0, 0.0, dx, ys);
+        }))
+      return;
     launch_plus(st, p->A, p->d_pbp, p->d_pfbr, p->d_pblk, p->plus_blocks, p->plus_has_long, get_tunable("xcd_chunk_tiles"),
-                p->d_ppartial, alpha, beta, dx, dy);
+                policy_for(*p), p->d_ppartial, alpha, beta, dx, dy);
     break;
   default:
     set_error(kErrUnknownStrategy, "unknown strategy id");

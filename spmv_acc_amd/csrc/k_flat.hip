@@ -55,7 +55,7 @@ __device__ __forceinline__ int tile_end_excl(const int *__restrict__ rp, const i
   return (e < m && rp[e] < t1) ? e + 1 : e;
 }
 
-template <int NPT, bool ALIGNED>
+template <int NPT, bool ALIGNED, bool NTC, bool NTV>
 __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int ntiles, double alpha, double beta,
                                                              const int *__restrict__ rp, const int *__restrict__ bp,
                                                              const int *__restrict__ ci,
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
   const int end_excl = tile_end_excl(rp, bp, t, ntiles, m, t1);
   const int nrows = end_excl - first;
 
-  stage_products<kThreads, NPT, ALIGNED>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
+  stage_products<kThreads, NPT, ALIGNED, NTC, NTV>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
 
   // lanes per row for this tile: as many as the tile's row count leaves room for (wave-uniform)
   int w = 1;
@@ -155,26 +155,34 @@ void launch_break_points(hipStream_t stream, const int *rp, int m, int nnz, int 
 }
 
 namespace {
-template <int NPT>
-void launch_flat_npt(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
-                     double *y) {
-  if (A.aligned16) {
-    hipLaunchKernelGGL((flat_tile_kernel<NPT, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz, P.ntiles,
-                       alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end, P.xcd_chunk);
-  } else {
-    hipLaunchKernelGGL((flat_tile_kernel<NPT, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz, P.ntiles,
-                       alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end, P.xcd_chunk);
-  }
+template <int NPT, bool ALIGNED, bool NTC, bool NTV>
+void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
+                         double *y) {
+  hipLaunchKernelGGL((flat_tile_kernel<NPT, ALIGNED, NTC, NTV>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
+                     P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
+                     P.xcd_chunk);
 }
 } // namespace
 
 void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                  double *y) {
   if (P.ntiles <= 0) return;
-  switch (P.stride / kThreads) {
-  case 4: launch_flat_npt<4>(stream, A, P, alpha, beta, x, y); break;
-  case 16: launch_flat_npt<16>(stream, A, P, alpha, beta, x, y); break;
-  default: launch_flat_npt<8>(stream, A, P, alpha, beta, x, y); break;
+  const int npt = P.stride / kThreads;
+  if (!A.aligned16) {
+    if (npt == 4) launch_flat_variant<4, false, true, true>(stream, A, P, alpha, beta, x, y);
+    else if (npt == 16) launch_flat_variant<16, false, true, true>(stream, A, P, alpha, beta, x, y);
+    else launch_flat_variant<8, false, true, true>(stream, A, P, alpha, beta, x, y);
+  } else if (npt == 4) {
+    launch_flat_variant<4, true, true, true>(stream, A, P, alpha, beta, x, y);
+  } else if (npt == 16) {
+    launch_flat_variant<16, true, true, true>(stream, A, P, alpha, beta, x, y);
+  } else {
+    switch (P.stream_policy & 3) { // cache policy of the stream loads, see kernels.hpp
+    case 1: launch_flat_variant<8, true, false, false>(stream, A, P, alpha, beta, x, y); break;
+    case 2: launch_flat_variant<8, true, false, true>(stream, A, P, alpha, beta, x, y); break;
+    case 3: launch_flat_variant<8, true, true, false>(stream, A, P, alpha, beta, x, y); break;
+    default: launch_flat_variant<8, true, true, true>(stream, A, P, alpha, beta, x, y); break;
+    }
   }
   if (P.ntiles > 1) {
     hipLaunchKernelGGL(flat_fixup_kernel, dim3((P.ntiles - 1 + 255) / 256), dim3(256), 0, stream, P.ntiles, P.stride,

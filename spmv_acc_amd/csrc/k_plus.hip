@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void plus_digest_kernel(int m, int nblocks, co
   blk[g] = rec;
 }
 
-template <bool ALIGNED>
+template <bool ALIGNED, bool NTC, bool NTV>
 __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, int xcd_chunk, double alpha, double beta,
                                                         const int4v *__restrict__ blk, const int *__restrict__ rp,
                                                         const int *__restrict__ ci, const double *__restrict__ v,
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
     }
     double acc = 0.0;
     for (int off = a0; off < s1; off += kPlusTile) {
-      stage_products<kThreads, kPlusNpt, ALIGNED>(lds, off, s1, nnz, ci, v, x);
+      stage_products<kThreads, kPlusNpt, ALIGNED, NTC, NTV>(lds, off, s1, nnz, ci, v, x);
       __syncthreads();
       const int lo = (r0 > off ? r0 : off) - off;
       const int hi = (r1 < off + kPlusTile ? r1 : off + kPlusTile) - off;
@@ -154,16 +154,23 @@ void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, cons
 }
 
 void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, const void *blk, int nblocks,
-                 bool has_long_rows, int xcd_chunk, double *partial, double alpha, double beta, const double *x,
-                 double *y) {
+                 bool has_long_rows, int xcd_chunk, int stream_policy, double *partial, double alpha, double beta,
+                 const double *x, double *y) {
   if (nblocks <= 0) return;
-  if (A.aligned16) {
-    hipLaunchKernelGGL((plus_kernel<true>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk, alpha, beta,
-                       static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial);
+#define SPMV_ACC_LAUNCH_PLUS(AL, NC, NV)                                                                                \
+  hipLaunchKernelGGL((plus_kernel<AL, NC, NV>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk,   \
+                     alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial)
+  if (!A.aligned16) {
+    SPMV_ACC_LAUNCH_PLUS(false, true, true);
   } else {
-    hipLaunchKernelGGL((plus_kernel<false>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk, alpha, beta,
-                       static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial);
+    switch (stream_policy & 3) {
+    case 1: SPMV_ACC_LAUNCH_PLUS(true, false, false); break;
+    case 2: SPMV_ACC_LAUNCH_PLUS(true, false, true); break;
+    case 3: SPMV_ACC_LAUNCH_PLUS(true, true, false); break;
+    default: SPMV_ACC_LAUNCH_PLUS(true, true, true); break;
+    }
   }
+#undef SPMV_ACC_LAUNCH_PLUS
   if (has_long_rows) {
     hipLaunchKernelGGL(plus_fixup_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, A.m, nblocks, alpha, beta,
                        bp, fbr, partial, y);

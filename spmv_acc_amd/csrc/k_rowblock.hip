@@ -25,7 +25,7 @@ namespace {
 
 using namespace dev;
 
-template <int VEC, bool ALIGNED>
+template <int VEC, bool ALIGNED, bool NTC, bool NTV>
 __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nnz, int nblocks, int rpb, int flags,
                                                                    double alpha, double beta,
                                                                    const int *__restrict__ rp,
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   double acc = 0.0;
   // tile origin aligned down so 16-B loads stay aligned; the (at most 3) extra leading products are never read
   for (int off = s0 & ~3; off < s1; off += kTile) {
-    stage_products<kThreads, kNnzPerThread, ALIGNED>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0);
+    stage_products<kThreads, kNnzPerThread, ALIGNED, NTC, NTV>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0);
     __syncthreads();
     const int lo = (r0 > off ? r0 : off) - off;
     const int hi = (r1 < off + kTile ? r1 : off + kTile) - off;
@@ -105,13 +105,22 @@ void launch_vec(hipStream_t stream, const CsrDev &A, int rpb, int xcd, double al
   const int nblocks = static_cast<int>((static_cast<long long>(A.m) + rpb - 1) / rpb);
   if (nblocks == 0) return;
   const int remap = ((xcd & 1) && nblocks >= 64 ? 1 : 0) | (xcd & ~1);
-  if (A.aligned16) {
-    hipLaunchKernelGGL((rowblock_stream_kernel<VEC, true>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,
-                       nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y);
+  // bits 4-5 of the flags: cache policy of the stream loads (0 nt/nt, 1 plain/plain, 2 colindex plain + values nt,
+  // 3 colindex nt + values plain)
+#define SPMV_ACC_LAUNCH_RB(AL, NC, NV)                                                                                  \
+  hipLaunchKernelGGL((rowblock_stream_kernel<VEC, AL, NC, NV>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,  \
+                     nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y)
+  if (!A.aligned16) {
+    SPMV_ACC_LAUNCH_RB(false, true, true);
   } else {
-    hipLaunchKernelGGL((rowblock_stream_kernel<VEC, false>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,
-                       nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y);
+    switch ((xcd >> 4) & 3) {
+    case 1: SPMV_ACC_LAUNCH_RB(true, false, false); break;
+    case 2: SPMV_ACC_LAUNCH_RB(true, false, true); break;
+    case 3: SPMV_ACC_LAUNCH_RB(true, true, false); break;
+    default: SPMV_ACC_LAUNCH_RB(true, true, true); break;
+    }
   }
+#undef SPMV_ACC_LAUNCH_RB
 }
 
 } // namespace

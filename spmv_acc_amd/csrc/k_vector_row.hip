@@ -118,6 +118,7 @@ __global__ __launch_bounds__(kThreads) void scale_y_kernel(int m, double beta, d
 }
 
 // streaming copy with the SpMV kernels' load shape (16 B per lane, non-temporal), 4 steps per lane
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void stream_copy_kernel(int4v *__restrict__ dst, const int4v *__restrict__ src,
                                                                long long n16) {
   const long long base = (static_cast<long long>(blockIdx.x) * kThreads * 4) + threadIdx.x;
@@ -125,12 +126,15 @@ __global__ __launch_bounds__(kThreads) void stream_copy_kernel(int4v *__restrict
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const long long i = base + static_cast<long long>(k) * kThreads;
-    if (i < n16) r[k] = __builtin_nontemporal_load(src + i);
+    if (i < n16) r[k] = NT ? __builtin_nontemporal_load(src + i) : src[i];
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const long long i = base + static_cast<long long>(k) * kThreads;
-    if (i < n16) __builtin_nontemporal_store(r[k], dst + i);
+    if (i < n16) {
+      if (NT) __builtin_nontemporal_store(r[k], dst + i);
+      else dst[i] = r[k];
+    }
   }
 }
 
@@ -162,11 +166,17 @@ void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double b
   }
 }
 
-void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes) {
+void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes, bool non_temporal) {
   const long long n16 = bytes / 16;
   if (n16 <= 0) return;
-  hipLaunchKernelGGL(stream_copy_kernel, dim3(ceil_div_ll(n16, kThreads * 4)), dim3(kThreads), 0, stream,
-                     static_cast<int4v *>(dst), static_cast<const int4v *>(src), n16);
+  const dim3 grid(ceil_div_ll(n16, kThreads * 4));
+  if (non_temporal) {
+    hipLaunchKernelGGL(stream_copy_kernel<true>, grid, dim3(kThreads), 0, stream, static_cast<int4v *>(dst),
+                       static_cast<const int4v *>(src), n16);
+  } else {
+    hipLaunchKernelGGL(stream_copy_kernel<false>, grid, dim3(kThreads), 0, stream, static_cast<int4v *>(dst),
+                       static_cast<const int4v *>(src), n16);
+  }
 }
 
 void launch_scale_y(hipStream_t stream, int m, double beta, double *y) {

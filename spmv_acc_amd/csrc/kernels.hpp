@@ -18,6 +18,15 @@ struct CsrDev {
   bool aligned16 = false; // ci and v are 16-byte aligned and nnz >= 8: wide-load kernels allowed
 };
 
+// Cache policy of the 16-B colindex / value stream loads of the tile kernels.  Which one is fastest depends on the
+// matrix (A/B on MI355X: default-policy loads win by 7-27 % on FEM-like matrices -- part of the matrix then stays
+// in the 256 MB Infinity Cache between SpMVs --, non-temporal loads win by 6-13 % where short rows make the x / rowptr
+// / y lines in L2 worth protecting), so the engine times the candidates once per matrix and keeps the winner.
+constexpr int kStreamPolicyNt = 0;          // both non-temporal
+constexpr int kStreamPolicyDefault = 1;     // both default
+constexpr int kStreamPolicyIndexDefault = 2; // colindex default, values non-temporal
+constexpr int kStreamPolicyValueDefault = 3; // colindex non-temporal, values default
+
 // ---- tile geometry (fixed at build time) -----------------------------------------------------------
 constexpr int kThreads = 256;             // 4 waves per workgroup
 constexpr int kNnzPerThread = 8;          // two 4-wide steps per lane per round
@@ -38,7 +47,9 @@ void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double b
 // line-enhance family: THREADS/vec consecutive rows per workgroup, non-zeros streamed through an
 // LDS tile in rounds.  vec in {1,2,4,8,16,32,64}.
 // rows_per_block <= kThreads / vec (0 = kThreads / vec).  flags: bit 0 XCD-contiguous block order, bit 1 read the
-// old y at kernel start instead of at the end, bit 2 XCD-chunked block order with chunk = flags >> 8.
+// old y at kernel start instead of at the end, bit 2 XCD-chunked block order with chunk = flags >> 8,
+// bit 3 per-lane predicated staging (A/B), bits 4-5 cache policy of the stream loads (0 nt, 1 default, 2 colindex default +
+// values nt, 3 colindex nt + values default).
 void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, int rows_per_block, int flags,
                             double alpha, double beta, const double *x, double *y);
 void pick_rowblock_shape(int m, int nnz, int target_products, int *vec, int *rows_per_block);
@@ -65,6 +76,7 @@ struct FlatPlan {
   int *tail_row = nullptr;  // per tile: that row, or -1
   int *tail_end = nullptr;  // per tile: rowptr[row + 1] of that row
   int xcd_chunk = 0;        // > 0: XCD-chunked tile order (device_utils.hpp::xcd_chunked_block)
+  int stream_policy = 0;    // cache policy of the stream loads (kStreamPolicy*)
 };
 void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                  double *y);
@@ -76,7 +88,8 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
 void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, void *blk,
                         int *d_has_long);
 void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, const void *blk, int nblocks,
-                 bool has_long_rows, int xcd_chunk, double *partial, double alpha, double beta, const double *x, double *y);
+                 bool has_long_rows, int xcd_chunk, int stream_policy, double *partial, double alpha, double beta,
+                 const double *x, double *y);
 
 // Device form of the row-block analysis (k_analyze.hip).  count: enqueue steps 1-3, d_total[0] = block count once
 // the stream has run; emit: write break_points (total + 1 entries) and first_block_of_row (m + 1 entries).
@@ -87,7 +100,7 @@ void plus_analyze_device_emit(hipStream_t stream, const int *rp, int m, int min_
                               int *d_fbr);
 
 // dst = src over `bytes` (16-B granules) with the kernels' streaming load shape: the copy ceiling probe
-void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes);
+void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes, bool non_temporal);
 
 // y[i] = beta * y[i] (used for m > 0, nnz == 0 and as a building block)
 void launch_scale_y(hipStream_t stream, int m, double beta, double *y);

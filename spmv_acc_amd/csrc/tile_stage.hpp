@@ -20,7 +20,7 @@ namespace dev {
 //   nnz : total non-zeros (array length) -- only the last, ragged group of the arrays takes the scalar path
 // Slots of lds whose non-zero index is < a-block's-first-nnz or >= hi hold unspecified values; no
 // reader touches them.
-template <int THREADS, int NPT, bool ALIGNED>
+template <int THREADS, int NPT, bool ALIGNED, bool NTC = true, bool NTV = true>
 __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0, int hi, int nnz,
                                                const int *__restrict__ ci, const double *__restrict__ v,
                                                const double *__restrict__ x, bool allow_fast = true) {
@@ -45,9 +45,9 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
       if (wave_has[k]) {
         const int j = a0 + 4 * (threadIdx.x + k * THREADS);
         const int jc = (j < hi) ? j : a0; // lanes past hi in the boundary wave re-read the tile's first group (L1 hit)
-        c[k] = load_stream_i4(ci + jc);
-        va[k] = load_stream_d2(v + jc);
-        vb[k] = load_stream_d2(v + jc + 2);
+        c[k] = load_stream_i4<NTC>(ci + jc);
+        va[k] = load_stream_d2<NTV>(v + jc);
+        vb[k] = load_stream_d2<NTV>(v + jc + 2);
       }
     }
     double xg[K][4];

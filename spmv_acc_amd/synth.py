@@ -23,6 +23,11 @@ LARGE_SET = {
     "TSOPF_RS_b2383": (38_120, 38_120, 16_171_169),
     "vas_stokes_2M": (2_146_677, 2_146_677, 65_129_037),
 }
+# the two endpoints BASELINE.json configs[2] names; not in the reference's scripts (dims as listed by SuiteSparse)
+LARGE_SET_EXTRA = {
+    "scircuit": (170_998, 170_998, 958_936),
+    "af_shell10": (1_508_065, 1_508_065, 52_672_325),
+}
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -176,7 +181,7 @@ def hardesty3_like_torch(device="cuda", seed=0xC2, scale=1.0):
 
 
 def large_set_like_torch(name, device="cuda", seed=0xC300, scale=1.0):
-    m0, n0, nnz0 = LARGE_SET[name]
+    m0, n0, nnz0 = LARGE_SET[name] if name in LARGE_SET else LARGE_SET_EXTRA[name]
     m, n = max(int(m0 * scale), 1), max(int(n0 * scale), 1)
     nnz = int(round(nnz0 * (m / m0)))
     spread = [1, 1, 1, 2]  # FEM blocks: mostly contiguous column runs

@@ -10,7 +10,7 @@ import spmv_acc_amd
 from rocsparse_row import RocsparseCsrmv
 from spmv_acc_amd import synth
 
-EXTRA = {"scircuit": (170_998, 170_998, 958_936), "af_shell10": (1_508_065, 1_508_065, 52_672_325)}  # SuiteSparse dims (stand-ins)
+EXTRA = synth.LARGE_SET_EXTRA  # SuiteSparse dims (stand-ins)
 names = list(synth.LARGE_SET) + list(EXTRA)
 ROC = RocsparseCsrmv()
 print("| matrix (stand-in) | rows | nnz | nnz/row | strategy | us (median) | GFLOP/s | B_alg GB/s | frac of 8 TB/s | ref GiB/s | rows failing verify_y rule | rocSPARSE dcsrmv us: no analysis / with analysis |")
