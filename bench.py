@@ -121,7 +121,13 @@ def copy_ceiling_gbs(torch, device):
     n = 1 << 27
     a = torch.empty(n, dtype=torch.float64, device=device).normal_()
     b = torch.empty_like(a)
-    return spmv_acc_amd.copy_ceiling_gbs(b, a, reps=5)
+    lib = spmv_acc_amd.load_library()
+    best = 0.0
+    for nt in (1, 0):  # non-temporal and default-policy copies: report the faster one
+        lib.spmv_acc_set_tunable(b"copy_nt", nt)
+        best = max(best, spmv_acc_amd.copy_ceiling_gbs(b, a, reps=5))
+    lib.spmv_acc_set_tunable(b"copy_nt", 1)
+    return best
 
 
 def main():

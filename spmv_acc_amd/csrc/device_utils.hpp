@@ -63,8 +63,9 @@ __device__ __forceinline__ double group_sum_dyn(double v, int w) {
 }
 
 // ---- streaming loads ----------------------------------------------------------------------------
-// values / colindex are read exactly once per SpMV: 16 B per lane, non-temporal so they do not
-// evict the x[] lines that the gathers want to find in L2 / Infinity Cache.
+// values / colindex are read exactly once per SpMV, 16 B per lane.  Whether they should be non-temporal is a
+// per-matrix question on MI355X (measured, kernels.hpp kStreamPolicy*): the templated forms below let the tile
+// kernels carry both and the engine picks by timing.  The untemplated forms (non-temporal) serve the scalar paths.
 __device__ __forceinline__ int4v load_stream_i4(const int *p) {
   return __builtin_nontemporal_load(reinterpret_cast<const int4v *>(p));
 }

@@ -5,7 +5,7 @@
 // hip-flat/flat_imp_one_pass.hpp:35-39, hip-line-enhance/line_enhance_spmv_imp.inl:55-62 and
 // hip-csr-adaptive-plus/csr_adaptive_plus_spmv_imp.inl:152-160 (one 4- or 8-byte load per lane).
 // Here a lane owns 4 consecutive non-zeros per step: one 16-B colindex load, two 16-B value loads
-// (all non-temporal), four x[] gathers, one 32-B LDS store.  Loads of all steps are issued before
+// (cache policy NTC / NTV chosen per matrix by the engine), four x[] gathers, one 32-B LDS store.  Loads of all steps are issued before
 // the first gather so every lane keeps NPT/4 * 48 B of stream plus NPT gathers in flight.
 #pragma once
 
