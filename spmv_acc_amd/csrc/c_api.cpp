@@ -231,6 +231,7 @@ int spmv_acc_query_plan(const int *d_rowptr, int m, int *out) {
   out[3] = info.flat_tiles;
   out[4] = info.plus_blocks;
   out[5] = info.aligned16;
+  out[6] = info.stream_policy;
   return 1;
 }
 

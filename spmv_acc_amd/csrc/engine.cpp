@@ -541,8 +541,8 @@ int policy_for(const Plan &p) {
 }
 
 // Time the stream-load cache policies on THIS matrix with the kernel family that will run it (scratch y, beta = 0:
-// no side effects on the caller's y) and keep the fastest.  Three launches per candidate, the first one warms the
-// caches the way a solver loop would find them; ~1-2 ms once per matrix.
+// no side effects on the caller's y) and keep the fastest.  Eight launches per candidate (3 to reach that policy's
+// cache steady state + 5 timed): 24 SpMVs' worth of time, once per matrix.
 template <typename Launch> bool autotune_policy(Plan &p, hipStream_t st, Launch &&launch) {
   if (p.stream_policy >= 0 || get_tunable("stream_plain") >= 0 || !p.A.aligned16) {
     if (p.stream_policy < 0) p.stream_policy = kStreamPolicyNt;
@@ -557,10 +557,11 @@ template <typename Launch> bool autotune_policy(Plan &p, hipStream_t st, Launch 
   float best = 1e30f;
   int best_policy = kStreamPolicyNt;
   for (int c = 0; ok && c < 3; ++c) {
-    launch(candidates[c], scratch); // warm-up in this policy
+    // the policies differ through what they leave in the Infinity Cache for the NEXT SpMV, so each candidate first
+    // runs until the caches hold its own steady state, then is timed over several launches
+    for (int w = 0; w < 3; ++w) launch(candidates[c], scratch);
     (void)hipEventRecord(e0, st);
-    launch(candidates[c], scratch);
-    launch(candidates[c], scratch);
+    for (int t = 0; t < 5; ++t) launch(candidates[c], scratch);
     (void)hipEventRecord(e1, st);
     float ms = 0.f;
     ok = hip_ok(hipEventSynchronize(e1), "sync tune") && hip_ok(hipEventElapsedTime(&ms, e0, e1), "elapsed tune");
@@ -756,6 +757,7 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->flat_tiles = p.flat_tiles;
       out->plus_blocks = p.plus_blocks;
       out->aligned16 = p.A.aligned16 ? 1 : 0;
+      out->stream_policy = p.stream_policy;
       return true;
     }
   }

@@ -106,6 +106,7 @@ struct PlanInfo {
   int flat_tiles = 0;
   int plus_blocks = 0;
   int aligned16 = 0;
+  int stream_policy = -1; // kStreamPolicy* chosen by the plan-time timing, -1 = not tuned yet
 };
 bool query_plan(const int *d_rowptr, int m, PlanInfo *out);
 int cached_plan_count();

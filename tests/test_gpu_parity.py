@@ -564,6 +564,7 @@ def test_plan_cache_lifecycle(torch_dev, hiplib, oracle):
     assert hiplib.spmv_acc_cached_plans() == 1  # one matrix, one plan shared by the strategies
     info = spmv_acc_amd.query_plan(drp, 5000)
     assert info["flat_tiles"] == -(-nnz // 2048) and info["plus_blocks"] > 0 and info["adaptive_branch"] in (2, 3)
+    assert info["stream_policy"] in (0, 1, 3)  # timed once when the plan was built
     # the values may change freely under a plan (only the structure is cached)
     dv.mul_(2.0)
     dy = dev(torch, y0)

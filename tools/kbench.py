@@ -65,7 +65,8 @@ def main():
                         assert lib.spmv_acc_set_tunable(k.encode(), int(val)) == 0, kv
                 ms = spmv_acc_amd.time_spmv(s, a.iters, 1.0, a.beta, m, n, nnz, rp, ci, v, x, y)
                 times[(s, t)] += list(ms[2:])
-        print(f"== {w}: m={m} n={n} nnz={nnz} avg={nnz / m:.2f} B_alg={balg / 1e6:.1f} MB")
+        info = spmv_acc_amd.query_plan(rp, m) or {}
+        print(f"== {w}: m={m} n={n} nnz={nnz} avg={nnz / m:.2f} B_alg={balg / 1e6:.1f} MB  (plan: stream_policy={info.get('stream_policy')})")
         for (s, t), ms in times.items():
             med, mn = float(np.median(ms)), float(np.min(ms))
             print(f"  {s:14s} {t:28s} median {med * 1e3:9.2f} us  min {mn * 1e3:9.2f} us  "
