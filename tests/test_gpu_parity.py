@@ -596,3 +596,27 @@ def test_ragged_array_end_every_residue(torch_dev, oracle):
             err = oracle.scaled_error(dy.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, vals, x, y0)
             assert err <= SCALED_TOL, (strat, extra, err)
         spmv_acc_amd.release_plans(drp)
+
+
+def test_stream_policies_are_bitwise_equivalent(torch_dev, hiplib):
+    """The cache policy of the stream loads (picked by timing at plan time) must never change a bit of the result."""
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(30000, 30000, 14, seed=55, kind="powerlaw")
+    rng = np.random.default_rng(9)
+    x, y0 = rng.standard_normal(30000), rng.standard_normal(30000)
+    drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+    nnz = int(rowptr[-1])
+    try:
+        for strat in ("line_enhance", "flat", "adaptive_plus"):
+            outs = []
+            for policy in (0, 1, 2, 3):
+                assert hiplib.spmv_acc_set_tunable(b"stream_plain", policy) == 0
+                dy = dev(torch, y0)
+                spmv_acc_amd.csr_spmv(0.75, -1.5, 30000, 30000, nnz, drp, dci, dv, dx, dy, strategy=strat)
+                torch.cuda.synchronize()
+                outs.append(dy.cpu().numpy())
+            for o in outs[1:]:
+                assert np.array_equal(o, outs[0]), strat
+    finally:
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans(drp)
