@@ -95,12 +95,21 @@ def cpu_baseline(W, x, y0, seconds):
             if time.perf_counter() - t_start > budget or reps >= 50:
                 return best, reps
 
+    cpu_model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     t1, r1 = timed(lambda y: oracle_lib.host_spmv_inplace(1.0, 1.0, rp, ci, v, hx, y), seconds * 0.4)
     tc, rc = timed(lambda y: oracle_lib.host_spmv_omp(1.0, 1.0, rp, ci, v, hx, y, cores), seconds * 0.6)
     return {
         "value": round(2.0 * nnz / tc / 1e9, 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
-        "sample": f"whole matrix ({W['m']} rows, {nnz} nnz), best of {rc} runs on {cores} threads (OpenMP over "
+        "sample": f"whole matrix ({W['m']} rows, {nnz} nnz), best of {rc} runs on {cores} threads of {cpu_model} (OpenMP over "
                   f"nnz-balanced row ranges); 1 thread: {2.0 * nnz / t1 / 1e9:.3f} GFLOP/s best of {r1}",
+        "cpu_model": cpu_model,
         "value_1thread": round(2.0 * nnz / t1 / 1e9, 3),
     }
 
