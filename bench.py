@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--strategy", default=None, help="KERNEL_STRATEGY name (default: adaptive; banded/rmat per BASELINE)")
     p.add_argument("--scale", type=float, default=1.0, help="shrink the workload (for rehearsals only)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-sensitivity", action="store_true", help="skip the far_fraction=0 variant of the N=1 workload")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-overlap", action="store_true", help="N>1: wait for each allgather before the next SpMV")
     return p.parse_args()
@@ -247,6 +248,20 @@ def main():
     result.update(out_extra)
     if rank == 0:
         result["copy_ceiling_gbs"] = round(copy_ceiling_gbs(torch, device), 1)
+    if rank == 0 and world == 1 and args.workload == "hardesty3" and args.scale == 1.0 and not args.no_sensitivity:
+        # Same dimensions and row lengths, none of the stand-in's 10 % uniformly random columns (SURVEY.md 8d prescribes
+        # them; the real matrix is not available): shows live how much of `roofline.frac` is the gather sector cost.
+        m2, n2, nnz2 = synth.LARGE_SET["Hardesty3"]
+        rp2, ci2, v2 = synth.structured_csr_torch(m2, n2, nnz2, 0xC2, device=device, far_fraction=0.0)
+        y2 = y0.clone()
+        for _ in range(10):
+            spmv_acc_amd.csr_spmv(alpha, beta, m2, n2, nnz2, rp2, ci2, v2, x, y2, strategy=strat)
+        t2 = spmv_acc_amd.time_spmv_total(strat, 100, alpha, beta, m2, n2, nnz2, rp2, ci2, v2, x, y2) / 100
+        result["sensitivity"] = {"workload": "same stand-in with far_fraction 0.0 (no random columns)",
+                                 "launch_ms_mean": round(t2, 6), "achieved_gbs": round(b_alg / (t2 * 1e-3) / 1e9, 2),
+                                 "frac": round(b_alg / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        spmv_acc_amd.release_plans(rp2)
+        del rp2, ci2, v2, y2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(W, x, y0, args.cpu_seconds)
     elif rank == 0:
