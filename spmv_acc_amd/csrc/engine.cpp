@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -279,6 +280,7 @@ struct Plan {
   double *d_ppartial = nullptr;
   void *d_pblk = nullptr;
 
+  ~Plan() { free_device(); }
   void free_device() {
     free_flat();
     if (d_pbp) (void)hipFree(d_pbp);
@@ -301,7 +303,7 @@ struct Plan {
 };
 
 typedef std::tuple<int, const void *, const void *, const void *, int, int> PlanKey;
-std::map<PlanKey, Plan *> g_plans;
+std::map<PlanKey, std::shared_ptr<Plan>> g_plans; // a running call keeps its plan alive through its own reference
 constexpr size_t kMaxPlans = 256;
 
 // Is p readable by the host?  The reference's sparse_spmv hands the SAME device pointer in as "host"
@@ -344,7 +346,7 @@ bool fetch_samples(Plan &p, const int *h_rowptr) {
   return true;
 }
 
-Plan *get_plan(int m, int n, int nnz, const int *h_rowptr, const int *rp, const int *ci, const double *v) {
+std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const int *rp, const int *ci, const double *v) {
   int dev = 0;
   if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
   const PlanKey key(dev, rp, ci, v, m, n);
@@ -353,17 +355,9 @@ Plan *get_plan(int m, int n, int nnz, const int *h_rowptr, const int *rp, const 
   if (it != g_plans.end()) {
     if (nnz < 0 || nnz == it->second->A.nnz) return it->second;
     // same buffers, different nnz: the caller rebuilt the matrix in place
-    it->second->free_device();
-    delete it->second;
     g_plans.erase(it);
   }
-  if (g_plans.size() >= kMaxPlans) {
-    for (auto &kv : g_plans) {
-      kv.second->free_device();
-      delete kv.second;
-    }
-    g_plans.clear();
-  }
+  if (g_plans.size() >= kMaxPlans) g_plans.clear();
   if (nnz < 0) {
     if ((h_rowptr = host_view(h_rowptr)) != nullptr) {
       nnz = h_rowptr[m];
@@ -375,7 +369,7 @@ Plan *get_plan(int m, int n, int nnz, const int *h_rowptr, const int *rp, const 
     set_error(kErrTooLarge, "nnz does not leave room for tile arithmetic in int32; shard the matrix");
     return nullptr;
   }
-  Plan *p = new Plan();
+  std::shared_ptr<Plan> p = std::make_shared<Plan>();
   p->device = dev;
   p->A.m = m;
   p->A.n = n;
@@ -398,11 +392,14 @@ bool ensure_flat(Plan &p, hipStream_t stream) {
   const int tiles = nnz / stride + (nnz % stride ? 1 : 0);
   const size_t n1 = static_cast<size_t>(tiles) + 1;
   FlatPlan &F = p.flat;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.bp), sizeof(int) * n1), "hipMalloc break points")) return false;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.head), sizeof(double) * n1), "hipMalloc head carries")) return false;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail), sizeof(double) * n1), "hipMalloc tail carries")) return false;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail_row), sizeof(int) * n1), "hipMalloc tail rows")) return false;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail_end), sizeof(int) * n1), "hipMalloc tail ends")) return false;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.bp), sizeof(int) * n1), "hipMalloc break points") ||
+      !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.head), sizeof(double) * n1), "hipMalloc head carries") ||
+      !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail), sizeof(double) * n1), "hipMalloc tail carries") ||
+      !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail_row), sizeof(int) * n1), "hipMalloc tail rows") ||
+      !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail_end), sizeof(int) * n1), "hipMalloc tail ends")) {
+    p.free_flat(); // nothing half-built stays behind
+    return false;
+  }
   F.stride = stride;
   F.ntiles = tiles;
   launch_break_points(stream, p.A.rp, p.A.m, nnz, stride, F.bp, static_cast<int>(n1));
@@ -662,7 +659,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     set_error(kErrUnknownStrategy, "unknown strategy id");
     return;
   }
-  Plan *p = get_plan(m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value);
+  const std::shared_ptr<Plan> p = get_plan(m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value);
   if (!p) return;
   hipStream_t st = g_stream;
 
@@ -735,8 +732,6 @@ void release_plans(const int *d_rowptr) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto it = g_plans.begin(); it != g_plans.end();) {
     if (!d_rowptr || std::get<1>(it->first) == d_rowptr) {
-      it->second->free_device();
-      delete it->second;
       it = g_plans.erase(it);
     } else {
       ++it;
