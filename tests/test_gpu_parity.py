@@ -620,3 +620,35 @@ def test_stream_policies_are_bitwise_equivalent(torch_dev, hiplib):
     finally:
         hiplib.spmv_acc_reset_tunables()
         spmv_acc_amd.release_plans(drp)
+
+
+def test_measurement_switches_keep_parity(torch_dev, oracle, hiplib):
+    """Every A/B switch of the engine (tile sizes, block orders, staging forms, analysis forms) is a speed matter only."""
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(40000, 40000, 9, seed=91, kind="powerlaw")
+    rng = np.random.default_rng(4)
+    x, y0 = rng.standard_normal(40000), rng.standard_normal(40000)
+    drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+    nnz = int(rowptr[-1])
+    ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+    variants = [("flat", {"flat_npt": 4}), ("flat", {"flat_npt": 16}), ("flat", {"xcd_chunk_tiles": 16}),
+                ("flat", {"stage_fast": 0}), ("line_enhance", {"xcd_remap": 1, "xcd_chunk": 0}),
+                ("line_enhance", {"xcd_chunk": 64}), ("line_enhance", {"rowblock_guard": 0}),
+                ("line_enhance", {"rowblock_vec": 8}), ("line_enhance", {"rowblock_target": 600}),
+                ("line_enhance", {"stage_fast": 0, "early_y": 0}), ("adaptive_plus", {"plus_host_analysis": 1}),
+                ("adaptive_plus", {"plus_ref_vec": 1}), ("adaptive_plus", {"xcd_chunk_tiles": 16})]
+    try:
+        for strat, knobs in variants:
+            hiplib.spmv_acc_reset_tunables()
+            for k, v in knobs.items():
+                assert hiplib.spmv_acc_set_tunable(k.encode(), v) == 0, k
+            spmv_acc_amd.release_plans(drp)  # analysis-level switches take effect when the plan is (re)built
+            dy = dev(torch, y0)
+            spmv_acc_amd.csr_spmv(1.0, 1.0, 40000, 40000, nnz, drp, dci, dv, dx, dy, strategy=strat)
+            torch.cuda.synchronize()
+            err = oracle.scaled_error(dy.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, vals, x, y0)
+            assert err <= SCALED_TOL, (strat, knobs, err)
+        assert hiplib.spmv_acc_set_tunable(b"no_such_knob", 1) == -1
+    finally:
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans(drp)
