@@ -652,3 +652,63 @@ def test_measurement_switches_keep_parity(torch_dev, oracle, hiplib):
     finally:
         hiplib.spmv_acc_reset_tunables()
         spmv_acc_amd.release_plans(drp)
+
+
+def test_randomised_shapes_all_strategies(torch_dev, oracle):
+    """Fuzz: 160 random (valid) CSR matrices -- sizes, row-length laws, column laws, ragged nnz, unaligned views,
+    alpha/beta -- through every hot strategy, against the oracle."""
+    torch = torch_dev
+    rng = np.random.default_rng(20261003)
+    for case in range(160):
+        m = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 257, 1000, 4099, 20011]))
+        n = int(rng.choice([1, 2, 64, 1000, 5000, 30000]))
+        law = case % 8
+        if law == 0:
+            lens = rng.integers(0, 9, m)
+        elif law == 1:
+            lens = rng.integers(0, 3, m)
+        elif law == 2:
+            lens = np.minimum((rng.pareto(1.0, m) * 4).astype(np.int64), 60000)
+        elif law == 3:
+            lens = np.zeros(m, dtype=np.int64)
+            lens[rng.integers(0, m, max(1, m // 40))] = rng.integers(1, 5000, max(1, m // 40))
+        elif law == 4:
+            lens = np.full(m, int(rng.integers(1, 70)))
+        elif law == 5:
+            lens = rng.integers(200, 900, m) if m <= 300 else rng.integers(0, 40, m)
+        elif law == 6:
+            lens = rng.integers(0, 6, m)
+            lens[-1] = int(rng.integers(0, 9000))  # a long last row: the arrays end inside a wide-load group
+        else:
+            lens = rng.integers(0, 6, m)
+            lens[0] = int(rng.integers(2048, 12000))  # a long first row
+        rowptr = np.zeros(m + 1, dtype=np.int64)
+        np.cumsum(lens, out=rowptr[1:])
+        nnz = int(rowptr[-1])
+        if nnz > 3_000_000:
+            continue
+        rowptr = rowptr.astype(np.int32)
+        cols = rng.integers(0, n, nnz).astype(np.int32)
+        if case % 3 == 0 and nnz:  # clustered columns
+            cols = np.clip((np.repeat(np.arange(m), lens) * n // max(m, 1)) + rng.integers(-8, 9, nnz), 0, n - 1).astype(np.int32)
+        vals = rng.standard_normal(nnz)
+        x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+        alpha, beta = [(1.0, 1.0), (1.0, 0.0), (-0.5, 2.0), (0.0, 1.0)][case % 4]
+        shift = case % 5 == 4  # unaligned views of colindex / values
+        if shift:
+            pc = torch.zeros(nnz + 1, dtype=torch.int32, device="cuda")
+            pv = torch.zeros(nnz + 1, dtype=torch.float64, device="cuda")
+            pc[1:] = dev(torch, cols)
+            pv[1:] = dev(torch, vals)
+            dci, dv = pc[1:], pv[1:]
+        else:
+            dci, dv = dev(torch, cols), dev(torch, vals)
+        drp, dx = dev(torch, rowptr), dev(torch, x)
+        ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+        for strat in spmv_acc_amd.HOT_STRATEGIES:
+            dy = dev(torch, y0)
+            spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat)
+            torch.cuda.synchronize()
+            err = oracle.scaled_error(dy.cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0)
+            assert err <= SCALED_TOL, (case, strat, m, n, nnz, alpha, beta, shift, err)
+        spmv_acc_amd.release_plans(drp)
