@@ -232,6 +232,7 @@ int spmv_acc_query_plan(const int *d_rowptr, int m, int *out) {
   out[4] = info.plus_blocks;
   out[5] = info.aligned16;
   out[6] = info.stream_policy;
+  out[7] = info.flat_fixup;
   return 1;
 }
 

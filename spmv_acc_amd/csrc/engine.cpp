@@ -403,6 +403,19 @@ bool ensure_flat(Plan &p, hipStream_t stream) {
   F.stride = stride;
   F.ntiles = tiles;
   launch_break_points(stream, p.A.rp, p.A.m, nnz, stride, F.bp, static_cast<int>(n1));
+  // does this matrix need the carry fix-up kernel at all? (only rows longer than a tile's finishing reach do)
+  int *d_flag = nullptr;
+  int h_flag = 1;
+  if (hip_ok(hipMalloc(reinterpret_cast<void **>(&d_flag), sizeof(int)), "hipMalloc flat flag")) {
+    if (hip_ok(hipMemsetAsync(d_flag, 0, sizeof(int), stream), "memset flat flag")) {
+      launch_flat_needs_fixup(stream, p.A, F, d_flag);
+      if (!hip_ok(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream), "read flat flag") ||
+          !hip_ok(hipStreamSynchronize(stream), "sync flat flag"))
+        h_flag = 1;
+    }
+    (void)hipFree(d_flag);
+  }
+  F.needs_fixup = h_flag != 0;
   p.flat_tiles = tiles;
   return true;
 }
@@ -753,6 +766,7 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->plus_blocks = p.plus_blocks;
       out->aligned16 = p.A.aligned16 ? 1 : 0;
       out->stream_policy = p.stream_policy;
+      out->flat_fixup = p.flat_tiles > 0 ? (p.flat.needs_fixup ? 1 : 0) : -1;
       return true;
     }
   }

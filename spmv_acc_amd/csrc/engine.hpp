@@ -107,6 +107,7 @@ struct PlanInfo {
   int plus_blocks = 0;
   int aligned16 = 0;
   int stream_policy = -1; // kStreamPolicy* chosen by the plan-time timing, -1 = not tuned yet
+  int flat_fixup = -1;    // 1: flat folds cut rows with the fix-up kernel, 0: tiles finish them, -1: no flat plan yet
 };
 bool query_plan(const int *d_rowptr, int m, PlanInfo *out);
 int cached_plan_count();

@@ -63,9 +63,13 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
                                                              const double *__restrict__ x, double *__restrict__ y,
                                                              double *__restrict__ head, double *__restrict__ tail,
                                                              int *__restrict__ tail_row, int *__restrict__ tail_end,
-                                                             int xcd_chunk) {
+                                                             int xcd_chunk, int reach) {
+  // reach: a tile finishes its last row itself when it ends at most `reach` (0 or kFlatFinish) non-zeros past the tile
   constexpr int STRIDE = kThreads * NPT;
   __shared__ __attribute__((aligned(16))) double lds[STRIDE]; // written 16 B at a time
+  __shared__ double sh_tail_sum;                               // partial of the row this tile will finish itself
+  __shared__ int sh_tail_row, sh_tail_end;
+  if (threadIdx.x == 0) sh_tail_row = -1;
   const int t = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, ntiles, xcd_chunk) : static_cast<int>(blockIdx.x);
   const int t0 = t * STRIDE; // host guarantees nnz + stride fits in int
   const int t1 = (nnz - t0 > STRIDE) ? t0 + STRIDE : nnz;
@@ -106,23 +110,71 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
       if (a >= t0 && b <= t1) {
         store_y(y, r, alpha, beta, s); // complete row (possibly empty): final value
       } else if (a < t0) {
-        head[t] = s; // row started in an earlier tile (it may also run past this one)
+        // row started in an earlier tile.  Its owner (the tile it starts in) finishes a short overhang itself; only a
+        // row that runs more than kFlatFinish non-zeros past its owner's end is folded from carries.
+        const long long owner_end = (static_cast<long long>(a) / STRIDE + 1) * STRIDE;
+        if (b - owner_end > reach) head[t] = s;
+      } else if (b - t1 <= reach) {
+        sh_tail_sum = s; // row starts here and ends at most kFlatFinish non-zeros into the next tile(s): finished below
+        sh_tail_row = r;
+        sh_tail_end = b;
       } else {
-        tail[t] = s; // row starts here and continues in the next tile
+        tail[t] = s; // long row: carry, folded by the fix-up kernel in tile order
         tail_row[t] = r;
         tail_end[t] = b;
       }
     }
   }
-  // a tile without a continuing row says so (the fix-up reads tail_row only)
+  if (reach > 0) __syncthreads();
+  // One wave reads the overhang [t1, row end) of the tile's last row straight from global memory (<= kFlatFinish
+  // non-zeros, kFlatFinish / 64 unrolled steps per lane) and completes y[row]: no carry, no second kernel for such rows.
+  if (reach > 0 && threadIdx.x < kWave) {
+    const int r = sh_tail_row;
+    double extra = 0.0;
+    if (r >= 0) {
+      const int b = sh_tail_end;
+      constexpr int STEPS = kFlatFinish / kWave; // all loads of the overhang in flight at once
+      int cc[STEPS];
+      double vv[STEPS];
+#pragma unroll
+      for (int k = 0; k < STEPS; ++k) {
+        const int j = t1 + static_cast<int>(threadIdx.x) + k * kWave;
+        cc[k] = j < b ? load_stream(ci + j) : -1;
+        vv[k] = j < b ? load_stream(v + j) : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < STEPS; ++k)
+        if (cc[k] >= 0) extra += vv[k] * x[cc[k]];
+    }
+    extra = group_sum<64>(extra);
+    if (r >= 0 && threadIdx.x == 0) store_y(y, r, alpha, beta, sh_tail_sum + extra);
+  }
+  // a tile without a carried row says so (the fix-up reads tail_row only)
   if (threadIdx.x == 0) {
-    bool has_tail = false;
+    bool has_carry = false;
     if (nrows > 0) {
       const int r = end_excl - 1;
-      has_tail = (rp[r + 1] > t1) && (rp[r] >= t0);
+      has_carry = (rp[r] >= t0) && (rp[r + 1] - t1 > reach);
     }
-    if (!has_tail) tail_row[t] = -1;
+    if (!has_carry) tail_row[t] = -1;
   }
+}
+
+// Plan time: does any row run more than kFlatFinish non-zeros past the end of the tile it starts in?  (Only then
+// does the fix-up kernel have anything to fold.)
+__global__ __launch_bounds__(256) void flat_needs_fixup_kernel(const int *__restrict__ rp, const int *__restrict__ bp,
+                                                               int ntiles, int m, int nnz, int stride,
+                                                               int *__restrict__ flag) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntiles - 1) return;
+  const int t0 = t * stride;
+  const int t1 = t0 + stride;
+  int first = bp[t];
+  first = first < m ? first : m;
+  const int end_excl = tile_end_excl(rp, bp, t, ntiles, m, t1);
+  if (end_excl <= first) return;
+  const int r = end_excl - 1;
+  if (rp[r] >= t0 && rp[r + 1] - t1 > kFlatFinish) *flag = 1; // idempotent store
 }
 
 // One thread per tile that holds the START of a cut row: adds its tail carry and the head carries of
@@ -160,9 +212,15 @@ void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P,
                          double *y) {
   hipLaunchKernelGGL((flat_tile_kernel<NPT, ALIGNED, NTC, NTV>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                      P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                     P.xcd_chunk);
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish);
 }
 } // namespace
+
+void launch_flat_needs_fixup(hipStream_t stream, const CsrDev &A, const FlatPlan &P, int *d_flag) {
+  if (P.ntiles <= 1) return;
+  hipLaunchKernelGGL(flat_needs_fixup_kernel, dim3((P.ntiles - 1 + 255) / 256), dim3(256), 0, stream, A.rp, P.bp, P.ntiles,
+                     A.m, A.nnz, P.stride, d_flag);
+}
 
 void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                  double *y) {
@@ -184,7 +242,7 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
     default: launch_flat_variant<8, true, true, true>(stream, A, P, alpha, beta, x, y); break;
     }
   }
-  if (P.ntiles > 1) {
+  if (P.ntiles > 1 && P.needs_fixup) {
     hipLaunchKernelGGL(flat_fixup_kernel, dim3((P.ntiles - 1 + 255) / 256), dim3(256), 0, stream, P.ntiles, P.stride,
                        alpha, beta, P.head, P.tail, P.tail_row, P.tail_end, y);
   }
