@@ -162,8 +162,13 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     spmv_acc_amd.load_library()
-    if world > 1:
+    # rehearsal only: SPMV_ACC_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group, RowShardedSpmv, allgather,
+    # max-over-ranks) on however many ranks there are, including one -- the only RCCL run a one-GPU box allows
+    force_dist = os.environ.get("SPMV_ACC_BENCH_FORCE_DIST", "0") == "1"
+    dist_leg = world > 1 or force_dist
+    if dist_leg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -180,12 +185,12 @@ def main():
     alpha = beta = 1.0  # cli/main.cpp:95-96, benchmark/main.cpp:101-102
 
     def sync_all():
-        if world > 1:
+        if dist_leg:
             dist.barrier()
         torch.cuda.synchronize()
 
     out_extra = {}
-    if world == 1:
+    if not dist_leg:
         # ---- warm-up (builds the plan: nnz / samples / break points are fetched once here) ----
         for _ in range(max(args.warmup, 1)):
             spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y, strategy=strat)
@@ -204,7 +209,8 @@ def main():
         out_extra["per_launch_event_ms_min"] = round(float(np.min(ms)), 6)
     else:
         bounds = np.arange(world + 1, dtype=np.int64) * m  # every rank owns m rows of the (world*m) x n matrix
-        eng = RowShardedSpmv(rank, world, bounds, W["rp"], W["ci"], W["v"], n, device, strategy=strat)
+        eng = RowShardedSpmv(rank, world, bounds, W["rp"], W["ci"], W["v"], n, device, strategy=strat,
+                             always_collective=force_dist)
         eng.set_y(y0)  # like the N = 1 leg, y is iterated in place (no per-step reset inside the timed region)
         for _ in range(max(args.warmup, 1)):
             eng.step(alpha, beta, x, overlap=not args.no_overlap)
@@ -268,7 +274,7 @@ def main():
         result["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist_leg:
         dist.destroy_process_group()
 
 

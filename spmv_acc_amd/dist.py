@@ -47,7 +47,7 @@ class RowShardedSpmv:
     """
 
     def __init__(self, rank: int, world: int, bounds, rowptr, cols, vals, n: int, device, strategy="adaptive",
-                 local_spmv: Optional[Callable] = None, h_rowptr=None):
+                 local_spmv: Optional[Callable] = None, h_rowptr=None, always_collective: bool = False):
         import torch
 
         self.torch = torch
@@ -64,6 +64,7 @@ class RowShardedSpmv:
         self.strategy = strategy
         self.device = device
         self.local_spmv = local_spmv or self._hip_spmv
+        self.always_collective = always_collective  # issue the allgather even on a one-rank group (RCCL rehearsal)
         # two y buffers: the allgather of step k may still be reading one while step k+1 writes the other
         self.y_local = [torch.zeros(self.pad, dtype=torch.float64, device=device) for _ in range(2)]
         self.y_full = torch.zeros(world * self.pad, dtype=torch.float64, device=device)
@@ -88,7 +89,7 @@ class RowShardedSpmv:
         if self.m_local > 0:
             self.local_spmv(alpha, beta, x, buf)
         self.wait()  # at most one allgather in flight: y_full is written by it
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             self.y_full[: self.pad].copy_(buf)
             return None
         work = dist.all_gather_into_tensor(self.y_full, buf, group=group, async_op=True)
