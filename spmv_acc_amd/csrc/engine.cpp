@@ -71,6 +71,7 @@ Tunable g_tunables[] = {
     {"rowblock_guard", 1, 1},  // imbalance probe + flat rescue for the row-block family
     {"plus_ref_vec", 0, 0},
     {"plus_host_analysis", 0, 0}, // 1: run the row-block analysis on the host (the reference's form)    // 1: row-block-plus analysis with the reference's VEC_SIZE pick
+    {"flat_finish", -1, -1},   // flat cut rows: -1 time both forms per matrix, 0 carries + fix-up kernel, 1 tiles finish them (when legal)
     {"flat_npt", 8, 8},        // non-zeros per lane per flat tile: 4, 8 or 16 (tile = 256 lanes x this)
 };
 } // namespace
@@ -415,7 +416,9 @@ bool ensure_flat(Plan &p, hipStream_t stream) {
     }
     (void)hipFree(d_flag);
   }
-  F.needs_fixup = h_flag != 0;
+  F.can_finish = h_flag == 0;
+  F.needs_fixup = true; // until run_flat has timed both forms on this matrix
+  F.mode_tuned = false;
   p.flat_tiles = tiles;
   return true;
 }
@@ -593,9 +596,50 @@ void launch_flat_with(hipStream_t st, Plan &p, int policy, double alpha, double 
   launch_flat(st, p.A, p.flat, alpha, beta, x, y);
 }
 
+// Cut rows of a flat plan without long overhangs can be folded two ways (kernels.hpp kFlatFinish).  Which is faster
+// depends on the matrix: the finishing wave lengthens every workgroup by a dependent global load (-5 % on 150 us
+// kernels) but saves the fix-up launch (+5..20 % on kernels under 30 us).  Timed once per matrix like the cache policy.
+bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
+  FlatPlan &F = p.flat;
+  const int forced = get_tunable("flat_finish");
+  if (!F.can_finish || F.ntiles <= 1) {
+    F.needs_fixup = !F.can_finish;
+    return true;
+  }
+  if (forced >= 0) { // pinned (A/B runs): follows the tunable on every call
+    F.needs_fixup = forced == 0;
+    return true;
+  }
+  if (F.mode_tuned) {
+    F.needs_fixup = F.tuned_fixup;
+    return true;
+  }
+  double *scratch = nullptr;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
+    return false;
+  hipEvent_t e0, e1;
+  bool ok = hip_ok(hipEventCreate(&e0), "event") && hip_ok(hipEventCreate(&e1), "event");
+  float ms[2] = {0.f, 0.f};
+  for (int mode = 0; ok && mode < 2; ++mode) {
+    F.needs_fixup = mode == 0;
+    for (int w = 0; w < 3; ++w) launch_flat_with(st, p, policy_for(p), 1.0, 0.0, x, scratch);
+    (void)hipEventRecord(e0, st);
+    for (int t = 0; t < 5; ++t) launch_flat_with(st, p, policy_for(p), 1.0, 0.0, x, scratch);
+    (void)hipEventRecord(e1, st);
+    ok = hip_ok(hipEventSynchronize(e1), "sync tune") && hip_ok(hipEventElapsedTime(&ms[mode], e0, e1), "elapsed tune");
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(scratch);
+  F.tuned_fixup = F.needs_fixup = !(ok && ms[1] < ms[0]);
+  F.mode_tuned = ok;
+  return ok;
+}
+
 bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *x, double *y) {
   if (!ensure_flat(p, st)) return false;
   if (!autotune_policy(p, st, [&](int pol, double *ys) { launch_flat_with(st, p, pol, 1.0, 0.0, x, ys); })) return false;
+  if (!autotune_flat_mode(p, st, x)) return false;
   launch_flat_with(st, p, policy_for(p), alpha, beta, x, y);
   return true;
 }

@@ -77,13 +77,16 @@ struct FlatPlan {
   int *tail_end = nullptr;  // per tile: rowptr[row + 1] of that row
   int xcd_chunk = 0;        // > 0: XCD-chunked tile order (device_utils.hpp::xcd_chunked_block)
   int stream_policy = 0;    // cache policy of the stream loads (kStreamPolicy*)
-  bool needs_fixup = true;  // some row runs more than kFlatFinish non-zeros past the tile it starts in: every cut row is then
-                            // folded from carries by the fix-up kernel; otherwise tiles finish their cut rows themselves
+  bool can_finish = false;  // no row runs more than kFlatFinish non-zeros past the tile it starts in (plan-time probe)
+  bool needs_fixup = true;  // true: every cut row is folded from carries by the fix-up kernel; false (only when
+                            // can_finish): tiles finish their cut rows themselves.  Chosen by timing, engine.cpp.
+  bool mode_tuned = false;  // tuned_fixup holds the timed choice
+  bool tuned_fixup = true;
 };
 // A tile finishes its last row itself when the row ends at most this many non-zeros past the tile (one wave, two
-// unrolled steps).  If any row of the matrix overhangs further, the plan falls back to head/tail carries and the fix-up
-// kernel for ALL cut rows (paying for both the finishing wave and the fix-up launch measured 3-6% slower on the
-// RM07R- and TSOPF-like matrices).  The overhang is read twice
+// unrolled steps).  If any row of the matrix overhangs further, the plan uses head/tail carries and the fix-up kernel
+// for ALL cut rows (paying for both the finishing wave and the fix-up launch measured 3-6% slower on the RM07R- and
+// TSOPF-like matrices); otherwise the engine times both forms on the matrix and keeps the faster.  The overhang is read twice
 // (by the finishing tile and by the next one), so the reach is kept small: <= 6% of a tile.  Measured with a reach of
 // 2048 the TSOPF-like matrix (424 nnz/row) lost 15%: ~10% extra traffic plus a serial tail per block.
 constexpr int kFlatFinish = 128;

@@ -715,9 +715,9 @@ def test_randomised_shapes_all_strategies(torch_dev, oracle):
 
 
 def test_flat_finish_and_carry_modes(torch_dev, oracle, hiplib):
-    """flat folds rows cut by a tile boundary in one of two ways, chosen at plan time (kernels.hpp kFlatFinish): tiles finish
-    short overhangs themselves (no fix-up kernel) unless some row overhangs its tile by more than 128 non-zeros, in which
-    case every cut row goes through the carries.  Both modes, and every flat_npt (tile size), against the oracle; the row
+    """flat folds rows cut by a tile boundary in one of two ways, chosen at plan time (kernels.hpp kFlatFinish): through
+    head/tail carries and a fix-up kernel, or -- legal only when no row overhangs its tile by more than 128 non-zeros --
+    by letting tiles finish short overhangs themselves (the engine times both per matrix; `flat_finish` pins one).  Both modes, and every flat_npt (tile size), against the oracle; the row
     lengths put cut rows at overhangs 1..127, exactly 128, and 129+ ."""
     torch = torch_dev
     rng = np.random.default_rng(77)
@@ -726,7 +726,7 @@ def test_flat_finish_and_carry_modes(torch_dev, oracle, hiplib):
     exact = np.concatenate([[2048 - 40, 40 + 128], short])       # a row ending exactly 128 past tile 0 -> still finishing
     over = np.concatenate([[2048 - 40, 40 + 129], short])        # 129 past -> carry mode
     long_ = np.concatenate([short[:3000], [7000], short[3000:]])  # a row spanning several tiles -> carry mode
-    for name, lens, want_fixup in (("short", short, 0), ("exact", exact, 0), ("over", over, 1), ("long", long_, 1)):
+    for name, lens, must_carry in (("short", short, 0), ("exact", exact, 0), ("over", over, 1), ("long", long_, 1)):
         rowptr = np.zeros(lens.size + 1, dtype=np.int32)
         np.cumsum(lens, out=rowptr[1:])
         nnz = int(rowptr[-1])
@@ -734,8 +734,9 @@ def test_flat_finish_and_carry_modes(torch_dev, oracle, hiplib):
         vals = rng.standard_normal(nnz)
         x, y0 = rng.standard_normal(n), rng.standard_normal(lens.size)
         m = lens.size
-        for npt in (8, 4, 16):
+        for npt, finish in ((8, 1), (8, 0), (8, -1), (4, 1), (16, 1), (16, 0)):
             assert hiplib.spmv_acc_set_tunable(b"flat_npt", npt) == 0
+            assert hiplib.spmv_acc_set_tunable(b"flat_finish", finish) == 0  # -1: the engine times both forms
             try:
                 drp, dci, dv, dx, dy = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
                 spmv_acc_amd.csr_spmv(0.75, -1.5, m, n, nnz, drp, dci, dv, dx, dy, strategy="flat", h_rowptr=rowptr)
@@ -745,6 +746,8 @@ def test_flat_finish_and_carry_modes(torch_dev, oracle, hiplib):
                 spmv_acc_amd.release_plans(drp)
             finally:
                 hiplib.spmv_acc_reset_tunables()
-            if npt == 8:
-                assert info["flat_fixup"] == want_fixup, (name, info)
-            check(oracle, got, 0.75, -1.5, rowptr, cols, vals, x, y0, f"flat-{name}-npt{npt}")
+            if npt == 8 and finish >= 0:
+                assert info["flat_fixup"] == (1 if (must_carry or finish == 0) else 0), (name, finish, info)
+            if must_carry and (npt == 8 or name == "long"):  # 'over' is built around the 2048-non-zero tile
+                assert info["flat_fixup"] == 1, (name, info)
+            check(oracle, got, 0.75, -1.5, rowptr, cols, vals, x, y0, f"flat-{name}-npt{npt}-finish{finish}")
