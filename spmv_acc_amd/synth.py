@@ -205,6 +205,28 @@ def banded_torch(m, first_row=0, total_rows=None, device="cuda", offsets=(-4, -3
     return rowptr.to(torch.int32), cols[ok].to(torch.int32), vals[ok].contiguous()
 
 
+def banded_interior_torch(m, first_row, device="cuda", offsets=(-4, -3, -2, -1, 0, 1, 2, 3), chunk_rows=1 << 24):
+    """Interior rows [first_row, first_row+m) of the same banded matrix (no clipping: every row has len(offsets) entries,
+    first_row + offsets[0] >= 0 assumed), written chunk by chunk into preallocated int32 / fp64 arrays so that a shard
+    at the int32 limit of nnz (2^31 - 65536) needs no multi-GB int64 temporaries."""
+    import torch
+
+    k = len(offsets)
+    assert first_row + min(offsets) >= 0 and m * k < 2**31
+    offs = torch.tensor(offsets, device=device, dtype=torch.int64)
+    rowptr = (torch.arange(m + 1, device=device, dtype=torch.int64) * k).to(torch.int32)
+    ci = torch.empty(m * k, dtype=torch.int32, device=device)
+    v = torch.empty(m * k, dtype=torch.float64, device=device)
+    mag = 1.0 / (1.0 + offs.abs().to(torch.float64))
+    for r0 in range(0, m, chunk_rows):
+        r1 = min(m, r0 + chunk_rows)
+        cols = torch.arange(first_row + r0, first_row + r1, device=device, dtype=torch.int64)[:, None] + offs[None, :]
+        ci[r0 * k: r1 * k] = cols.reshape(-1).to(torch.int32)
+        v[r0 * k: r1 * k] = (torch.where(cols % 2 == 0, 1.0, -1.0).to(torch.float64) * mag[None, :]).reshape(-1)
+        del cols
+    return rowptr, ci, v
+
+
 def rmat_torch(scale, edge_factor=16, abcd=(0.57, 0.19, 0.19, 0.05), seed=0xC4, device="cuda", chunk=1 << 26):
     """R-MAT: 2^scale rows, edge_factor * 2^scale generated edges, duplicates merged."""
     import torch

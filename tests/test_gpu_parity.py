@@ -751,3 +751,38 @@ def test_flat_finish_and_carry_modes(torch_dev, oracle, hiplib):
             if must_carry and (npt == 8 or name == "long"):  # 'over' is built around the 2048-non-zero tile
                 assert info["flat_fixup"] == 1, (name, info)
             check(oracle, got, 0.75, -1.5, rowptr, cols, vals, x, y0, f"flat-{name}-npt{npt}-finish{finish}")
+
+
+def test_largest_int32_nnz(torch_dev):
+    """Maximum size (include/spmv_acc.h: nnz <= INT_MAX - 65536 per call): 268,427,263 interior rows of the configs[4]
+    banded matrix = 2,147,418,104 non-zeros, one below-the-limit call per strategy.  x[j] = (j mod 7) - 3 makes every
+    gather index matter; y is then a closed-form pattern of period 14 in the global row id.  One more non-zero's worth of
+    rows must be refused (SPMV_ACC_ERR_TOO_LARGE) without touching y."""
+    torch = torch_dev
+    first, k = 8, 8
+    m = (2**31 - 1 - 65536) // k
+    n = first + m + 8
+    rp, ci, v = synth.banded_interior_torch(m, first, device="cuda")
+    nnz = m * k
+    assert int(rp[-1].item()) == nnz and int(ci[-1].item()) == first + m - 1 + 3 and int(ci[0].item()) == first - 4
+    x = ((torch.arange(n, device="cuda", dtype=torch.int64) % 7) - 3).to(torch.float64)
+    offs = np.arange(-4, 4)
+    pat = np.array([np.sum(np.where((g + offs) % 2 == 0, 1.0, -1.0) / (1.0 + np.abs(offs)) * (((g + offs) % 7) - 3.0))
+                    for g in range(first, first + 14)])
+    want = torch.from_numpy(pat).cuda()[torch.arange(m, device="cuda", dtype=torch.int64) % 14]
+    for strat in ("adaptive", "flat", "line_enhance", "adaptive_plus", "default"):
+        y = torch.full((m,), 7.0, dtype=torch.float64, device="cuda")
+        spmv_acc_amd.csr_spmv(1.0, 0.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
+        torch.cuda.synchronize()
+        err = float((y - want).abs().max().item())
+        assert err <= 1e-13, (strat, err)
+        del y
+    spmv_acc_amd.release_plans(rp)
+    del want, ci, v
+    # one row more than fits: rowptr alone decides (the arrays are never dereferenced)
+    rp2 = (torch.arange(m + 10000 + 1, device="cuda", dtype=torch.int64) * k).clamp(max=2**31 - 1).to(torch.int32)
+    y = torch.full((16,), 7.0, dtype=torch.float64, device="cuda")
+    with pytest.raises(spmv_acc_amd.SpmvAccError):
+        spmv_acc_amd.csr_spmv(1.0, 0.0, m + 10000, n, -1, rp2, rp2, x, x, y, strategy="adaptive")
+    torch.cuda.synchronize()
+    assert float(y.min().item()) == 7.0
