@@ -61,7 +61,8 @@ struct Tunable {
 Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
     {"xcd_chunk", 16, 16},     // row-block family: each XCD takes this many consecutive blocks per super-chunk (0 = off)
-    {"xcd_chunk_tiles", 0, 0}, // same order for the flat / row-block-plus grids (A/B: -4 % .. +3 % time, mixed: off)
+    {"xcd_chunk_tiles", 16, 16}, // same order for the flat / row-block-plus grids (A/B after the cache-policy autotune,
+                               // 9 stand-ins: 0 .. -4 % time on every one, none slower)
     {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
     {"rowblock_target", 1900, 1900}, // products a row block should bring to its 2048-product tile
     {"stream_plain", -1, -1},  // stream-load cache policy: -1 = timed once per matrix; 0 nt, 1 default, 2 index default, 3 value default

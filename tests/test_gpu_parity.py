@@ -631,12 +631,12 @@ def test_measurement_switches_keep_parity(torch_dev, oracle, hiplib):
     drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
     nnz = int(rowptr[-1])
     ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
-    variants = [("flat", {"flat_npt": 4}), ("flat", {"flat_npt": 16}), ("flat", {"xcd_chunk_tiles": 16}),
+    variants = [("flat", {"flat_npt": 4}), ("flat", {"flat_npt": 16}), ("flat", {"xcd_chunk_tiles": 0}), ("flat", {"xcd_chunk_tiles": 5}),
                 ("flat", {"stage_fast": 0}), ("line_enhance", {"xcd_remap": 1, "xcd_chunk": 0}),
                 ("line_enhance", {"xcd_chunk": 64}), ("line_enhance", {"rowblock_guard": 0}),
                 ("line_enhance", {"rowblock_vec": 8}), ("line_enhance", {"rowblock_target": 600}),
                 ("line_enhance", {"stage_fast": 0, "early_y": 0}), ("adaptive_plus", {"plus_host_analysis": 1}),
-                ("adaptive_plus", {"plus_ref_vec": 1}), ("adaptive_plus", {"xcd_chunk_tiles": 16})]
+                ("adaptive_plus", {"plus_ref_vec": 1}), ("adaptive_plus", {"xcd_chunk_tiles": 0}), ("adaptive_plus", {"xcd_chunk_tiles": 3})]
     try:
         for strat, knobs in variants:
             hiplib.spmv_acc_reset_tunables()
