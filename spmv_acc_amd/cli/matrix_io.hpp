@@ -36,6 +36,21 @@ struct HostCsr {
   std::vector<double> x; // only the .csr text format carries the dense vector
 };
 
+// Structural checks every reader ends with: a file that fails them would send the kernels out of bounds (the reference's
+// readers hand such files straight to the GPU).
+inline void validate_csr(const std::string &path, const HostCsr &A) {
+  if (A.rows < 0 || A.cols < 0 || A.nnz < 0 || A.rowptr.size() != static_cast<size_t>(A.rows) + 1 ||
+      A.colidx.size() != static_cast<size_t>(A.nnz) || A.values.size() != static_cast<size_t>(A.nnz))
+    throw std::runtime_error(path + ": array sizes do not match the header");
+  if (A.rowptr.front() != 0 || A.rowptr.back() != A.nnz) throw std::runtime_error(path + ": rowptr does not match nnz");
+  for (size_t i = 0; i + 1 < A.rowptr.size(); ++i)
+    if (A.rowptr[i] > A.rowptr[i + 1]) throw std::runtime_error(path + ": rowptr decreases at row " + std::to_string(i));
+  for (size_t j = 0; j < A.colidx.size(); ++j)
+    if (A.colidx[j] < 0 || A.colidx[j] >= A.cols)
+      throw std::runtime_error(path + ": column index " + std::to_string(A.colidx[j]) + " outside [0, " + std::to_string(A.cols) +
+                               ") at non-zero " + std::to_string(j));
+}
+
 inline std::string slurp(const std::string &path) {
   std::ifstream f(path, std::ios::in | std::ios::binary);
   if (!f) throw std::runtime_error("cannot open " + path);
@@ -84,6 +99,7 @@ inline HostCsr read_csr_text(const std::string &path) {
   A.nnz = static_cast<int>(A.values.size());
   if (A.colidx.size() != A.values.size() || A.rowptr.back() != A.nnz || A.rowptr.front() != 0)
     throw std::runtime_error(path + ": inconsistent .csr file (nnz / rowptr mismatch)");
+  validate_csr(path, A);
   return A;
 }
 
@@ -103,6 +119,16 @@ inline HostCsr read_bin2(const std::string &path) {
   A.cols = hdr[4];
   A.nnz = hdr[5];
   if (A.rows < 0 || A.cols < 0 || A.nnz < 0) throw std::runtime_error(path + ": negative dimension");
+  {
+    // size the body from the header BEFORE allocating: a corrupt nnz must not reserve gigabytes
+    const std::streampos here = f.tellg();
+    f.seekg(0, std::ios::end);
+    const long long body = static_cast<long long>(f.tellg()) - static_cast<long long>(here);
+    f.seekg(here);
+    const long long per_value = valtype == 1 ? 0 : (valtype == 2 ? 4 : 8);
+    const long long need = 4LL * (static_cast<long long>(A.rows) + 1) + (4LL + per_value) * A.nnz;
+    if (body < need) throw std::runtime_error(path + ": truncated bin2 body");
+  }
   A.rowptr.resize(static_cast<size_t>(A.rows) + 1);
   A.colidx.resize(static_cast<size_t>(A.nnz));
   A.values.resize(static_cast<size_t>(A.nnz));
@@ -118,7 +144,7 @@ inline HostCsr read_bin2(const std::string &path) {
     f.read(reinterpret_cast<char *>(A.values.data()), static_cast<std::streamsize>(sizeof(double) * A.values.size()));
   }
   if (!f) throw std::runtime_error(path + ": truncated bin2 body");
-  if (A.rowptr.front() != 0 || A.rowptr.back() != A.nnz) throw std::runtime_error(path + ": rowptr does not match nnz");
+  validate_csr(path, A);
   return A;
 }
 
@@ -178,8 +204,12 @@ inline HostCsr read_matrix_market(const std::string &path) {
     if (!(ss >> rows >> cols >> declared)) throw std::runtime_error(path + ": bad size line");
     break;
   }
+  constexpr long kMaxEntries = 2147483647L - 65536; // the library's per-call nnz limit (include/spmv_acc.h)
+  if (rows < 0 || cols < 0 || declared < 0 || rows > kMaxEntries || cols > kMaxEntries || declared > kMaxEntries)
+    throw std::runtime_error(path + ": size line out of the int32 range");
   std::vector<CooEntry> e;
-  e.reserve(static_cast<size_t>(declared) * (mirror ? 2 : 1));
+  // an entry line has at least 4 characters ("1 1\n"): never reserve more than the file can hold
+  e.reserve(static_cast<size_t>(std::min<long>(declared, static_cast<long>(buf.size() / 4) + 1)) * (mirror ? 2 : 1));
   long seen = 0;
   while (std::getline(in, line)) {
     const char *s = line.c_str();
@@ -201,7 +231,10 @@ inline HostCsr read_matrix_market(const std::string &path) {
   }
   if (seen != declared)
     throw std::runtime_error(path + ": expected " + std::to_string(declared) + " entries, found " + std::to_string(seen));
-  return coo_to_csr(static_cast<int>(rows), static_cast<int>(cols), e);
+  if (e.size() > static_cast<size_t>(kMaxEntries)) throw std::runtime_error(path + ": more non-zeros than one call can take");
+  HostCsr A = coo_to_csr(static_cast<int>(rows), static_cast<int>(cols), e);
+  validate_csr(path, A);
+  return A;
 }
 
 // ---- writers (tests, tools) --------------------------------------------------------------------------------------------

@@ -216,3 +216,65 @@ def test_readers_match_compiled_reference_random(cli, tmp_path, oracle):
                 assert np.array_equal(a, b), (trial, fmt)
             if fmt == "csr":
                 assert np.array_equal(got[6], want[6])
+
+
+def test_readers_reject_malformed_files_under_sanitizers(tmp_path):
+    """The readers, compiled alone with AddressSanitizer + UBSan (CPU build), on corrupt inputs: every one must be
+    refused with a message -- no sanitizer report, no crash, no out-of-range structure reaching the kernels.  (The
+    reference's readers pass such files on: cli/csr_binary_reader.hpp:44-99 never checks the body against the header.)"""
+    exe = tmp_path / "reader_sanitize"
+    src = os.path.join(ROOT, "tests", "cxx", "reader_sanitize.cpp")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I", os.path.join(ROOT, "spmv_acc_amd", "cli"), src, "-o", str(exe)], check=True)
+    rowptr = np.array([0, 2, 3, 5], dtype=np.int32)
+    cols = np.array([0, 2, 1, 0, 2], dtype=np.int32)
+    vals = np.arange(1.0, 6.0)
+    hdr = lambda rows, ncols, nnz, vt=3, magic=0x20211015, ver=2: struct.pack("<6i", magic, ver, vt, rows, ncols, nnz)
+    body = rowptr.tobytes() + cols.tobytes() + vals.tobytes()
+    files = {
+        "good.bin2": (hdr(3, 3, 5) + body, "ok 3 3 5 5"),
+        "bad_magic.bin2": (hdr(3, 3, 5, magic=0x1234) + body, "error"),
+        "bad_version.bin2": (hdr(3, 3, 5, ver=1) + body, "error"),
+        "bad_valtype.bin2": (hdr(3, 3, 5, vt=9) + body, "error"),
+        "short_header.bin2": (hdr(3, 3, 5)[:10], "error"),
+        "truncated.bin2": (hdr(3, 3, 5) + body[:-9], "error"),
+        "huge_nnz.bin2": (hdr(3, 3, 2**31 - 1) + body, "error"),       # must not allocate 24 GB first
+        "huge_rows.bin2": (hdr(2**31 - 1, 3, 5) + body, "error"),
+        "negative.bin2": (hdr(-3, 3, 5) + body, "error"),
+        "col_out_of_range.bin2": (hdr(3, 2, 5) + body, "error"),          # column 2 with 2 columns
+        "negative_col.bin2": (hdr(3, 3, 5) + rowptr.tobytes() + np.array([0, -1, 1, 0, 2], np.int32).tobytes() + vals.tobytes(), "error"),
+        "rowptr_decreases.bin2": (hdr(3, 3, 5) + np.array([0, 3, 2, 5], np.int32).tobytes() + cols.tobytes() + vals.tobytes(), "error"),
+        "rowptr_overshoots.bin2": (hdr(3, 3, 5) + np.array([0, 2, 9, 5], np.int32).tobytes() + cols.tobytes() + vals.tobytes(), "error"),
+        "rowptr_nnz_mismatch.bin2": (hdr(3, 3, 5) + np.array([0, 2, 3, 4], np.int32).tobytes() + cols.tobytes() + vals.tobytes(), "error"),
+        "pattern.bin2": (hdr(3, 3, 5, vt=1) + rowptr.tobytes() + cols.tobytes(), "ok 3 3 5 5"),
+        "good.mtx": (b"%%MatrixMarket matrix coordinate real general\n% c\n3 3 2\n1 1 1.5\n3 2 -2\n", "ok 3 3 2 1"),
+        "index_zero.mtx": (b"%%MatrixMarket matrix coordinate real general\n3 3 1\n0 1 1.5\n", "error"),
+        "index_big.mtx": (b"%%MatrixMarket matrix coordinate real general\n3 3 1\n1 4 1.5\n", "error"),
+        "missing_value.mtx": (b"%%MatrixMarket matrix coordinate real general\n3 3 1\n1 1\n", "error"),
+        "too_few.mtx": (b"%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 1.0\n", "error"),
+        "too_many.mtx": (b"%%MatrixMarket matrix coordinate real general\n3 3 1\n1 1 1.0\n2 2 1.0\n", "error"),
+        "huge_declared.mtx": (b"%%MatrixMarket matrix coordinate real general\n3 3 999999999999999999\n1 1 1.0\n", "error"),
+        "huge_dims.mtx": (b"%%MatrixMarket matrix coordinate real general\n99999999999 3 1\n1 1 1.0\n", "error"),
+        "negative_dims.mtx": (b"%%MatrixMarket matrix coordinate real general\n-3 3 1\n1 1 1.0\n", "error"),
+        "array_format.mtx": (b"%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n", "error"),
+        "garbage.mtx": (bytes(range(256)) * 8, "error"),
+        "empty.mtx": (b"", "error"),
+        "good.csr": (b"hdr\n1 2 3\n0 1 0\n0 2 3\n0.5 0.25\n", "ok 2 2 3 1"),
+        "four_lines.csr": (b"hdr\n1 2 3\n0 1 0\n0 2 3\n", "error"),
+        "col_out_of_range.csr": (b"hdr\n1 2 3\n0 5 0\n0 2 3\n0.5 0.25\n", "error"),
+        "rowptr_mismatch.csr": (b"hdr\n1 2 3\n0 1 0\n0 2 4\n0.5 0.25\n", "error"),
+        "rowptr_decreases.csr": (b"hdr\n1 2 3\n0 1 0\n0 3 2 3\n0.5 0.25\n", "error"),
+        "bad_token.csr": (b"hdr\n1 x 3\n0 1 0\n0 2 3\n0.5 0.25\n", "error"),
+        "empty.csr": (b"", "error"),
+    }
+    paths = []
+    for name, (data, _) in files.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        paths.append(str(p))
+    r = subprocess.run([str(exe)] + paths, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == len(files), r.stdout
+    for (name, (_, want)), got in zip(files.items(), lines):
+        assert got.startswith(want), (name, got)
