@@ -173,9 +173,16 @@ int spmv_acc_time_spmv_total(int strategy, int iters, double alpha, double beta,
  * replaces: the WITH_MEM_BANDWIDTH macros of src/acc/common/mem_bandwidth.hpp:13-38 as the yardstick. */
 double spmv_acc_copy_ceiling_gbs(void *d_dst, const void *d_src, long long bytes, int reps);
 
-/* ---- measurement switches (new) -------------------------------------------------------------------------------------
- * A/B knobs for tools/kbench.py: "xcd_remap" (1), "rowblock_vec" (0 = auto), "rowblock_guard" (1).
- * Defaults are the shipped configuration; unknown names return -1. */
+/* ---- switches (new) -------------------------------------------------------------------------------------------------
+ * A/B knobs for tools/kbench.py ("xcd_chunk", "rowblock_target", "stream_plain", "flat_finish", "flat_npt", ...; the table
+ * with every default is in spmv_acc_amd/csrc/engine.cpp) and one behavioural switch:
+ *   "validate" (0): 1 = check rowptr / colindex of every new matrix on the device before the first launch (rowptr
+ *   monotone and non-negative, rowptr[m] == nnz, 0 <= colindex < n); a matrix that fails is refused with
+ *   SPMV_ACC_ERR_BAD_ARGUMENT on this and every later call and y is left untouched.  One pass over the indices per
+ *   matrix; the reference has no counterpart (its kernels read through whatever the caller passes).
+ * Defaults are the shipped configuration; unknown names return -1.  The environment variable
+ * SPMV_ACC_TUNABLES="name=value,name=value" seeds the defaults at load time, for executables that cannot call the setter
+ * (the reference's spmv-cli / benchmark linked against this library). */
 int spmv_acc_set_tunable(const char *name, int value);
 int spmv_acc_get_tunable(const char *name);
 void spmv_acc_reset_tunables(void);

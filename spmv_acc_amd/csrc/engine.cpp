@@ -73,11 +73,39 @@ Tunable g_tunables[] = {
     {"plus_ref_vec", 0, 0},
     {"plus_host_analysis", 0, 0}, // 1: run the row-block analysis on the host (the reference's form)    // 1: row-block-plus analysis with the reference's VEC_SIZE pick
     {"flat_finish", -1, -1},   // flat cut rows: -1 time both forms per matrix, 0 carries + fix-up kernel, 1 tiles finish them (when legal)
-    {"flat_npt", 8, 8},        // non-zeros per lane per flat tile: 4, 8 or 16 (tile = 256 lanes x this)
+    {"flat_npt", 8, 8},
+    {"validate", 0, 0},        // 1: check rowptr / colindex of every new matrix on the device before the first launch        // non-zeros per lane per flat tile: 4, 8 or 16 (tile = 256 lanes x this)
 };
 } // namespace
 
+namespace {
+// SPMV_ACC_TUNABLES="validate=1,flat_finish=0": initial values for a process that cannot call spmv_acc_set_tunable
+// (the reference's executables linked against this library).  Read once, before the first lookup.
+void apply_env_tunables() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  const char *env = std::getenv("SPMV_ACC_TUNABLES");
+  if (!env) return;
+  std::string s(env);
+  size_t pos = 0;
+  while (pos < s.size()) {
+    size_t end = s.find(',', pos);
+    if (end == std::string::npos) end = s.size();
+    const std::string item = s.substr(pos, end - pos);
+    const size_t eq = item.find('=');
+    if (eq != std::string::npos) {
+      const std::string name = item.substr(0, eq);
+      for (auto &t : g_tunables)
+        if (name == t.name) t.val = t.def = std::atoi(item.c_str() + eq + 1);
+    }
+    pos = end + 1;
+  }
+}
+} // namespace
+
 int set_tunable(const char *name, int value) {
+  apply_env_tunables();
   for (auto &t : g_tunables) {
     if (std::strcmp(t.name, name) == 0) {
       t.val = value;
@@ -87,11 +115,13 @@ int set_tunable(const char *name, int value) {
   return -1;
 }
 int get_tunable(const char *name) {
+  apply_env_tunables();
   for (auto &t : g_tunables)
     if (std::strcmp(t.name, name) == 0) return t.val;
   return -1;
 }
 void reset_tunables() {
+  apply_env_tunables();
   for (auto &t : g_tunables) t.val = t.def;
 }
 
@@ -266,6 +296,8 @@ struct Plan {
   RowptrSamples samples;
   // cache policy of the stream loads (kStreamPolicy*), timed once per matrix; -1 = not tuned yet
   int stream_policy = -1;
+  // opt-in structural check (tunable `validate`): -1 not run, 0 arrays are consistent, else the failure bits
+  int invalid = -1;
   // row-block family: -1 unknown, 1 balanced, 0 some workgroup would need too many LDS rounds
   int rowblock_ok = -1;
   int rowblock_rpb = 0;
@@ -645,6 +677,34 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
   return true;
 }
 
+// Opt-in (tunable `validate`): one pass over rowptr and colindex per new matrix; a matrix that fails is refused on this
+// and every later call (until its plan is released) instead of sending a kernel out of bounds.
+bool validate_plan(Plan &p, hipStream_t st) {
+  if (p.invalid < 0) {
+    int *d_flags = nullptr;
+    int h = -1;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d_flags), sizeof(int)), "hipMalloc validate")) return false;
+    if (hip_ok(hipMemsetAsync(d_flags, 0, sizeof(int), st), "memset validate")) {
+      launch_validate_csr(st, p.A, d_flags);
+      if (!hip_ok(hipMemcpyAsync(&h, d_flags, sizeof(int), hipMemcpyDeviceToHost, st), "read validate") ||
+          !hip_ok(hipStreamSynchronize(st), "sync validate"))
+        h = -1;
+    }
+    (void)hipFree(d_flags);
+    if (h < 0) return false;
+    p.invalid = h;
+  }
+  if (p.invalid != 0) {
+    std::string what = "matrix failed validation:";
+    if (p.invalid & 1) what += " rowptr decreases or is negative;";
+    if (p.invalid & 2) what += " rowptr[m] != nnz;";
+    if (p.invalid & 4) what += " column index outside [0, n);";
+    set_error(kErrBadArgument, what);
+    return false;
+  }
+  return true;
+}
+
 // Once per matrix: would any fixed row block have to stream more than kRowblockMaxRounds tiles?
 // (power-law matrices: R-MAT hub rows put millions of non-zeros into one workgroup.)
 bool probe_rowblock(Plan &p, int rpb, hipStream_t st) {
@@ -729,6 +789,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     set_error(kErrBadArgument, "null colindex / value with nnz > 0");
     return;
   }
+  if (get_tunable("validate") && !validate_plan(*p, st)) return;
 
   const long long avg = static_cast<long long>(p->A.nnz) / m;
   switch (strategy) {

@@ -117,6 +117,25 @@ __global__ __launch_bounds__(kThreads) void scale_y_kernel(int m, double beta, d
   if (i < m) y[i] = (beta == 0.0) ? 0.0 : beta * y[i];
 }
 
+// Opt-in structural check of the caller's arrays (tunable `validate`): bit 0 rowptr decreases or is negative, bit 1
+// rowptr[m] != nnz, bit 2 a column index outside [0, n).  Reads every index once; no kernel of the library is launched
+// on a matrix that fails.
+__global__ __launch_bounds__(kThreads) void validate_csr_kernel(const int *__restrict__ rp, const int *__restrict__ ci, int m,
+                                                                int n, int nnz, int *__restrict__ flags) {
+  const long long stride = static_cast<long long>(gridDim.x) * kThreads;
+  int bad = 0;
+  for (long long i = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x; i < m; i += stride) {
+    const int a = rp[i], b = rp[i + 1];
+    if (a < 0 || a > b) bad |= 1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && rp[m] != nnz) bad |= 2;
+  for (long long j = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x; j < nnz; j += stride) {
+    const int c = ci[j];
+    if (c < 0 || c >= n) bad |= 4;
+  }
+  if (bad) atomicOr(flags, bad);
+}
+
 // streaming copy with the SpMV kernels' load shape (16 B per lane, non-temporal), 4 steps per lane
 template <bool NT>
 __global__ __launch_bounds__(kThreads) void stream_copy_kernel(int4v *__restrict__ dst, const int4v *__restrict__ src,
@@ -177,6 +196,15 @@ void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long lon
     hipLaunchKernelGGL(stream_copy_kernel<false>, grid, dim3(kThreads), 0, stream, static_cast<int4v *>(dst),
                        static_cast<const int4v *>(src), n16);
   }
+}
+
+void launch_validate_csr(hipStream_t stream, const CsrDev &A, int *d_flags) {
+  const long long work = A.m > A.nnz ? A.m : A.nnz;
+  long long blocks = (work + kThreads - 1) / kThreads;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(validate_csr_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, A.n,
+                     A.nnz, d_flags);
 }
 
 void launch_scale_y(hipStream_t stream, int m, double beta, double *y) {

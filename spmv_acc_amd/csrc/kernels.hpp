@@ -117,5 +117,6 @@ void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long lon
 
 // y[i] = beta * y[i] (used for m > 0, nnz == 0 and as a building block)
 void launch_scale_y(hipStream_t stream, int m, double beta, double *y);
+void launch_validate_csr(hipStream_t stream, const CsrDev &A, int *d_flags); // *d_flags pre-zeroed; bits: see kernel
 
 } // namespace spmv_acc

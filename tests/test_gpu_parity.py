@@ -786,3 +786,38 @@ def test_largest_int32_nnz(torch_dev):
         spmv_acc_amd.csr_spmv(1.0, 0.0, m + 10000, n, -1, rp2, rp2, x, x, y, strategy="adaptive")
     torch.cuda.synchronize()
     assert float(y.min().item()) == 7.0
+
+
+def test_opt_in_validation_refuses_corrupt_matrices(torch_dev, oracle, hiplib):
+    """Tunable `validate` (or SPMV_ACC_TUNABLES=validate=1): rowptr / colindex of a new matrix are checked on the device
+    before the first launch.  A consistent matrix computes as usual; a column index outside [0, n), a decreasing rowptr or
+    an nnz that disagrees with rowptr[m] is refused with SPMV_ACC_ERR_BAD_ARGUMENT and y is left untouched -- no kernel
+    reads through the bad index."""
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(3000, 2500, 7, seed=5, kind="uniform")
+    rng = np.random.default_rng(6)
+    x, y0 = rng.standard_normal(2500), rng.standard_normal(3000)
+    m, n, nnz = 3000, 2500, int(rowptr[-1])
+    assert hiplib.spmv_acc_set_tunable(b"validate", 1) == 0
+    try:
+        for strat in ("adaptive", "flat", "adaptive_plus", "default"):
+            got = run(torch, strat, 1.0, 1.0, rowptr, cols, vals, x, y0)
+            check(oracle, got, 1.0, 1.0, rowptr, cols, vals, x, y0, f"validate-ok-{strat}")
+        bad_col = cols.copy(); bad_col[nnz // 2] = n          # one past the last column
+        neg_col = cols.copy(); neg_col[7] = -1
+        bad_rp = rowptr.copy(); bad_rp[100], bad_rp[101] = rowptr[101], rowptr[100] - 1 if rowptr[100] > 0 else 0
+        bad_rp = rowptr.copy(); bad_rp[1500] = rowptr[1501] + 3  # rowptr[1500] > rowptr[1501]
+        cases = {"col == n": (rowptr, bad_col, nnz), "col < 0": (rowptr, neg_col, nnz), "rowptr decreases": (bad_rp, cols, nnz),
+                 "nnz mismatch": (rowptr, cols, nnz - 1)}
+        for tag, (rp_, ci_, nnz_) in cases.items():
+            for strat in ("adaptive", "flat"):
+                drp, dci, dv, dx, dy = dev(torch, rp_), dev(torch, ci_), dev(torch, vals), dev(torch, x), dev(torch, y0)
+                with pytest.raises(spmv_acc_amd.SpmvAccError, match="validation"):
+                    spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz_, drp, dci, dv, dx, dy, strategy=strat)
+                with pytest.raises(spmv_acc_amd.SpmvAccError, match="validation"):  # the verdict is kept with the plan
+                    spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz_, drp, dci, dv, dx, dy, strategy=strat)
+                torch.cuda.synchronize()
+                assert np.array_equal(dy.cpu().numpy(), y0), (tag, strat)
+                spmv_acc_amd.release_plans(drp)
+    finally:
+        hiplib.spmv_acc_reset_tunables()

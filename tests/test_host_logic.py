@@ -4,6 +4,7 @@ pass, row partition) matches the oracle / the reference-generated goldens.  No c
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -172,3 +173,15 @@ def test_product_never_touches_oracle():
                     if re.search(r"oracle_lib|liboracle|libref_analyze|#include\s+\"[^\"]*oracle|import oracle|from oracle", text):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_env_tunables_seed_defaults():
+    """SPMV_ACC_TUNABLES seeds tunables for processes that cannot call spmv_acc_set_tunable (the reference's own
+    executables linked against the library); reset returns to the seeded values; unknown names are ignored."""
+    code = ("import spmv_acc_amd as s; l = s.load_library(); "
+            "print(l.spmv_acc_get_tunable(b'validate'), l.spmv_acc_get_tunable(b'flat_finish'), l.spmv_acc_get_tunable(b'xcd_chunk')); "
+            "l.spmv_acc_set_tunable(b'validate', 0); l.spmv_acc_reset_tunables(); print(l.spmv_acc_get_tunable(b'validate'))")
+    env = dict(os.environ, SPMV_ACC_TUNABLES="validate=1,flat_finish=0,no_such=5", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert r.stdout.split() == ["1", "0", "16", "1"], r.stdout
