@@ -41,6 +41,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-sensitivity", action="store_true", help="skip the far_fraction=0 variant of the N=1 workload")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--exchange", default="auto", choices=["auto", "allgather", "p2p"],
+                   help="N > 1: how the y slices travel -- RCCL all_gather_into_tensor, a direct point-to-point fan-out "
+                        "over all xGMI links, or (auto) whichever is faster on this job's communicator, timed before the run")
     p.add_argument("--no-overlap", action="store_true", help="N>1: wait for each allgather before the next SpMV")
     return p.parse_args()
 
@@ -210,7 +213,11 @@ def main():
     else:
         bounds = np.arange(world + 1, dtype=np.int64) * m  # every rank owns m rows of the (world*m) x n matrix
         eng = RowShardedSpmv(rank, world, bounds, W["rp"], W["ci"], W["v"], n, device, strategy=strat,
-                             always_collective=force_dist)
+                             always_collective=force_dist,
+                             exchange="allgather" if args.exchange == "auto" else args.exchange)
+        if args.exchange == "auto" and backend == "nccl":  # (gloo rehearsals: no point-to-point on GPU tensors)
+            out_extra["exchange_ms"] = {k: round(v, 4) for k, v in eng.tune_exchange().items()}
+        out_extra["exchange"] = eng.exchange
         eng.set_y(y0)  # like the N = 1 leg, y is iterated in place (no per-step reset inside the timed region)
         for _ in range(max(args.warmup, 1)):
             eng.step(alpha, beta, x, overlap=not args.no_overlap)
@@ -243,7 +250,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": W["name"], "rows_per_gpu": m, "cols": n, "nnz_per_gpu": nnz, "strategy": strat,
                    "alpha": alpha, "beta": beta, "scale": args.scale,
-                   "parallelism": "single GPU" if world == 1 else f"row-range shard x{world} + RCCL allgather(y)"},
+                   "parallelism": "single GPU" if world == 1 else f"row-range shard x{world} + allgather(y) over {'RCCL' if backend == 'nccl' else backend}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": pmc_traffic(args.workload, strat) if args.scale == 1.0 else None,

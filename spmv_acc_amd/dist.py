@@ -7,6 +7,13 @@ partition needs no reduction: rank r computes y[r0:r1) from its CSR slice (rebas
 ids) and a full copy of x, then every rank receives every slice.  Shards are padded to the same row count
 because RCCL has no allgatherv.
 
+The exchange has two forms with the same result (every rank ends with every slice): RCCL's ``all_gather_into_tensor``,
+and a direct fan-out -- every rank sends its slice to each of its world-1 peers and receives theirs, all in one
+grouped batch of point-to-point operations, staggered so that at every position of the batch each rank talks to a
+different peer.  On a fully connected xGMI node (7 links per GPU) the fan-out drives all links at once whatever
+ring/tree RCCL would pick for the collective; which one is faster is measured on the job's own communicator
+(``tune_exchange``), not assumed.
+
 The local compute is pluggable (``local_spmv``) so the partition / padding / collective logic can be
 exercised with the gloo backend on CPU in tests; the default is the HIP library and there is no CPU
 fallback in the product path.
@@ -18,6 +25,9 @@ from typing import Callable, Optional
 import numpy as np
 
 import spmv_acc_amd
+
+
+EXCHANGE_MODES = ("allgather", "p2p")
 
 
 def shard_bounds(m: int, world: int, mode: int = 0, h_rowptr=None):
@@ -47,7 +57,8 @@ class RowShardedSpmv:
     """
 
     def __init__(self, rank: int, world: int, bounds, rowptr, cols, vals, n: int, device, strategy="adaptive",
-                 local_spmv: Optional[Callable] = None, h_rowptr=None, always_collective: bool = False):
+                 local_spmv: Optional[Callable] = None, h_rowptr=None, always_collective: bool = False,
+                 exchange: str = "allgather"):
         import torch
 
         self.torch = torch
@@ -65,6 +76,9 @@ class RowShardedSpmv:
         self.device = device
         self.local_spmv = local_spmv or self._hip_spmv
         self.always_collective = always_collective  # issue the allgather even on a one-rank group (RCCL rehearsal)
+        if exchange not in EXCHANGE_MODES:
+            raise ValueError(f"exchange must be one of {EXCHANGE_MODES}")
+        self.exchange = exchange
         # two y buffers: the allgather of step k may still be reading one while step k+1 writes the other
         self.y_local = [torch.zeros(self.pad, dtype=torch.float64, device=device) for _ in range(2)]
         self.y_full = torch.zeros(world * self.pad, dtype=torch.float64, device=device)
@@ -92,11 +106,55 @@ class RowShardedSpmv:
         if self.world == 1 and not self.always_collective:
             self.y_full[: self.pad].copy_(buf)
             return None
-        work = dist.all_gather_into_tensor(self.y_full, buf, group=group, async_op=True)
+        work = self._issue_exchange(buf, group)
         self._pending = work
         if not overlap:
             self.wait()
         return work
+
+    def _issue_exchange(self, buf, group=None):
+        """Start moving ``buf`` (this rank's padded slice) into every rank's y_full; returns the pending work(s)."""
+        import torch.distributed as dist
+
+        if self.exchange == "allgather":
+            return [dist.all_gather_into_tensor(self.y_full, buf, group=group, async_op=True)]
+        pad, rank, world = self.pad, self.rank, self.world
+        self.y_full[rank * pad: (rank + 1) * pad].copy_(buf)
+        ops = []
+        for k in range(1, world):  # position k: send to rank+k, receive from rank-k -- a different peer pair per position
+            dst, src = (rank + k) % world, (rank - k) % world
+            ops.append(dist.P2POp(dist.isend, buf, dst, group))
+            ops.append(dist.P2POp(dist.irecv, self.y_full[src * pad: (src + 1) * pad], src, group))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def tune_exchange(self, group=None, warm: int = 2, iters: int = 5):
+        """Time both exchange forms on this job's communicator (slice-sized messages, no SpMV), agree on the faster
+        across ranks (max over ranks per form) and keep it.  Returns {form: ms per exchange}."""
+        import time
+
+        import torch.distributed as dist
+
+        self.wait()
+        buf = self.y_local[0]
+        on_gpu = buf.is_cuda
+        result = {}
+        for mode in EXCHANGE_MODES:
+            self.exchange = mode
+            for i in range(warm + iters):
+                if i == warm:
+                    if on_gpu:
+                        self.torch.cuda.synchronize()
+                    dist.barrier(group=group)
+                    t0 = time.perf_counter()
+                for w in self._issue_exchange(buf, group):
+                    w.wait()
+            if on_gpu:
+                self.torch.cuda.synchronize()
+            t = self.y_full.new_tensor([(time.perf_counter() - t0) / iters * 1e3])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            result[mode] = float(t.item())
+        self.exchange = min(result, key=result.get)  # same numbers on every rank -> same choice
+        return result
 
     def set_y(self, y_slice):
         """Seed both y buffers with this rank's slice of y (for in-place iteration with beta != 0)."""
@@ -105,7 +163,8 @@ class RowShardedSpmv:
 
     def wait(self):
         if self._pending is not None:
-            self._pending.wait()
+            for w in self._pending:
+                w.wait()
             self._pending = None
 
     def gathered(self):

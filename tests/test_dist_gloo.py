@@ -1,4 +1,4 @@
-"""CPU suite, world_size 2 (gloo): the row-range shard + allgather(y) path.  The local SpMV is injected
+"""CPU suite, world_size 2 and 3 (gloo): the row-range shard + allgather(y) path in both exchange forms.  The local SpMV is injected
 (the oracle stands in for the HIP kernels, which need a GPU); partition, CSR slicing, padding, the
 double-buffered allgather and the re-assembly of y are the product code under test."""
 import os
@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, m, out_path):
+def _worker(rank, world, port, mode, m, out_path, exchange="allgather"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -46,7 +46,9 @@ def _worker(rank, world, port, mode, m, out_path):
         yl = yt.numpy()[: r1 - r0]
         oracle_lib.host_spmv_inplace(alpha, beta, rp, ci, v, xt.numpy(), yl)
 
-    eng = RowShardedSpmv(rank, world, bounds, rp, ci, v, n, torch.device("cpu"), local_spmv=local_spmv)
+    eng = RowShardedSpmv(rank, world, bounds, rp, ci, v, n, torch.device("cpu"), local_spmv=local_spmv,
+                         exchange="allgather" if exchange == "tune" else exchange)
+    tuned = eng.tune_exchange(warm=1, iters=2) if exchange == "tune" else None
     xt = torch.from_numpy(x)
     ylocal = torch.from_numpy(y0[r0:r1].copy())
     results = []
@@ -55,24 +57,31 @@ def _worker(rank, world, port, mode, m, out_path):
         eng.step(alpha, beta, xt, y_prev=ylocal, overlap=True)  # second step exercises the double buffer
         results.append(eng.gathered().numpy().copy())
     if rank == 0:
-        np.savez(out_path, bounds=bounds, **{f"y{i}": r for i, r in enumerate(results)})
+        np.savez(out_path, bounds=bounds, exchange=np.array(eng.exchange), tuned=np.array(sorted(tuned) if tuned else []),
+                 **{f"y{i}": r for i, r in enumerate(results)})
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,m", [(0, 4001), (1, 4001), (0, 4096)])
-def test_row_sharded_spmv_world2(tmp_path, oracle, mode, m):
+@pytest.mark.parametrize("mode,m,world,exchange", [(0, 4001, 2, "allgather"), (1, 4001, 2, "allgather"), (0, 4096, 2, "allgather"),
+                                                   (0, 4001, 2, "p2p"), (1, 4001, 3, "p2p"), (0, 4099, 3, "tune")])
+def test_row_sharded_spmv_world2(tmp_path, oracle, mode, m, world, exchange):
+    """world 2 and 3, both exchange forms (RCCL allgather / direct fan-out) and the timed choice between them."""
     from spmv_acc_amd import synth
 
     out = str(tmp_path / "y.npz")
-    mp.spawn(_worker, args=(2, _free_port(), mode, m, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, m, out, exchange), nprocs=world, join=True)
     g = np.load(out)
+    if exchange == "tune":
+        assert list(g["tuned"]) == ["allgather", "p2p"] and str(g["exchange"]) in ("allgather", "p2p")
+    else:
+        assert str(g["exchange"]) == exchange
     rowptr, cols, vals = synth.random_csr(m, m, 7, seed=123, kind="powerlaw")
     rng = np.random.default_rng(5)
     x = rng.standard_normal(m)
     y0 = rng.standard_normal(m)
     b = g["bounds"]
-    assert b[0] == 0 and b[-1] == m and len(b) == 3
+    assert b[0] == 0 and b[-1] == m and len(b) == world + 1
     for i, (alpha, beta) in enumerate(((1.0, 1.0), (0.5, 0.0), (2.0, -1.0))):
         ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
         assert g[f"y{i}"].shape == (m,)
