@@ -658,10 +658,15 @@ def test_randomised_shapes_all_strategies(torch_dev, oracle):
     """Fuzz: 160 random (valid) CSR matrices -- sizes, row-length laws, column laws, ragged nnz, unaligned views,
     alpha/beta -- through every hot strategy, against the oracle."""
     torch = torch_dev
-    rng = np.random.default_rng(20261003)
-    for case in range(160):
+    # soak runs: SPMV_ACC_FUZZ_CASES / SPMV_ACC_FUZZ_SEED / SPMV_ACC_FUZZ_ALL=1 (every strategy name, not only the hot ones)
+    cases = int(os.environ.get("SPMV_ACC_FUZZ_CASES", "160"))
+    rng = np.random.default_rng(int(os.environ.get("SPMV_ACC_FUZZ_SEED", "20261003")))
+    strategies = ALL if os.environ.get("SPMV_ACC_FUZZ_ALL") == "1" else spmv_acc_amd.HOT_STRATEGIES
+    for case in range(cases):
         m = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 257, 1000, 4099, 20011]))
         n = int(rng.choice([1, 2, 64, 1000, 5000, 30000]))
+        if cases > 160 and case % 7 == 3:  # soak only: arbitrary sizes
+            m, n = int(rng.integers(1, 60000)), int(rng.integers(1, 80000))
         law = case % 8
         if law == 0:
             lens = rng.integers(0, 9, m)
@@ -705,7 +710,7 @@ def test_randomised_shapes_all_strategies(torch_dev, oracle):
             dci, dv = dev(torch, cols), dev(torch, vals)
         drp, dx = dev(torch, rowptr), dev(torch, x)
         ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
-        for strat in spmv_acc_amd.HOT_STRATEGIES:
+        for strat in strategies:
             dy = dev(torch, y0)
             spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat)
             torch.cuda.synchronize()
