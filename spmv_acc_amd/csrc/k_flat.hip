@@ -67,39 +67,54 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
   // reach: a tile finishes its last row itself when it ends at most `reach` (0 or kFlatFinish) non-zeros past the tile
   constexpr int STRIDE = kThreads * NPT;
   __shared__ __attribute__((aligned(16))) double lds[STRIDE]; // written 16 B at a time
-  __shared__ double sh_tail_sum;                               // partial of the row this tile will finish itself
+  __shared__ double sh_tail_sum, sh_tail_yold;                 // partial (and old y) of the row this tile will finish itself
   __shared__ int sh_tail_row, sh_tail_end;
   if (threadIdx.x == 0) sh_tail_row = -1;
   const int t = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, ntiles, xcd_chunk) : static_cast<int>(blockIdx.x);
   const int t0 = t * STRIDE; // host guarantees nnz + stride fits in int
   const int t1 = (nnz - t0 > STRIDE) ? t0 + STRIDE : nnz;
 
-  // the tile's row range first (scalar loads, independent of the stream) so it is known long before the
-  // products are
+  // The tile's row range first (scalar chain bp -> rowptr), then each lane group's row extents and old y, THEN the
+  // stream: the reduction after the barrier finds everything in registers (no global latency follows the barrier on the
+  // common path).  Issuing the stream loads before this chain instead (split staging) was measured: +46 VGPRs, occupancy
+  // 8 -> 5, 2-4 % slower on six of seven stand-ins.
   int first = bp[t];
   first = first < m ? first : m;
   const int end_excl = tile_end_excl(rp, bp, t, ntiles, m, t1);
   const int nrows = end_excl - first;
 
-  stage_products<kThreads, NPT, ALIGNED, NTC, NTV>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
-
   // lanes per row for this tile: as many as the tile's row count leaves room for (wave-uniform)
   int w = 1;
   while (w < 64 && nrows * (w * 2) <= kThreads) w <<= 1;
-
-  __syncthreads();
-
   const int lane = threadIdx.x & (w - 1);
   const int vec_id = threadIdx.x / w;
   const int vecs = kThreads / w;
+  // row extents and old y of the first pass over the rows (the only pass unless the tile holds more than 256 rows)
+  const bool live0 = vec_id < nrows;
+  int a0 = 0, b0 = 0;
+  if (live0) {
+    a0 = rp[first + vec_id];
+    b0 = rp[first + vec_id + 1];
+  }
+  const bool early_y = beta != 0.0;
+  double y_old0 = 0.0;
+  if (early_y && live0 && lane == 0) y_old0 = y[first + vec_id]; // read for cut rows too (<= 2 per tile): harmless
+
+  stage_products<kThreads, NPT, ALIGNED, NTC, NTV>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
+
+  __syncthreads();
+
   // all lanes walk the same number of iterations so the DPP reduction sees a full exec mask
   for (int base = 0; base < nrows; base += vecs) {
     const int r = first + base + vec_id;
     const bool live = (base + vec_id) < nrows;
-    int a = 0, b = 0;
-    if (live) {
-      a = rp[r];
-      b = rp[r + 1];
+    int a = a0, b = b0;
+    if (base > 0) {
+      a = b = 0;
+      if (live) {
+        a = rp[r];
+        b = rp[r + 1];
+      }
     }
     const int lo = (a > t0 ? a : t0) - t0;
     const int hi = (b < t1 ? b : t1) - t0;
@@ -108,7 +123,9 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
     s = group_sum_dyn(s, w);
     if (live && lane == 0) {
       if (a >= t0 && b <= t1) {
-        store_y(y, r, alpha, beta, s); // complete row (possibly empty): final value
+        // complete row (possibly empty): final value
+        if (base == 0 && early_y) y[r] = alpha * s + beta * y_old0;
+        else store_y(y, r, alpha, beta, s);
       } else if (a < t0) {
         // row started in an earlier tile.  Its owner (the tile it starts in) finishes a short overhang itself; only a
         // row that runs more than kFlatFinish non-zeros past its owner's end is folded from carries.
@@ -118,6 +135,7 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
         sh_tail_sum = s; // row starts here and ends at most kFlatFinish non-zeros into the next tile(s): finished below
         sh_tail_row = r;
         sh_tail_end = b;
+        sh_tail_yold = (base == 0 && early_y) ? y_old0 : (early_y ? y[r] : 0.0);
       } else {
         tail[t] = s; // long row: carry, folded by the fix-up kernel in tile order
         tail_row[t] = r;
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
         if (cc[k] >= 0) extra += vv[k] * x[cc[k]];
     }
     extra = group_sum<64>(extra);
-    if (r >= 0 && threadIdx.x == 0) store_y(y, r, alpha, beta, sh_tail_sum + extra);
+    if (r >= 0 && threadIdx.x == 0) y[r] = (beta == 0.0) ? alpha * (sh_tail_sum + extra) : alpha * (sh_tail_sum + extra) + beta * sh_tail_yold;
   }
   // a tile without a carried row says so (the fix-up reads tail_row only)
   if (threadIdx.x == 0) {
