@@ -69,8 +69,11 @@ Tunable g_tunables[] = {
     {"copy_nt", 1, 1},         // copy-ceiling probe: non-temporal loads/stores (0 = default cache policy)
     {"stage_fast", 1, 1},      // tile staging: wave-skip + branch-free form (0: per-lane predicated loads)
     {"early_y", 1, 1},         // row-block kernel: load the old y before the tile instead of after it
-    {"rowblock_guard", 1, 1},  // imbalance probe + flat rescue for the row-block family
+    {"rowblock_guard", 1, 1},  // imbalance probe + rescue for the row-block family
+    {"rescue_flat", 0, 0},     // 1: the rescue is flat (nnz-cut tiles) instead of the row-block-plus kernel
     {"plus_ref_vec", 0, 0},
+    {"plus_min_nnz", 0, 0},    // adaptive-plus analysis: MIN_NNZ_PER_BLOCK; 0 = time 1024 (the reference's instance) / 1536 /
+                               // 1920 on the matrix and keep the fastest
     {"plus_host_analysis", 0, 0}, // 1: run the row-block analysis on the host (the reference's form)    // 1: row-block-plus analysis with the reference's VEC_SIZE pick
     {"flat_finish", -1, -1},   // flat cut rows: -1 time both forms per matrix, 0 carries + fix-up kernel, 1 tiles finish them (when legal)
     {"flat_npt", 8, 8},
@@ -238,10 +241,13 @@ int plus_pick_vec(int m, int nnz) {
   return v;
 }
 
-int plus_pick_vec_tuned(int m, int nnz) {
+int plus_pick_vec_tuned(int m, int nnz, int min_nnz) {
   const long long avg = (m > 0) ? static_cast<long long>(nnz) / m : 0;
+  // largest pow2 v with (THREADS / v) * avg >= 1.25 * MIN_NNZ (avg/5 for MIN_NNZ 1024): blocks then close on their
+  // non-zero count, not on the row cap
+  const long long per_vec = (5LL * min_nnz + 4 * kPlusThreads - 1) / (4 * kPlusThreads);
   int v = 1;
-  while (v < 64 && static_cast<long long>(v) * 2 * 5 <= avg) v <<= 1; // largest pow2 <= avg/5: cap*avg >= 1.25*MIN_NNZ
+  while (v < 64 && static_cast<long long>(v) * 2 * per_vec <= avg) v <<= 1;
   return v;
 }
 
@@ -308,6 +314,8 @@ struct Plan {
   // row-block-plus
   int plus_blocks = -1;
   int plus_vec = 0;
+  int plus_min = 0; // MIN_NNZ_PER_BLOCK the analysis ran with
+  int plus_tuned_min = 0; // the timed choice (0 = not timed yet)
   bool plus_has_long = false;
   int *d_pbp = nullptr;
   int *d_pfbr = nullptr;
@@ -515,9 +523,11 @@ int plus_analyze_device(int m, int min_nnz, int threads, int vec, const int *d_r
 
 namespace {
 
-bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
-  const int want_vec = get_tunable("plus_ref_vec") ? plus_pick_vec(p.A.m, p.A.nnz) : plus_pick_vec_tuned(p.A.m, p.A.nnz);
-  if (p.plus_blocks >= 0 && p.plus_vec == want_vec) return true;
+bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) {
+  if (min_nnz < 256 || min_nnz > kTile) min_nnz = kPlusMinNnz;
+  const int want_vec =
+      get_tunable("plus_ref_vec") ? plus_pick_vec(p.A.m, p.A.nnz) : plus_pick_vec_tuned(p.A.m, p.A.nnz, min_nnz);
+  if (p.plus_blocks >= 0 && p.plus_vec == want_vec && p.plus_min == min_nnz) return true;
   if (p.plus_blocks >= 0) { // analysis parameters changed (measurement switch): rebuild
     if (p.d_pbp) (void)hipFree(p.d_pbp);
     if (p.d_pfbr) (void)hipFree(p.d_pfbr);
@@ -546,7 +556,7 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
       hrp = staged.data();
     }
     std::vector<int> bp, fbr;
-    blocks = plus_analyze_host(m, kPlusMinNnz, kPlusThreads, vec, hrp, bp, fbr);
+    blocks = plus_analyze_host(m, min_nnz, kPlusThreads, vec, hrp, bp, fbr);
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pbp), sizeof(int) * bp.size()), "hipMalloc plus bp")) return false;
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pfbr), sizeof(int) * fbr.size()), "hipMalloc plus fbr"))
       return false;
@@ -556,7 +566,7 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
       return false;
   } else {
     // device form: no host rowptr, no PCIe traffic beyond one int
-    blocks = analyze_on_device(stream, p.A.rp, m, kPlusMinNnz, kPlusThreads, vec, &p.d_pbp, &p.d_pfbr);
+    blocks = analyze_on_device(stream, p.A.rp, m, min_nnz, kPlusThreads, vec, &p.d_pbp, &p.d_pfbr);
     if (blocks < 0) return false;
   }
   int *d_flag = nullptr;
@@ -568,13 +578,14 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream) {
   int has_long = 0;
   bool ok = hip_ok(hipMemsetAsync(d_flag, 0, sizeof(int), stream), "memset plus flag");
   if (ok) {
-    launch_plus_digest(stream, p.A, p.d_pbp, p.d_pfbr, blocks, p.d_pblk, d_flag);
+    launch_plus_digest(stream, p.A, p.d_pbp, p.d_pfbr, blocks, 2 * min_nnz, p.d_pblk, d_flag);
     ok = hip_ok(hipMemcpyAsync(&has_long, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream), "read plus flag") &&
          hip_ok(hipStreamSynchronize(stream), "sync plus digest");
   }
   (void)hipFree(d_flag);
   if (!ok) return false;
   p.plus_vec = vec;
+  p.plus_min = min_nnz;
   p.plus_blocks = blocks;
   p.plus_has_long = has_long != 0;
   return true;
@@ -736,7 +747,9 @@ bool probe_rowblock(Plan &p, int rpb, hipStream_t st) {
 // line-enhance family with its imbalance rescue: fixed row blocks while every block stays within a
 // few LDS rounds, otherwise the same tile machinery cut by non-zeros (flat) so hub rows are shared
 // by many workgroups instead of serialising one.
-bool run_rowblock(hipStream_t st, Plan &p, double alpha, double beta, const double *x, double *y) {
+bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y);
+
+bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y) {
   int vec = 1, rpb = kThreads;
   pick_rowblock_shape(p.A.m, p.A.nnz, get_tunable("rowblock_target"), &vec, &rpb);
   const int forced = get_tunable("rowblock_vec");
@@ -746,7 +759,12 @@ bool run_rowblock(hipStream_t st, Plan &p, double alpha, double beta, const doub
   }
   if (get_tunable("rowblock_guard")) {
     if (!probe_rowblock(p, rpb, st)) return false;
-    if (p.rowblock_ok == 0) return run_flat(st, p, alpha, beta, x, y);
+    // Imbalanced (power-law) matrix: fixed row blocks would leave a few workgroups with most of the work.  The rescue
+    // is the row-block-PLUS kernel -- the reference's own answer to this (hip-csr-adaptive-plus is its line-enhance
+    // kernel over analysed row blocks, long rows cut into dedicated blocks) -- which measures 1 % (R-MAT scale 25),
+    // 5 % (scale 22) and 17 % (scale 20) faster than the nnz-cut tiles of flat; `rescue_flat` keeps the older choice.
+    if (p.rowblock_ok == 0)
+      return get_tunable("rescue_flat") ? run_flat(st, p, alpha, beta, x, y) : run_plus(st, p, h_rowptr, alpha, beta, x, y);
   }
   const int chunk = get_tunable("xcd_chunk");
   const int base_flags = (get_tunable("xcd_remap") ? 1 : 0) | (get_tunable("early_y") ? 2 : 0) |
@@ -756,6 +774,59 @@ bool run_rowblock(hipStream_t st, Plan &p, double alpha, double beta, const doub
       }))
     return false;
   launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p) << 4), alpha, beta, x, y);
+  return true;
+}
+
+// adaptive-plus: analysis (row blocks) + the two per-matrix timings.  MIN_NNZ_PER_BLOCK decides how full a block's
+// 2048-product tile gets: 1024 (the reference's instance) half-fills it, 1920 fills it but pushes blocks with one longer
+// row into a second round; which wins depends on the row-length law (FEM-like: 1536-1920, -10..-18 % time; power-law: 1024),
+// so the candidates are timed once per matrix like the cache policy.
+bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double *x) {
+  auto launch = [&](int pol, double *ys) {
+    launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, get_tunable("xcd_chunk_tiles"), pol,
+                p.d_ppartial, 1.0, 0.0, x, ys);
+  };
+  const int forced = get_tunable("plus_min_nnz");
+  if (forced > 0 || get_tunable("plus_ref_vec")) {
+    return ensure_plus(p, h_rowptr, st, forced > 0 ? forced : kPlusMinNnz) && autotune_policy(p, st, launch);
+  }
+  if (p.plus_tuned_min > 0) return ensure_plus(p, h_rowptr, st, p.plus_tuned_min) && autotune_policy(p, st, launch);
+  // first call on this matrix: cache policy on the middle candidate, then the three block sizes under that policy
+  if (!ensure_plus(p, h_rowptr, st, 1536) || !autotune_policy(p, st, launch)) return false;
+  double *scratch = nullptr;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
+    return false;
+  hipEvent_t e0, e1;
+  bool ok = hip_ok(hipEventCreate(&e0), "event") && hip_ok(hipEventCreate(&e1), "event");
+  const int candidates[3] = {1536, 1920, kPlusMinNnz};
+  float best = 1e30f;
+  int best_min = kPlusMinNnz;
+  for (int c = 0; ok && c < 3; ++c) {
+    ok = ensure_plus(p, h_rowptr, st, candidates[c]);
+    if (!ok) break;
+    for (int w = 0; w < 2; ++w) launch(policy_for(p), scratch);
+    (void)hipEventRecord(e0, st);
+    for (int t = 0; t < 4; ++t) launch(policy_for(p), scratch);
+    (void)hipEventRecord(e1, st);
+    float ms = 0.f;
+    ok = hip_ok(hipEventSynchronize(e1), "sync tune") && hip_ok(hipEventElapsedTime(&ms, e0, e1), "elapsed tune");
+    if (ok && ms < best) {
+      best = ms;
+      best_min = candidates[c];
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(scratch);
+  if (!ok) return false;
+  p.plus_tuned_min = best_min;
+  return ensure_plus(p, h_rowptr, st, best_min);
+}
+
+bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y) {
+  if (!run_plus_prepare(p, h_rowptr, st, x)) return false;
+  launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, get_tunable("xcd_chunk_tiles"),
+              policy_for(p), p.d_ppartial, alpha, beta, x, y);
   return true;
 }
 
@@ -805,7 +876,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   case kThreadRow:
   case kLineEnhance:
   case kLine:
-    run_rowblock(st, *p, alpha, beta, dx, dy);
+    run_rowblock(st, *p, h_rowptr, alpha, beta, dx, dy);
     break;
   case kFlat:
     run_flat(st, *p, alpha, beta, dx, dy);
@@ -826,20 +897,13 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
       // the row-block kernel carries a plan-time balance probe and falls back to the nnz-cut tiles (flat) exactly
       // then, and measures 1-5 % faster than flat on the balanced large-set stand-ins (one kernel, no carry
       // fix-up), so every non-split branch goes through it.
-      run_rowblock(st, *p, alpha, beta, dx, dy);
+      run_rowblock(st, *p, h_rowptr, alpha, beta, dx, dy);
       break;
     }
     break;
   }
   case kAdaptivePlus:
-    if (!ensure_plus(*p, h_rowptr, st)) return;
-    if (!autotune_policy(*p, st, [&](int pol, double *ys) {
-          launch_plus(st, p->A, p->d_pbp, p->d_pfbr, p->d_pblk, p->plus_blocks, p->plus_has_long,
-                      get_tunable("xcd_chunk_tiles"), pol, p->d_ppartial, 1.0, 0.0, dx, ys);
-        }))
-      return;
-    launch_plus(st, p->A, p->d_pbp, p->d_pfbr, p->d_pblk, p->plus_blocks, p->plus_has_long, get_tunable("xcd_chunk_tiles"),
-                policy_for(*p), p->d_ppartial, alpha, beta, dx, dy);
+    run_plus(st, *p, h_rowptr, alpha, beta, dx, dy);
     break;
   default:
     set_error(kErrUnknownStrategy, "unknown strategy id");

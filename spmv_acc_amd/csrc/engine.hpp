@@ -85,7 +85,7 @@ int plus_analyze_host(int m, int min_nnz_per_block, int threads_per_block, int v
 int plus_analyze_device(int m, int min_nnz_per_block, int threads_per_block, int vec_size, const int *d_rowptr,
                         int *d_break_points, int bp_cap, int *d_first_block_of_row);
 int plus_pick_vec(int m, int nnz);       // csr_adaptive_plus_spmv.cpp:139-165
-int plus_pick_vec_tuned(int m, int nnz); // row cap chosen so blocks close on MIN_NNZ_PER_BLOCK, not on the cap
+int plus_pick_vec_tuned(int m, int nnz, int min_nnz); // row cap chosen so blocks close on MIN_NNZ_PER_BLOCK, not on the cap
 
 // ---- execution ------------------------------------------------------------------------------------------
 // One SpMV y = alpha*A*x + beta*y with the given strategy.  h_rowptr may be null: the four samples

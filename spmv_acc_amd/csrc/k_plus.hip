@@ -39,7 +39,7 @@ __device__ __forceinline__ int first_block_at_row(const int *__restrict__ bp, in
 // kernel starts streaming after ONE scalar load instead of the bp -> first_block_of_row -> rowptr chain.
 //   normal block : {row_begin, row_end, nnz_begin, nnz_end}
 //   long-row slice: {row, -1, slice_begin, slice_end}
-__global__ __launch_bounds__(256) void plus_digest_kernel(int m, int nblocks, const int *__restrict__ bp,
+__global__ __launch_bounds__(256) void plus_digest_kernel(int m, int nblocks, int long_chunk, const int *__restrict__ bp,
                                                           const int *__restrict__ fbr, const int *__restrict__ rp,
                                                           int4v *__restrict__ blk, int *__restrict__ has_long) {
   const int g = blockIdx.x * 256 + threadIdx.x;
@@ -57,12 +57,12 @@ __global__ __launch_bounds__(256) void plus_digest_kernel(int m, int nblocks, co
   } else {
     const int r = row_begin;
     const int idx = g - first_block_at_row(bp, flag, r);
-    const int c0 = rp[r] + idx * kPlusLongChunk;
+    const int c0 = rp[r] + idx * long_chunk;
     const bool last = bp[g + 1] != r;
     rec.x = r;
     rec.y = -1;
     rec.z = c0;
-    rec.w = last ? rp[r + 1] : c0 + kPlusLongChunk;
+    rec.w = last ? rp[r + 1] : c0 + long_chunk;
     *has_long = 1; // idempotent store
   }
   blk[g] = rec;
@@ -146,10 +146,10 @@ __global__ __launch_bounds__(256) void plus_fixup_kernel(int m, int nblocks, dou
 
 } // namespace
 
-void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, void *blk,
-                        int *d_has_long) {
+void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, int long_chunk,
+                        void *blk, int *d_has_long) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(plus_digest_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, A.m, nblocks, bp, fbr, A.rp,
+  hipLaunchKernelGGL(plus_digest_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, A.m, nblocks, long_chunk, bp, fbr, A.rp,
                      static_cast<int4v *>(blk), d_has_long);
 }
 

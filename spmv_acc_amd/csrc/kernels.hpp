@@ -98,7 +98,7 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
 // made with threads_per_block = kPlusThreads).  launch_plus_digest (once per plan) packs one 16-B record per
 // block into blk (nblocks * 16 bytes); the long-row fix-up runs only when the analysis found long rows.
 // *d_has_long (pre-zeroed) is set to 1 if any block is a long-row slice.
-void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, void *blk,
+void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, int long_chunk, void *blk,
                         int *d_has_long);
 void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, const void *blk, int nblocks,
                  bool has_long_rows, int xcd_chunk, int stream_policy, double *partial, double alpha, double beta,

@@ -466,9 +466,22 @@ def test_rmat_power_law_parity(torch_dev, oracle):
         err = oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 1.0, hrp, hci, hv, hx, hy0)
         assert err <= SCALED_TOL, (strat, err)
         assert oracle.verify_y(y.cpu().numpy(), ref)[2] == 0, strat
-    info = spmv_acc_amd.query_plan(rp, m)
-    assert info["flat_tiles"] > 0  # the balance probe sent line_enhance / adaptive to the nnz-cut tiles
     spmv_acc_amd.release_plans(rp)
+    # the balance probe sends line_enhance / adaptive to the row-block-plus kernel (tunable rescue_flat: to the nnz-cut tiles)
+    lib = spmv_acc_amd.load_library()
+    for rescue_flat, built, not_built in ((0, "plus_blocks", "flat_tiles"), (1, "flat_tiles", "plus_blocks")):
+        assert lib.spmv_acc_set_tunable(b"rescue_flat", rescue_flat) == 0
+        try:
+            for strat in ("line_enhance", "adaptive"):
+                y = y0.clone()
+                spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
+                torch.cuda.synchronize()
+                assert oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 1.0, hrp, hci, hv, hx, hy0) <= SCALED_TOL, (strat, rescue_flat)
+            info = spmv_acc_amd.query_plan(rp, m)
+            assert info[built] > 0 and info[not_built] <= 0, (rescue_flat, info)
+        finally:
+            lib.spmv_acc_reset_tunables()
+            spmv_acc_amd.release_plans(rp)
 
 
 def test_banded_shard_closed_form(torch_dev):
