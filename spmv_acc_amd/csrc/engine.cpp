@@ -597,9 +597,40 @@ int policy_for(const Plan &p) {
   return p.stream_policy >= 0 ? p.stream_policy : kStreamPolicyNt;
 }
 
+// Shared by the per-matrix timings below: average milliseconds of fn() in the cache state fn itself leaves behind.  The
+// first launch is timed alone and sizes the rest, so tuning a matrix whose SpMV takes milliseconds costs 2 launches per
+// candidate, not 8: under 0.5 ms per launch 2 more warm-ups + 5 timed, under 2 ms 2 + 2, else the one warm-up + 1 timed.
+struct TuneTimer {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool ok = false;
+  TuneTimer() { ok = hip_ok(hipEventCreate(&e0), "event") && hip_ok(hipEventCreate(&e1), "event"); }
+  ~TuneTimer() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+  template <typename F> bool time(hipStream_t st, F &&fn, float *ms_per_launch) {
+    if (!ok) return false;
+    float first = 0.f;
+    (void)hipEventRecord(e0, st);
+    fn();
+    (void)hipEventRecord(e1, st);
+    if (!hip_ok(hipEventSynchronize(e1), "sync tune") || !hip_ok(hipEventElapsedTime(&first, e0, e1), "elapsed tune")) return false;
+    const int warm = first < 2.0f ? 2 : 0;
+    const int timed = first < 0.5f ? 5 : (first < 2.0f ? 2 : 1);
+    for (int w = 0; w < warm; ++w) fn();
+    (void)hipEventRecord(e0, st);
+    for (int t = 0; t < timed; ++t) fn();
+    (void)hipEventRecord(e1, st);
+    float ms = 0.f;
+    if (!hip_ok(hipEventSynchronize(e1), "sync tune") || !hip_ok(hipEventElapsedTime(&ms, e0, e1), "elapsed tune")) return false;
+    *ms_per_launch = ms / timed;
+    return true;
+  }
+};
+
 // Time the stream-load cache policies on THIS matrix with the kernel family that will run it (scratch y, beta = 0:
-// no side effects on the caller's y) and keep the fastest.  Eight launches per candidate (3 to reach that policy's
-// cache steady state + 5 timed): 24 SpMVs' worth of time, once per matrix.
+// no side effects on the caller's y) and keep the fastest.  Up to eight launches per candidate (TuneTimer: 3 to reach
+// that policy's cache steady state + 5 timed; 2 in all when a launch takes milliseconds), once per matrix.
 template <typename Launch> bool autotune_policy(Plan &p, hipStream_t st, Launch &&launch) {
   if (p.stream_policy >= 0 || get_tunable("stream_plain") >= 0 || !p.A.aligned16) {
     if (p.stream_policy < 0) p.stream_policy = kStreamPolicyNt;
@@ -608,27 +639,21 @@ template <typename Launch> bool autotune_policy(Plan &p, hipStream_t st, Launch 
   double *scratch = nullptr;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
     return false;
-  hipEvent_t e0, e1;
-  bool ok = hip_ok(hipEventCreate(&e0), "event") && hip_ok(hipEventCreate(&e1), "event");
+  TuneTimer timer;
+  bool ok = timer.ok;
   const int candidates[3] = {kStreamPolicyNt, kStreamPolicyDefault, kStreamPolicyValueDefault};
   float best = 1e30f;
   int best_policy = kStreamPolicyNt;
   for (int c = 0; ok && c < 3; ++c) {
     // the policies differ through what they leave in the Infinity Cache for the NEXT SpMV, so each candidate first
     // runs until the caches hold its own steady state, then is timed over several launches
-    for (int w = 0; w < 3; ++w) launch(candidates[c], scratch);
-    (void)hipEventRecord(e0, st);
-    for (int t = 0; t < 5; ++t) launch(candidates[c], scratch);
-    (void)hipEventRecord(e1, st);
     float ms = 0.f;
-    ok = hip_ok(hipEventSynchronize(e1), "sync tune") && hip_ok(hipEventElapsedTime(&ms, e0, e1), "elapsed tune");
+    ok = timer.time(st, [&] { launch(candidates[c], scratch); }, &ms);
     if (ok && ms < best) {
       best = ms;
       best_policy = candidates[c];
     }
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   (void)hipFree(scratch);
   if (ok) p.stream_policy = best_policy;
   return ok;
@@ -661,19 +686,13 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
   double *scratch = nullptr;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
     return false;
-  hipEvent_t e0, e1;
-  bool ok = hip_ok(hipEventCreate(&e0), "event") && hip_ok(hipEventCreate(&e1), "event");
+  TuneTimer timer;
+  bool ok = timer.ok;
   float ms[2] = {0.f, 0.f};
   for (int mode = 0; ok && mode < 2; ++mode) {
     F.needs_fixup = mode == 0;
-    for (int w = 0; w < 3; ++w) launch_flat_with(st, p, policy_for(p), 1.0, 0.0, x, scratch);
-    (void)hipEventRecord(e0, st);
-    for (int t = 0; t < 5; ++t) launch_flat_with(st, p, policy_for(p), 1.0, 0.0, x, scratch);
-    (void)hipEventRecord(e1, st);
-    ok = hip_ok(hipEventSynchronize(e1), "sync tune") && hip_ok(hipEventElapsedTime(&ms[mode], e0, e1), "elapsed tune");
+    ok = timer.time(st, [&] { launch_flat_with(st, p, policy_for(p), 1.0, 0.0, x, scratch); }, &ms[mode]);
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   (void)hipFree(scratch);
   F.tuned_fixup = F.needs_fixup = !(ok && ms[1] < ms[0]);
   F.mode_tuned = ok;
@@ -796,27 +815,21 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
   double *scratch = nullptr;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
     return false;
-  hipEvent_t e0, e1;
-  bool ok = hip_ok(hipEventCreate(&e0), "event") && hip_ok(hipEventCreate(&e1), "event");
+  TuneTimer timer;
+  bool ok = timer.ok;
   const int candidates[3] = {1536, 1920, kPlusMinNnz};
   float best = 1e30f;
   int best_min = kPlusMinNnz;
   for (int c = 0; ok && c < 3; ++c) {
     ok = ensure_plus(p, h_rowptr, st, candidates[c]);
     if (!ok) break;
-    for (int w = 0; w < 2; ++w) launch(policy_for(p), scratch);
-    (void)hipEventRecord(e0, st);
-    for (int t = 0; t < 4; ++t) launch(policy_for(p), scratch);
-    (void)hipEventRecord(e1, st);
     float ms = 0.f;
-    ok = hip_ok(hipEventSynchronize(e1), "sync tune") && hip_ok(hipEventElapsedTime(&ms, e0, e1), "elapsed tune");
+    ok = timer.time(st, [&] { launch(policy_for(p), scratch); }, &ms);
     if (ok && ms < best) {
       best = ms;
       best_min = candidates[c];
     }
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   (void)hipFree(scratch);
   if (!ok) return false;
   p.plus_tuned_min = best_min;
