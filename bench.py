@@ -41,9 +41,11 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-sensitivity", action="store_true", help="skip the far_fraction=0 variant of the N=1 workload")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
-    p.add_argument("--exchange", default="auto", choices=["auto", "allgather", "p2p"],
+    p.add_argument("--exchange", default="auto", choices=["auto", "allgather", "p2p", "ghost"],
                    help="N > 1: how the y slices travel -- RCCL all_gather_into_tensor, a direct point-to-point fan-out "
-                        "over all xGMI links, or (auto) whichever is faster on this job's communicator, timed before the run")
+                        "over all xGMI links, or (auto) whichever is faster on this job's communicator, timed before the run; "
+                        "ghost (square workloads, i.e. --workload banded): x is partitioned like the rows and each rank receives "
+                        "only the entries its columns reference (x <- alpha*A*x iteration, beta = 0)")
     p.add_argument("--no-overlap", action="store_true", help="N>1: wait for each allgather before the next SpMV")
     return p.parse_args()
 
@@ -210,6 +212,36 @@ def main():
         ms = spmv_acc_amd.time_spmv(strat, min(args.steps, 50), alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y)
         out_extra["per_launch_event_ms_median"] = round(float(np.median(ms)), 6)
         out_extra["per_launch_event_ms_min"] = round(float(np.min(ms)), 6)
+    elif args.exchange == "ghost":
+        # square workloads only: x partitioned like the rows, x <- alpha * A * x, each rank receiving just the entries its
+        # columns reference (BASELINE configs[4]: 4 + 3 doubles per neighbour instead of an allgather of 256 MB slices)
+        from spmv_acc_amd.dist import GhostedRowShardedSpmv
+
+        if n != world * m:
+            raise SystemExit("--exchange ghost needs a square workload (--workload banded)")
+        bounds = np.arange(world + 1, dtype=np.int64) * m
+        eng = GhostedRowShardedSpmv(rank, world, bounds, W["rp"], W["ci"], W["v"], device, strategy=strat)
+        eng.set_x(x[rank * m: (rank + 1) * m])
+        alpha, beta = 0.4, 0.0  # spectral radius of 0.4 * A is below 1: the iteration neither overflows nor underflows
+        for _ in range(max(args.warmup, 1)):
+            eng.iterate(alpha)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.iterate(alpha)
+        sync_all()
+        wall = time.perf_counter() - t0
+        xe = eng.x_ext.clone()
+        ms = spmv_acc_amd.time_spmv(strat, min(args.steps, 50), alpha, beta, m, eng.n_local + eng.n_ghost, nnz, W["rp"],
+                                    eng.cols_local, W["v"], xe, y)
+        ev_ms = float(np.mean(ms))
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        out_extra["exchange"] = "ghost"
+        out_extra["spmv_only_gflops_per_gpu"] = round(2.0 * nnz / (ev_ms * 1e-3) / 1e9, 3)
+        out_extra["exchanged_bytes_per_rank_per_step"] = eng.exchanged_bytes_per_step
+        out_extra["ghost_columns"] = eng.n_ghost
     else:
         bounds = np.arange(world + 1, dtype=np.int64) * m  # every rank owns m rows of the (world*m) x n matrix
         eng = RowShardedSpmv(rank, world, bounds, W["rp"], W["ci"], W["v"], n, device, strategy=strat,
@@ -241,7 +273,7 @@ def main():
     ms_per_step = wall / args.steps * 1e3
     nnz_total = nnz * world  # weak scaling: every rank processes its own nnz
     gflops = 2.0 * nnz_total * args.steps / wall / 1e9
-    b_alg = synth.algorithmic_bytes(m, n, nnz, beta_nonzero=True)
+    b_alg = synth.algorithmic_bytes(m, n, nnz, beta_nonzero=beta != 0.0)
     achieved = b_alg / (ev_ms * 1e-3) / 1e9
     result = {
         "metric": "CSR SpMV GFLOP/s (fp64, int32 indices; achieved HBM GB/s in roofline)",

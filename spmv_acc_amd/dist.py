@@ -175,3 +175,122 @@ class RowShardedSpmv:
             k = int(self.bounds[r + 1] - self.bounds[r])
             parts.append(self.y_full[r * self.pad: r * self.pad + k])
         return self.torch.cat(parts)
+
+
+class GhostedRowShardedSpmv:
+    """Row-sharded SpMV for SQUARE matrices whose x is partitioned like the rows (x_{k+1} = f(y_k) solvers): instead of
+    every rank receiving every y slice, each rank receives only the entries of x its columns reference.
+
+    Plan (once per matrix): the distinct column ids outside this rank's own range ("ghosts", sorted, hence grouped by
+    owner) are found on the device; ranks exchange how many and which entries they need from each other; colindex is
+    rewritten once into local numbering -- own columns to [0, n_local), ghosts to n_local + their rank in the sorted ghost
+    list -- so the local SpMV is the ordinary library call on an (m_local) x (n_local + n_ghost) matrix.
+    Step: pack the entries the peers asked for (one gather), one grouped batch of point-to-point sends / receives straight
+    into the ghost segment of x_ext (the ghosts of one owner are contiguous there), local SpMV.
+    For the banded matrix of BASELINE configs[4] the exchange is 4 + 3 doubles per neighbour instead of 256 MB per peer.
+
+    Same summation order per row as the unsharded matrix, so results are bit-identical to it.  Arrays are torch
+    tensors (CPU with gloo in tests, CUDA with RCCL in use); ``local_spmv`` is pluggable as in ``RowShardedSpmv``.
+    """
+
+    def __init__(self, rank: int, world: int, bounds, rowptr, cols, vals, device, strategy="adaptive",
+                 local_spmv: Optional[Callable] = None, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch = torch
+        self.rank, self.world, self.group = rank, world, group
+        self.bounds = np.asarray(bounds, dtype=np.int64)
+        self.c0, self.c1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
+        self.m_local = self.n_local = self.c1 - self.c0
+        self.rowptr, self.vals = rowptr, vals
+        self.nnz_local = int(rowptr[self.m_local])
+        self.strategy, self.device = strategy, device
+        self.local_spmv = local_spmv or self._hip_spmv
+
+        cols64 = cols.to(torch.int64)
+        remote = (cols64 < self.c0) | (cols64 >= self.c1)
+        ghosts = torch.unique(cols64[remote])  # sorted global ids
+        self.n_ghost = int(ghosts.numel())
+        tb = torch.as_tensor(self.bounds, device=ghosts.device)
+        cut = torch.searchsorted(ghosts, tb)  # ghosts owned by p: [cut[p], cut[p+1])
+        want = (cut[1:] - cut[:-1]).to(torch.int64)  # entries this rank needs from each owner (0 for itself)
+        # everyone learns the whole want matrix: asked[q] = what rank q needs from me
+        table = [torch.zeros_like(want) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(table, want, group=group)
+        else:
+            table[0] = want
+        self.recv_counts = [int(v) for v in want.tolist()]
+        self.send_counts = [int(table[q][rank].item()) for q in range(world)]
+        self.ghost_off = [int(v) for v in cut.tolist()]
+        # tell every owner WHICH of its entries this rank needs (owner-local indices), learn what the others need from me
+        send_idx = [torch.empty(self.send_counts[q], dtype=torch.int64, device=ghosts.device) for q in range(world)]
+        ops, keep = [], []
+        for k in range(1, world):
+            dst, src = (rank + k) % world, (rank - k) % world
+            if self.recv_counts[dst] > 0:
+                need = (ghosts[self.ghost_off[dst]: self.ghost_off[dst + 1]] - int(self.bounds[dst])).contiguous()
+                keep.append(need)
+                ops.append(dist.P2POp(dist.isend, need, dst, group))
+            if self.send_counts[src] > 0:
+                ops.append(dist.P2POp(dist.irecv, send_idx[src], src, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        self.send_idx = torch.cat(send_idx) if world > 1 else send_idx[0]  # grouped by destination rank
+        self.send_off = np.concatenate([[0], np.cumsum(self.send_counts)]).astype(np.int64)
+        # colindex in local numbering
+        local = torch.where(remote, self.n_local + torch.searchsorted(ghosts, cols64), cols64 - self.c0)
+        self.cols_local = local.to(torch.int32).contiguous()
+        self.x_ext = torch.zeros(self.n_local + self.n_ghost, dtype=torch.float64, device=device)
+        self._x_other = None  # second buffer, allocated by iterate()
+        self.send_buf = torch.empty(int(self.send_off[-1]), dtype=torch.float64, device=device)
+        self.exchanged_bytes_per_step = 8 * int(self.send_off[-1])
+
+    def _hip_spmv(self, alpha, beta, x, y):
+        spmv_acc_amd.csr_spmv(alpha, beta, self.m_local, self.n_local + self.n_ghost, self.nnz_local, self.rowptr,
+                              self.cols_local, self.vals, x, y, strategy=self.strategy)
+
+    def set_x(self, x_local):
+        """This rank's slice of x (n_local values)."""
+        self.x_ext[: self.n_local].copy_(x_local[: self.n_local])
+
+    def exchange(self):
+        """Bring the ghost entries of x_ext up to date with the owners' current slices."""
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return
+        torch = self.torch
+        if self.send_buf.numel():
+            torch.index_select(self.x_ext[: self.n_local], 0, self.send_idx, out=self.send_buf)
+        ops = []
+        for k in range(1, self.world):
+            dst, src = (self.rank + k) % self.world, (self.rank - k) % self.world
+            if self.send_counts[dst] > 0:
+                ops.append(dist.P2POp(dist.isend, self.send_buf[int(self.send_off[dst]): int(self.send_off[dst + 1])], dst, self.group))
+            if self.recv_counts[src] > 0:
+                seg = self.x_ext[self.n_local + self.ghost_off[src]: self.n_local + self.ghost_off[src + 1]]
+                ops.append(dist.P2POp(dist.irecv, seg, src, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def iterate(self, alpha: float):
+        """x <- alpha * A * x in place across the ranks (power-iteration shape, beta = 0): the product is written straight
+        into the own-slice of a second x buffer, which then becomes the current one -- no copy between steps."""
+        if self._x_other is None:
+            self._x_other = self.torch.zeros_like(self.x_ext)
+        self.exchange()
+        if self.m_local > 0:
+            self.local_spmv(alpha, 0.0, self.x_ext, self._x_other[: self.n_local])
+        self.x_ext, self._x_other = self._x_other, self.x_ext
+        return self.x_ext[: self.n_local]
+
+    def step(self, alpha: float, beta: float, y_local):
+        """y_local = alpha * A_local * x + beta * y_local with x = the owners' current slices (set_x on every rank)."""
+        self.exchange()
+        if self.m_local > 0:
+            self.local_spmv(alpha, beta, self.x_ext, y_local)
+        return y_local

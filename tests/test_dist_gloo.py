@@ -100,3 +100,78 @@ def test_shard_helpers():
     rp, ci, v = local_csr_slice(rowptr, cols, vals, 100, 300)
     assert rp[0] == 0 and rp.size == 201 and ci.size == rp[-1] == rowptr[300] - rowptr[100]
     assert np.array_equal(ci, cols[rowptr[100]:rowptr[300]])
+
+
+def _ghost_worker(rank, world, port, kind, m, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib
+    from spmv_acc_amd.dist import GhostedRowShardedSpmv, local_csr_slice, shard_bounds
+
+    rowptr, cols, vals, x0 = _ghost_problem(kind, m)
+    bounds = shard_bounds(m, world, mode=1 if kind == "powerlaw" else 0, h_rowptr=rowptr)
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    rp, ci, v = (np.ascontiguousarray(a) for a in local_csr_slice(rowptr, cols, vals, r0, r1))
+    seen = {}
+
+    def local_spmv(alpha, beta, xt, yt):  # oracle stands in for the HIP kernel on CPU; cols are the engine's local numbering
+        seen["n"] = xt.numel()
+        oracle_lib.host_spmv_inplace(alpha, beta, rp, eng.cols_local.numpy(), v, xt.numpy(), yt.numpy())
+
+    eng = GhostedRowShardedSpmv(rank, world, bounds, torch.from_numpy(rp), torch.from_numpy(ci), torch.from_numpy(v),
+                                torch.device("cpu"), local_spmv=local_spmv)
+    x = torch.from_numpy(x0[r0:r1].copy())
+    y = torch.zeros(r1 - r0, dtype=torch.float64)
+    for _ in range(3):  # x_{k+1} = 0.5 * A x_k + 0.25 * x_k, every rank holding only its slice
+        eng.set_x(x)
+        y.copy_(x)
+        eng.step(0.5, 0.25, y)
+        x = y.clone()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x.numpy(), r0=r0, r1=r1, n_ghost=eng.n_ghost, n_ext=seen.get("n", 0),
+             bytes=eng.exchanged_bytes_per_step)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _ghost_problem(kind, m):
+    from spmv_acc_amd import synth
+
+    if kind == "banded":
+        offs = np.arange(-4, 4)
+        rows = np.arange(m)[:, None] + offs[None, :]
+        ok = (rows >= 0) & (rows < m)
+        rowptr = np.concatenate([[0], np.cumsum(ok.sum(1))]).astype(np.int32)
+        cols = rows[ok].astype(np.int32)
+        vals = (np.where(rows % 2 == 0, 1.0, -1.0) / (1.0 + np.abs(offs))[None, :])[ok]
+    else:
+        rowptr, cols, vals = synth.random_csr(m, m, 7, seed=321, kind=kind)
+    x0 = np.random.default_rng(8).standard_normal(m)
+    return rowptr, cols, vals, x0
+
+
+@pytest.mark.parametrize("kind,m,world", [("banded", 3001, 2), ("banded", 3001, 3), ("powerlaw", 2500, 2), ("uniform", 1999, 3),
+                                          ("empty_rows", 1500, 3)])
+def test_ghosted_exchange_iterates_like_the_unsharded_matrix(tmp_path, oracle, kind, m, world):
+    """Column-footprint exchange (GhostedRowShardedSpmv): three steps of x <- 0.5 A x + 0.25 x with x partitioned like the
+    rows, every rank receiving only the x entries its columns reference, equal bit for bit to the unsharded iteration.
+    Banded (BASELINE configs[4] family): a rank needs 4 + 3 entries from its neighbours, nothing from anyone else."""
+    mp.spawn(_ghost_worker, args=(world, _free_port(), kind, m, str(tmp_path)), nprocs=world, join=True)
+    rowptr, cols, vals, x = _ghost_problem(kind, m)
+    for _ in range(3):
+        x = oracle.host_spmv(0.5, 0.25, rowptr, cols, vals, x, x.copy())
+    got = np.empty(m)
+    total_bytes = 0
+    for r in range(world):
+        g = np.load(tmp_path / f"rank{r}.npz")
+        got[int(g["r0"]): int(g["r1"])] = g["x"]
+        assert int(g["n_ext"]) == int(g["r1"]) - int(g["r0"]) + int(g["n_ghost"])
+        total_bytes += int(g["bytes"])
+        if kind == "banded":
+            inner = 0 < r < world - 1
+            assert int(g["n_ghost"]) == (7 if inner else (3 if r == 0 else 4)), (r, int(g["n_ghost"]))
+    assert np.array_equal(got, x)
+    if kind == "banded":
+        assert total_bytes == 8 * 7 * (world - 1)
