@@ -248,7 +248,11 @@ def main():
                              always_collective=force_dist,
                              exchange="allgather" if args.exchange == "auto" else args.exchange)
         if args.exchange == "auto" and backend == "nccl":  # (gloo rehearsals: no point-to-point on GPU tensors)
-            out_extra["exchange_ms"] = {k: round(v, 4) for k, v in eng.tune_exchange().items()}
+            try:
+                out_extra["exchange_ms"] = {k: round(v, 4) for k, v in eng.tune_exchange().items()}
+            except Exception as ex:  # noqa: BLE001 -- a backend without grouped point-to-point: keep the collective
+                out_extra["exchange_tune_error"] = repr(ex)[:200]
+                eng.exchange = "allgather"
         out_extra["exchange"] = eng.exchange
         eng.set_y(y0)  # like the N = 1 leg, y is iterated in place (no per-step reset inside the timed region)
         for _ in range(max(args.warmup, 1)):
