@@ -839,3 +839,36 @@ def test_opt_in_validation_refuses_corrupt_matrices(torch_dev, oracle, hiplib):
                 spmv_acc_amd.release_plans(drp)
     finally:
         hiplib.spmv_acc_reset_tunables()
+
+
+def test_host_staging_then_spmv(torch_dev, oracle, hiplib):
+    """spmv_acc_stage_csr (north_star: 'host-side C++ stages CSR arrays with pinned hipMemcpyAsync'): host arrays -- writable
+    numpy memory that can be pinned in place, and a read-only buffer that cannot and takes the bounce-buffer route -- arrive
+    intact: an SpMV on the staged device pointers matches the oracle; NULL host pointers skip their array."""
+    import ctypes
+
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(20011, 9000, 9, seed=17, kind="powerlaw")
+    rng = np.random.default_rng(18)
+    x, y0 = rng.standard_normal(9000), rng.standard_normal(20011)
+    m, n, nnz = 20011, 9000, int(rowptr[-1])
+    ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+    ro_vals = np.frombuffer(vals.tobytes(), dtype=np.float64)  # read-only memory
+    assert not ro_vals.flags.writeable
+    for hv in (vals, ro_vals):
+        outs = [ctypes.c_void_p() for _ in range(5)]
+        rc = hiplib.spmv_acc_stage_csr(m, n, nnz, rowptr.ctypes.data, cols.ctypes.data, hv.ctypes.data, x.ctypes.data, None,
+                                       *[ctypes.byref(o) for o in outs])
+        assert rc == 0, spmv_acc_amd.load_library().spmv_acc_last_error_string()
+        d_rp, d_ci, d_v, d_x, d_y = (o.value for o in outs)
+        assert d_rp and d_ci and d_v and d_x and d_y is None  # h_y was NULL: no buffer made for it
+        dy = dev(torch, y0)
+        hiplib.spmv_acc_csr_spmv_strategy(spmv_acc_amd.strategy_id("adaptive"), 0, 1.0, 1.0, m, n, nnz, None, d_rp, d_ci, d_v, d_x,
+                                          dy.data_ptr())
+        torch.cuda.synchronize()
+        assert hiplib.spmv_acc_last_error() == 0
+        got = dy.cpu().numpy()
+        assert oracle.scaled_error(got, ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL
+        hiplib.spmv_acc_release_plans(d_rp)
+        for p in (d_rp, d_ci, d_v, d_x):
+            assert hiplib.spmv_acc_free_device(p) == 0
