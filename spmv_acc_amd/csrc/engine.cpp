@@ -623,7 +623,7 @@ struct TuneTimer {
     (void)hipEventRecord(e1, st);
     float ms = 0.f;
     if (!hip_ok(hipEventSynchronize(e1), "sync tune") || !hip_ok(hipEventElapsedTime(&ms, e0, e1), "elapsed tune")) return false;
-    *ms_per_launch = ms / timed;
+    *ms_per_launch = ms / static_cast<float>(timed);
     return true;
   }
 };
