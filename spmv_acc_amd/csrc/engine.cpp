@@ -877,7 +877,6 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
 
   const long long avg = static_cast<long long>(p->A.nnz) / m;
   switch (strategy) {
-  case kDefault:
   case kLight:
   case kVectorRow:
     launch_vector_row(st, p->A, m, classic_vec(avg), 1, alpha, beta, dx, dy);
@@ -886,6 +885,8 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   case kBlockRowOrdinary:
     launch_wave_row(st, p->A, alpha, beta, dx, dy);
     break;
+  case kDefault: // the reference's DEFAULT is its one-lane sequential correctness kernel (hip/spmv_hip_acc_imp.cpp:15-35) and
+                 // also what its build ships with (config.cmake:15): here the name gets the general-purpose kernel
   case kThreadRow:
   case kLineEnhance:
   case kLine:
