@@ -879,8 +879,12 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   switch (strategy) {
   case kLight:
   case kVectorRow:
-    launch_vector_row(st, p->A, m, classic_vec(avg), 1, alpha, beta, dx, dy);
+  {
+    const int w = classic_vec(avg);
+    if (get_tunable("rowblock_guard") && !probe_rowblock(*p, kThreads / w, st)) return;
+    launch_vector_row(st, p->A, m, w, 1, alpha, beta, dx, dy, p->rowblock_ok == 0);
     break;
+  }
   case kWfRow:
   case kBlockRowOrdinary:
     launch_wave_row(st, p->A, alpha, beta, dx, dy);

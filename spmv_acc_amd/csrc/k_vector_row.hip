@@ -19,7 +19,14 @@ namespace {
 using namespace dev;
 
 // w lanes per row, w wave-uniform per workgroup.  blocks [0, nb0) serve rows [0, row_split) with
-// width w0, the rest serve [row_split, m) with width w1.
+// width w0, the rest serve [row_split, m) with width w1.  A lane group owns kVecRows rows (kThreads / w apart, so that
+// neighbouring groups read neighbouring rowptr entries) and asks for the row extents of all of them, then for the first
+// two steps of all of them, before it consumes anything: 2 * kVecRows stream loads and as many gathers per lane in flight
+// instead of one (one row per group measured 2.8 TB/s on the boneS10-like matrix: a chain of three dependent latencies
+// with nothing beside it).
+// (kVecRows = 1 for matrices whose rows are longer than the two hoisted steps: their tails would otherwise run one row
+// after the other inside a group.)
+template <int kVecRows>
 __global__ __launch_bounds__(kThreads) void vector_row_kernel(int m, int row_split, int nb0, int w0, int w1,
                                                               double alpha, double beta,
                                                               const int *__restrict__ rp, const int *__restrict__ ci,
@@ -27,25 +34,75 @@ __global__ __launch_bounds__(kThreads) void vector_row_kernel(int m, int row_spl
                                                               const double *__restrict__ x, double *__restrict__ y) {
   const bool second = static_cast<int>(blockIdx.x) >= nb0;
   const int w = second ? w1 : w0;
-  const int rows_per_block = kThreads / w;
+  const int groups = kThreads / w;
   const int row_lo = second ? row_split : 0;
   const int row_hi = second ? m : row_split;
   const int b = second ? blockIdx.x - nb0 : blockIdx.x;
   const int lane = threadIdx.x & (w - 1);
-  const long long row_ll = static_cast<long long>(row_lo) + static_cast<long long>(b) * rows_per_block + threadIdx.x / w;
-  const bool live = row_ll < row_hi;
-  const int row = static_cast<int>(row_ll);
+  const long long first = static_cast<long long>(row_lo) + static_cast<long long>(b) * groups * kVecRows + threadIdx.x / w;
 
-  double s = 0.0;
-  if (live) {
-    const int j0 = rp[row];
-    const int j1 = rp[row + 1];
-    for (int j = j0 + lane; j < j1; j += w) {
-      s += load_stream(v + j) * x[load_stream(ci + j)];
+  int j0[kVecRows], j1[kVecRows];
+  bool live[kVecRows];
+#pragma unroll
+  for (int k = 0; k < kVecRows; ++k) {
+    const long long r = first + static_cast<long long>(k) * groups;
+    live[k] = r < row_hi;
+    j0[k] = j1[k] = 0;
+    if (live[k]) {
+      j0[k] = rp[r];
+      j1[k] = rp[r + 1];
     }
   }
-  s = group_sum_dyn(s, w); // every lane takes part (DPP needs a full exec mask)
-  if (live && lane == 0) store_y(y, row, alpha, beta, s);
+  // first two steps of every row: all loads, then all gathers
+  int c[kVecRows][2];
+  double a[kVecRows][2];
+#pragma unroll
+  for (int k = 0; k < kVecRows; ++k) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = j0[k] + lane + i * w;
+      c[k][i] = -1;
+      a[k][i] = 0.0;
+      if (j < j1[k]) {
+        c[k][i] = load_stream(ci + j);
+        a[k][i] = load_stream(v + j);
+      }
+    }
+  }
+  double s[kVecRows];
+#pragma unroll
+  for (int k = 0; k < kVecRows; ++k) {
+    s[k] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (c[k][i] >= 0) s[k] += a[k][i] * x[c[k][i]];
+  }
+  // rows longer than two steps: four steps at a time, loads before gathers
+#pragma unroll
+  for (int k = 0; k < kVecRows; ++k) {
+    for (int j = j0[k] + lane + 2 * w; j < j1[k]; j += 4 * w) {
+      int cc[4];
+      double aa[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int jj = j + u * w;
+        cc[u] = -1;
+        aa[u] = 0.0;
+        if (jj < j1[k]) {
+          cc[u] = load_stream(ci + jj);
+          aa[u] = load_stream(v + jj);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (cc[u] >= 0) s[k] += aa[u] * x[cc[u]];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kVecRows; ++k) {
+    const double sum = group_sum_dyn(s[k], w); // every lane takes part (DPP needs a full exec mask)
+    if (live[k] && lane == 0) store_y(y, static_cast<int>(first + static_cast<long long>(k) * groups), alpha, beta, sum);
+  }
 }
 
 // One 64-lane wavefront per row, for rows of hundreds of non-zeros (reference role: hip-wf-row/, KERNEL_STRATEGY
@@ -162,15 +219,24 @@ inline int ceil_div_ll(long long a, long long b) { return static_cast<int>((a + 
 } // namespace
 
 void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w0, int w1, double alpha, double beta,
-                       const double *x, double *y) {
+                       const double *x, double *y, bool single_row_groups) {
   if (A.m <= 0) return;
   if (row_split < 0) row_split = 0;
   if (row_split > A.m) row_split = A.m;
-  const int nb0 = ceil_div_ll(row_split, kThreads / w0);
-  const int nb1 = ceil_div_ll(A.m - row_split, kThreads / w1);
+  const long long avg = static_cast<long long>(A.nnz) / A.m;
+  const int wide = w0 > w1 ? w0 : w1;
+  // rows per lane group: 1 when rows outgrow the hoisted steps, or when the caller knows the row lengths are very uneven
+  // (four hub rows of a power-law matrix in one group would run one after the other)
+  const int rows = (single_row_groups || avg > 2LL * wide) ? 1 : 4;
+  const int nb0 = ceil_div_ll(row_split, rows * (kThreads / w0));
+  const int nb1 = ceil_div_ll(A.m - row_split, rows * (kThreads / w1));
   if (nb0 + nb1 == 0) return;
-  hipLaunchKernelGGL(vector_row_kernel, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1,
-                     alpha, beta, A.rp, A.ci, A.v, x, y);
+  if (rows == 1)
+    hipLaunchKernelGGL(vector_row_kernel<1>, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1, alpha, beta,
+                       A.rp, A.ci, A.v, x, y);
+  else
+    hipLaunchKernelGGL(vector_row_kernel<4>, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1, alpha, beta,
+                       A.rp, A.ci, A.v, x, y);
 }
 
 void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y) {

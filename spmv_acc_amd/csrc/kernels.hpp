@@ -39,7 +39,7 @@ constexpr int kPlusLongChunk = 2 * kPlusMinNnz;        // NN_EI * MIN_NNZ_PER_BL
 // default / vector-row family: `w` lanes per row straight from global memory.
 // Rows [0, row_split) use width w0, rows [row_split, m) use width w1 (row_split = m: one width).
 void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w0, int w1, double alpha, double beta,
-                       const double *x, double *y);
+                       const double *x, double *y, bool single_row_groups = false);
 
 // wavefront-per-row for long rows: 4 consecutive non-zeros per lane per step (16-B loads), two steps in flight.
 void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y);
