@@ -139,7 +139,9 @@ int spmv_acc_cached_plans(void);
  * plan yet; returns 1 if a plan exists */
 int spmv_acc_query_plan(const int *d_rowptr, int m, int *out);
 
-void spmv_acc_set_stream(void *hip_stream); /* hipStream_t; NULL = the NULL stream (reference behaviour) */
+void spmv_acc_set_stream(void *hip_stream); /* hipStream_t; NULL = the NULL stream (reference behaviour).  Steady-state calls are
+                                             * launches only and may be captured into a hipGraph; the first call on a matrix
+                                             * (plan: allocations, synchronisation, timings) must run outside a capture. */
 void *spmv_acc_get_stream(void);
 
 int spmv_acc_last_error(void); /* 0 = ok; see enum below */
