@@ -126,6 +126,18 @@ int spmv_acc_stage_csr(int m, int n, int nnz, const int *h_rowptr, const int *h_
                        double **d_x, double **d_y);
 int spmv_acc_free_device(void *p);
 
+/* ---- explicit preprocessing (new) ---------------------------------------------------------------------------------------
+ * Builds everything the FIRST call on a matrix would build for `strategy` -- the structural passes (break points, row-block
+ * analysis, balance probe) and the per-matrix timings (cache policy, flat's cut-row form, adaptive-plus block size) -- by
+ * running that first call into a scratch y (beta = 0), then synchronises.  The caller's y is not touched; x is read.
+ * After it every spmv call on the matrix is kernel launches only (capturable into a hipGraph).  ms_out (may be NULL):
+ * device time of the preparation, the figure the reference's benchmark reports as `pre` (benchmark_time.cpp:23-43;
+ * there it is the per-call break-point / analysis cost, here it is paid once).
+ * replaces: nothing callable in the reference (its preprocessing is re-done inside every SpMV call, flat.cpp:35-45,
+ * csr_adaptive_plus_spmv.cpp:104-125). */
+int spmv_acc_prepare(int strategy, int m, int n, int nnz, const int *h_rowptr, const int *d_rowptr, const int *d_colindex,
+                     const double *d_value, const double *dx, float *ms_out);
+
 /* ---- plan cache, stream, errors ------------------------------------------------------------------------------------------
  * Preprocessing results (break points, row blocks, carries) are cached per matrix, keyed by
  * (device, rowptr, colindex, value, m, n).  Release when a matrix' structure changes in place or its

@@ -35,7 +35,7 @@ C_ABI_SYMBOLS = (
     "spmv_acc_free_device", "spmv_acc_release_plans", "spmv_acc_cached_plans", "spmv_acc_query_plan",
     "spmv_acc_set_stream", "spmv_acc_get_stream", "spmv_acc_last_error", "spmv_acc_last_error_string",
     "spmv_acc_clear_error", "spmv_acc_time_spmv", "spmv_acc_version", "spmv_acc_set_tunable",
-    "spmv_acc_get_tunable", "spmv_acc_reset_tunables", "spmv_acc_time_spmv_total", "spmv_acc_copy_ceiling_gbs", "spmv_acc_adaptive_plus_analyze_device",
+    "spmv_acc_get_tunable", "spmv_acc_reset_tunables", "spmv_acc_time_spmv_total", "spmv_acc_copy_ceiling_gbs", "spmv_acc_adaptive_plus_analyze_device", "spmv_acc_prepare",
 )
 
 _lib = None
@@ -86,6 +86,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_partition_rows.argtypes = [ci, ci, ci, vp, vp]
     lib.spmv_acc_stage_csr.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp] + [ctypes.POINTER(vp)] * 5
     lib.spmv_acc_free_device.argtypes = [vp]
+    lib.spmv_acc_prepare.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     lib.spmv_acc_release_plans.argtypes = [vp]
     lib.spmv_acc_release_plans.restype = None
     lib.spmv_acc_query_plan.argtypes = [vp, ci, vp]
@@ -160,6 +161,19 @@ def csr_spmv(alpha: float, beta: float, m: int, n: int, nnz: int, rowptr, colind
     else:
         lib.spmv_acc_csr_spmv_strategy(strategy_id(strategy), *args)
     _check(lib)
+
+
+def prepare(m: int, n: int, nnz: int, rowptr, colindex, value, x, strategy=None, h_rowptr=None) -> float:
+    """Build the plan of ``strategy`` for this matrix (structural passes + per-matrix timings) without touching any y.
+    Returns the device milliseconds it took."""
+    lib = load_library()
+    _require_cuda(rowptr, colindex, value, x)
+    ms = ctypes.c_float(0.0)
+    sid = lib.spmv_acc_get_strategy() if strategy is None else strategy_id(strategy)
+    rc = lib.spmv_acc_prepare(sid, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr), _ptr(colindex), _ptr(value), _ptr(x), ctypes.byref(ms))
+    if rc != 0:
+        _check(lib)
+    return float(ms.value)
 
 
 def break_points(rowptr, m: int, nnz: int, stride: int, out) -> None:

@@ -247,6 +247,32 @@ int spmv_acc_last_error(void) { return last_error(); }
 const char *spmv_acc_last_error_string(void) { return last_error_string(); }
 void spmv_acc_clear_error(void) { clear_error(); }
 
+int spmv_acc_prepare(int strategy, int m, int n, int nnz, const int *h_rowptr, const int *d_rowptr, const int *d_colindex,
+                     const double *d_value, const double *dx, float *ms_out) {
+  if (m <= 0) return kOk;
+  hipStream_t st = get_stream();
+  double *scratch = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(m)) != hipSuccess) {
+    set_error(kErrHip, "spmv_acc_prepare: hipMalloc failed");
+    return kErrHip;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool timed = ms_out && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+  clear_error();
+  if (timed) (void)hipEventRecord(e0, st);
+  // beta = 0: y is written, never read -- the scratch needs no initial value and the caller's y is not involved
+  run_spmv(strategy, 0, 1.0, 0.0, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, scratch);
+  if (timed) (void)hipEventRecord(e1, st);
+  int rc = hipStreamSynchronize(st) == hipSuccess ? kOk : kErrHip;
+  if (timed && rc == kOk && hipEventElapsedTime(ms_out, e0, e1) != hipSuccess) rc = kErrHip;
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(scratch);
+  if (rc != kOk) set_error(kErrHip, "spmv_acc_prepare: HIP failure");
+  if (rc == kOk && last_error() != kOk) rc = last_error();
+  return rc;
+}
+
 int spmv_acc_time_spmv(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
                        const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
                        const double *dx, double *dy, const double *d_y0, float *ms_out) {

@@ -872,3 +872,34 @@ def test_host_staging_then_spmv(torch_dev, oracle, hiplib):
         hiplib.spmv_acc_release_plans(d_rp)
         for p in (d_rp, d_ci, d_v, d_x):
             assert hiplib.spmv_acc_free_device(p) == 0
+
+
+def test_prepare_then_first_call_is_capturable(torch_dev, oracle, hiplib):
+    """spmv_acc_prepare builds the plan (structural passes + per-matrix timings) without any y; the very first SpMV call
+    afterwards is launches only: it is captured into a hipGraph here, and the replay matches the oracle."""
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(30000, 30000, 13, seed=41, kind="powerlaw")
+    m = n = 30000
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(42)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+    side = torch.cuda.Stream()
+    try:
+        hiplib.spmv_acc_set_stream(side.cuda_stream)
+        for strat in ("adaptive", "flat", "line_enhance", "adaptive_plus", "default", "vector_row"):
+            drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))  # fresh buffers: no plan yet
+            assert spmv_acc_amd.query_plan(drp, m) is None
+            ms = spmv_acc_amd.prepare(m, n, nnz, drp, dci, dv, dx, strategy=strat)
+            assert ms > 0.0 and spmv_acc_amd.query_plan(drp, m) is not None
+            static_y = dev(torch, y0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):  # the FIRST spmv call on this matrix, under capture
+                spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, static_y, strategy=strat)
+            g.replay()
+            torch.cuda.synchronize()
+            err = oracle.scaled_error(static_y.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, vals, x, y0)
+            assert err <= SCALED_TOL, (strat, err)
+            spmv_acc_amd.release_plans(drp)
+    finally:
+        hiplib.spmv_acc_set_stream(None)
