@@ -70,6 +70,7 @@ Tunable g_tunables[] = {
     {"stage_fast", 1, 1},      // tile staging: wave-skip + branch-free form (0: per-lane predicated loads)
     {"early_y", 1, 1},         // row-block kernel: load the old y before the tile instead of after it
     {"rowblock_guard", 1, 1},  // imbalance probe + rescue for the row-block family
+    {"adaptive_split", 0, 0},  // adaptive, halves differing >= 4x: 1 = the reference's two-width vector-row split
     {"rescue_flat", 0, 0},     // 1: the rescue is flat (nnz-cut tiles) instead of the row-block-plus kernel
     {"plus_ref_vec", 0, 0},
     {"plus_min_nnz", 0, 0},    // adaptive-plus analysis: MIN_NNZ_PER_BLOCK; 0 = time 1024 (the reference's instance) / 1536 /
@@ -902,17 +903,24 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   case kAdaptive: {
     if (!fetch_samples(*p, h_rowptr)) return;
     switch (adaptive_branch(m, p->samples)) {
-    case 1: {
-      const int half_rows = m / 2;
-      const long long a0 = half_rows > 0 ? p->samples.half / half_rows : 0;
-      const long long a1 = (static_cast<long long>(p->samples.last) - p->samples.half) / (m - half_rows);
-      launch_vector_row(st, p->A, half_rows, classic_vec(a0), classic_vec(a1), alpha, beta, dx, dy);
+    case 1:
+      // The two row halves differ >= 4x in non-zeros.  The reference answers with two lane widths, one per half
+      // (vector_row.cpp:30-38; still available as adaptive_vec_row_sparse_spmv / tunable adaptive_split).  Blocks cut by
+      // non-zero count with lanes per row chosen per block fit such a matrix better: on a 2 M-row matrix with halves of 40
+      // and 5 nnz/row the split took 185 us, row-block-plus 110 us, flat 110 us, fixed row blocks 120 us.
+      if (get_tunable("adaptive_split")) {
+        const int half_rows = m / 2;
+        const long long a0 = half_rows > 0 ? p->samples.half / half_rows : 0;
+        const long long a1 = (static_cast<long long>(p->samples.last) - p->samples.half) / (m - half_rows);
+        launch_vector_row(st, p->A, half_rows, classic_vec(a0), classic_vec(a1), alpha, beta, dx, dy);
+      } else {
+        run_plus(st, *p, h_rowptr, alpha, beta, dx, dy);
+      }
       break;
-    }
     default:
       // 2 (adaptive line), 3 (adaptive line-enhance), 4 (adaptive flat), 5 (line-enhance).  The reference sends
       // branch 4 (nnz > 2^23) to flat because its row-block kernels lose balance on large irregular matrices; here
-      // the row-block kernel carries a plan-time balance probe and falls back to the nnz-cut tiles (flat) exactly
+      // the row-block kernel carries a plan-time balance probe and falls back to the row-block-plus kernel exactly
       // then, and measures 1-5 % faster than flat on the balanced large-set stand-ins (one kernel, no carry
       // fix-up), so every non-split branch goes through it.
       run_rowblock(st, *p, h_rowptr, alpha, beta, dx, dy);

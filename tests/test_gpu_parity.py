@@ -242,6 +242,16 @@ def test_adaptive_branches_reached(torch_dev, oracle):
         check(oracle, got, 1.0, 1.0, rowptr, cols, vals, x, y0, ("adaptive", want))
         got = run(torch, "adaptive", 1.0, 1.0, rowptr, cols, vals, x, y0, pass_host_rowptr=False)
         check(oracle, got, 1.0, 1.0, rowptr, cols, vals, x, y0, ("adaptive-device-samples", want))
+    # branch 1 in the reference's own form (two lane widths, one per half) stays available behind a tunable
+    lib = spmv_acc_amd.load_library()
+    rowptr, cols, vals = synth.csr_from_row_lengths(specs[1], 6000, rng)
+    x, y0 = rng.standard_normal(6000), rng.standard_normal(6000)
+    assert lib.spmv_acc_set_tunable(b"adaptive_split", 1) == 0
+    try:
+        got = run(torch, "adaptive", 1.0, 1.0, rowptr, cols, vals, x, y0)
+    finally:
+        lib.spmv_acc_reset_tunables()
+    check(oracle, got, 1.0, 1.0, rowptr, cols, vals, x, y0, ("adaptive-split", 1))
 
 
 # ---- full-size checks (BASELINE.json configs[1]: Hardesty3-like, 8.2M rows / 40.5M nnz) --------------------------
