@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A matrix whose two row halves differ 8x in density (adaptive.cpp:34-35 sends it to the two-width vector-row split): which kernel
+"""A matrix whose two row halves differ in density (default 40 vs 5 nnz per row; argv: d0 d1) (adaptive.cpp:34-35 sends it to the two-width vector-row split): which kernel
 family serves it best?  Per-launch hipEvent medians."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,8 +8,10 @@ import spmv_acc_amd
 from spmv_acc_amd import synth
 
 m = n = 2_000_000
+d0, d1 = (int(a) for a in (sys.argv[1:3] if len(sys.argv) >= 3 else (40, 5)))  # mean nnz per row of the two halves
 g = torch.Generator(device="cuda"); g.manual_seed(5)
-lens = torch.cat([torch.randint(30, 51, (m // 2,), generator=g, device="cuda"), torch.randint(3, 8, (m - m // 2,), generator=g, device="cuda")])
+lens = torch.cat([torch.randint(d0 - d0 // 4, d0 + d0 // 4 + 1, (m // 2,), generator=g, device="cuda"),
+                  torch.randint(d1 - d1 // 4, d1 + d1 // 4 + 1, (m - m // 2,), generator=g, device="cuda")])
 rp = torch.zeros(m + 1, dtype=torch.int64, device="cuda"); torch.cumsum(lens, 0, out=rp[1:])
 nnz = int(rp[-1].item())
 rows = torch.repeat_interleave(torch.arange(m, device="cuda"), lens, output_size=nnz)
