@@ -320,6 +320,7 @@ struct Plan {
   int rowblock_ok = -1;
   int rowblock_rpb = 0;
   int max_block_nnz = 0;
+  bool rowblock_uneven = false; // many row blocks far from the average block (balance probe)
   // flat
   int flat_tiles = -1;
   FlatPlan flat;
@@ -753,22 +754,26 @@ bool probe_rowblock(Plan &p, int rpb, hipStream_t st) {
   if (p.rowblock_ok >= 0 && p.rowblock_rpb == rpb) return true;
   p.rowblock_rpb = rpb;
   int *d_max = nullptr;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d_max), sizeof(int)), "hipMalloc probe")) return false;
-  bool ok = hip_ok(hipMemsetAsync(d_max, 0, sizeof(int), st), "memset probe");
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d_max), 2 * sizeof(int)), "hipMalloc probe")) return false;
+  bool ok = hip_ok(hipMemsetAsync(d_max, 0, 2 * sizeof(int), st), "memset probe");
   if (ok) {
-    launch_max_block_nnz(st, p.A.rp, p.A.m, rpb, d_max);
-    int h = 0;
-    ok = hip_ok(hipMemcpyAsync(&h, d_max, sizeof(int), hipMemcpyDeviceToHost, st), "read probe") &&
+    const long long nblocks = (static_cast<long long>(p.A.m) + rpb - 1) / rpb;
+    const long long avg_block = nblocks > 0 ? p.A.nnz / nblocks : 0;
+    launch_max_block_nnz(st, p.A.rp, p.A.m, rpb, static_cast<int>(avg_block), d_max);
+    int h[2] = {0, 0};
+    ok = hip_ok(hipMemcpyAsync(h, d_max, 2 * sizeof(int), hipMemcpyDeviceToHost, st), "read probe") &&
          hip_ok(hipStreamSynchronize(st), "sync probe");
     if (ok) {
-      p.max_block_nnz = h;
+      p.max_block_nnz = h[0];
       // balanced enough = the heaviest block needs few LDS rounds AND is not far above the average block
       // (a block that fits one tile is always fine)
-      const long long nblocks = (static_cast<long long>(p.A.m) + rpb - 1) / rpb;
-      const long long avg_block = nblocks > 0 ? p.A.nnz / nblocks : 0;
-      const bool few_rounds = h <= kRowblockMaxRounds * kTile;
-      const bool near_avg = h <= kTile || h <= 4 * avg_block;
+      const bool few_rounds = h[0] <= kRowblockMaxRounds * kTile;
+      const bool near_avg = h[0] <= kTile || h[0] <= 4 * avg_block;
       p.rowblock_ok = (few_rounds && near_avg) ? 1 : 0;
+      // uneven = a fifth or more of the blocks are > 35 % away from the average block or spill into a second LDS round: fixed
+      // row blocks then alternate between half-empty tiles and second rounds (striped densities), and blocks cut by
+      // non-zero count do better
+      p.rowblock_uneven = nblocks >= 16 && 5LL * h[1] >= nblocks;
     }
   }
   (void)hipFree(d_max);
@@ -780,7 +785,8 @@ bool probe_rowblock(Plan &p, int rpb, hipStream_t st) {
 // by many workgroups instead of serialising one.
 bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y);
 
-bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y) {
+bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y,
+                  bool allow_uneven_switch = false) {
   int vec = 1, rpb = kThreads;
   pick_rowblock_shape(p.A.m, p.A.nnz, get_tunable("rowblock_target"), &vec, &rpb);
   const int forced = get_tunable("rowblock_vec");
@@ -796,6 +802,10 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
     // 5 % (scale 22) and 17 % (scale 20) faster than the nnz-cut tiles of flat; `rescue_flat` keeps the older choice.
     if (p.rowblock_ok == 0)
       return get_tunable("rescue_flat") ? run_flat(st, p, alpha, beta, x, y) : run_plus(st, p, h_rowptr, alpha, beta, x, y);
+    // Uneven but not pathological (striped densities: 60 / 20 nnz per row alternating every 300 or 5000 rows ran 196 us here and
+    // 177 us in row-block-plus; 30 / 10 every 64 rows 108 vs 97 us): same answer, for the strategies that leave the choice to
+    // the engine.  line / line-enhance / thread_row keep their fixed row blocks.
+    if (p.rowblock_uneven && allow_uneven_switch && !get_tunable("rescue_flat")) return run_plus(st, p, h_rowptr, alpha, beta, x, y);
   }
   const int chunk = get_tunable("xcd_chunk");
   const int base_flags = (get_tunable("xcd_remap") ? 1 : 0) | (get_tunable("early_y") ? 2 : 0) |
@@ -903,6 +913,8 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     break;
   case kDefault: // the reference's DEFAULT is its one-lane sequential correctness kernel (hip/spmv_hip_acc_imp.cpp:15-35) and
                  // also what its build ships with (config.cmake:15): here the name gets the general-purpose kernel
+    run_rowblock(st, *p, h_rowptr, alpha, beta, dx, dy, true); // engine's choice, like adaptive's even-matrix branch
+    break;
   case kThreadRow:
   case kLineEnhance:
   case kLine:
@@ -938,7 +950,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
       // decision already holds) differ 1.75x or more in non-zeros, blocks cut by non-zero count fit better: row-block-plus
       // measures 3-7 % faster at 2x-3x (tools/halves_bench.py), the same within 1 % at 1.5x.
       if (quarters_uneven(p->samples) && !get_tunable("adaptive_split")) run_plus(st, *p, h_rowptr, alpha, beta, dx, dy);
-      else run_rowblock(st, *p, h_rowptr, alpha, beta, dx, dy);
+      else run_rowblock(st, *p, h_rowptr, alpha, beta, dx, dy, true);
       break;
     }
     break;

@@ -79,23 +79,34 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   }
 }
 
-// Largest number of non-zeros any workgroup of `rpb` consecutive rows would own (plan-time imbalance probe).
+// Plan-time balance probe over the workgroups of `rpb` consecutive rows the row-block kernel would use:
+//   out[0] = largest number of non-zeros any of them would own,
+//   out[1] = how many of them are more than 35 % away from the average block (`avg_block` non-zeros) in either direction, or
+//            spill over one 2048-product tile.
 __global__ __launch_bounds__(256) void max_block_nnz_kernel(const int *__restrict__ rp, int m, int rpb, int nblocks,
-                                                            int *__restrict__ out) {
+                                                            int avg_block, int *__restrict__ out) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   int v = 0;
+  bool off = false;
   if (b < nblocks) {
     const long long lo = static_cast<long long>(b) * rpb;
     const long long hi = lo + rpb < m ? lo + rpb : m;
     v = rp[hi] - rp[lo];
+    const long long d = static_cast<long long>(v) - avg_block;
+    // the ragged last block does not count; a block that needs a second (mostly empty) LDS round counts whatever its distance
+    off = hi - lo == rpb && (20 * (d < 0 ? -d : d) > 7LL * avg_block || v > kTile);
   }
+  const unsigned long long votes = __ballot(off);
   // wave max, then one atomic per wave
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const int other = __shfl_xor(v, o, 64);
     v = other > v ? other : v;
   }
-  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(out, v);
+  if ((threadIdx.x & 63) == 0) {
+    if (v > 0) atomicMax(out, v);
+    if (votes) atomicAdd(out + 1, __popcll(votes));
+  }
 }
 
 template <int VEC>
@@ -125,11 +136,11 @@ void launch_vec(hipStream_t stream, const CsrDev &A, int rpb, int xcd, double al
 
 } // namespace
 
-void launch_max_block_nnz(hipStream_t stream, const int *rp, int m, int rows_per_block, int *d_out) {
+void launch_max_block_nnz(hipStream_t stream, const int *rp, int m, int rows_per_block, int avg_block, int *d_out) {
   const int nblocks = static_cast<int>((static_cast<long long>(m) + rows_per_block - 1) / rows_per_block);
   if (nblocks <= 0) return;
   hipLaunchKernelGGL(max_block_nnz_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, rp, m, rows_per_block,
-                     nblocks, d_out);
+                     nblocks, avg_block, d_out);
 }
 
 void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, int rows_per_block, int xcd_remap,

@@ -56,7 +56,7 @@ void pick_rowblock_shape(int m, int nnz, int target_products, int *vec, int *row
 
 // plan-time imbalance probe for the row-block family: *d_out (pre-zeroed) = max non-zeros owned by any
 // workgroup of rows_per_block consecutive rows.
-void launch_max_block_nnz(hipStream_t stream, const int *rp, int m, int rows_per_block, int *d_out);
+void launch_max_block_nnz(hipStream_t stream, const int *rp, int m, int rows_per_block, int avg_block, int *d_out); // d_out[2], pre-zeroed
 // a row block is "balanced enough" while it needs at most this many LDS rounds
 constexpr int kRowblockMaxRounds = 8;
 

@@ -10,8 +10,13 @@ from spmv_acc_amd import synth
 m = n = 2_000_000
 d0, d1 = (int(a) for a in (sys.argv[1:3] if len(sys.argv) >= 3 else (40, 5)))  # mean nnz per row of the two halves
 g = torch.Generator(device="cuda"); g.manual_seed(5)
+stripe = int(sys.argv[3]) if len(sys.argv) >= 4 else 0  # 0: two halves; else alternate densities every `stripe` rows
 lens = torch.cat([torch.randint(d0 - d0 // 4, d0 + d0 // 4 + 1, (m // 2,), generator=g, device="cuda"),
                   torch.randint(d1 - d1 // 4, d1 + d1 // 4 + 1, (m - m // 2,), generator=g, device="cuda")])
+if stripe > 0:
+    dense = ((torch.arange(m, device="cuda") // stripe) % 2) == 0
+    perm = torch.cat([torch.nonzero(dense).flatten(), torch.nonzero(~dense).flatten()])  # first half of lens is the dense law
+    lens = torch.empty_like(lens).scatter_(0, perm, lens)
 rp = torch.zeros(m + 1, dtype=torch.int64, device="cuda"); torch.cumsum(lens, 0, out=rp[1:])
 nnz = int(rp[-1].item())
 rows = torch.repeat_interleave(torch.arange(m, device="cuda"), lens, output_size=nnz)
