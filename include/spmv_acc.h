@@ -144,11 +144,12 @@ int spmv_acc_prepare(int strategy, int m, int n, int nnz, const int *h_rowptr, c
  * buffers are freed; NULL releases everything. */
 void spmv_acc_release_plans(const int *d_rowptr);
 int spmv_acc_cached_plans(void);
-/* plan introspection: fills out[8] = {nnz, adaptive_branch, vec, flat_tiles, plus_blocks, aligned16, stream_policy,
- * flat_fixup};
+/* plan introspection: fills out[9] = {nnz, adaptive_branch, vec, flat_tiles, plus_blocks, aligned16, stream_policy,
+ * flat_fixup, adaptive_family};
  * stream_policy: cache policy of the stream loads chosen by timing at plan time (0 nt, 1 default, 3 values default,
  * -1 not tuned yet); flat_fixup: 1 the flat plan folds cut rows with its fix-up kernel, 0 tiles finish them, -1 no flat
- * plan yet; returns 1 if a plan exists */
+ * plan yet; adaptive_family: the kernel family adaptive settled on by timing (0 fixed row blocks, 1 row-block-plus, 2 flat,
+ * -1 not timed); returns 1 if a plan exists */
 int spmv_acc_query_plan(const int *d_rowptr, int m, int *out);
 
 void spmv_acc_set_stream(void *hip_stream); /* hipStream_t; NULL = the NULL stream (reference behaviour).  Steady-state calls are

@@ -286,11 +286,11 @@ def release_plans(rowptr=None) -> None:
 def query_plan(rowptr, m: int):
     import numpy as np
 
-    out = np.zeros(8, dtype=np.int32)
+    out = np.zeros(9, dtype=np.int32)
     found = load_library().spmv_acc_query_plan(_ptr(rowptr), m, _ptr(out))
     if not found:
         return None
-    keys = ("nnz", "adaptive_branch", "vec", "flat_tiles", "plus_blocks", "aligned16", "stream_policy", "flat_fixup")
+    keys = ("nnz", "adaptive_branch", "vec", "flat_tiles", "plus_blocks", "aligned16", "stream_policy", "flat_fixup", "adaptive_family")
     return dict(zip(keys, (int(v) for v in out)))
 
 

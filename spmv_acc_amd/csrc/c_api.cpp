@@ -233,6 +233,7 @@ int spmv_acc_query_plan(const int *d_rowptr, int m, int *out) {
   out[5] = info.aligned16;
   out[6] = info.stream_policy;
   out[7] = info.flat_fixup;
+  out[8] = info.adaptive_family;
   return 1;
 }
 

@@ -70,6 +70,8 @@ Tunable g_tunables[] = {
     {"stage_fast", 1, 1},      // tile staging: wave-skip + branch-free form (0: per-lane predicated loads)
     {"early_y", 1, 1},         // row-block kernel: load the old y before the tile instead of after it
     {"rowblock_guard", 1, 1},  // imbalance probe + rescue for the row-block family
+    {"adaptive_timed", 1, 1},  // adaptive: 1 = time row blocks / row-block-plus / flat on the matrix and keep the fastest;
+                               // 0 = decide from the four rowptr samples and the balance probe only
     {"adaptive_split", 0, 0},  // adaptive, halves differing >= 4x: 1 = the reference's two-width vector-row split
     {"rescue_flat", 0, 0},     // 1: the rescue is flat (nnz-cut tiles) instead of the row-block-plus kernel
     {"plus_ref_vec", 0, 0},
@@ -321,6 +323,7 @@ struct Plan {
   int rowblock_rpb = 0;
   int max_block_nnz = 0;
   bool rowblock_uneven = false; // many row blocks far from the average block (balance probe)
+  int adaptive_family = -1;     // adaptive's timed choice: 0 fixed row blocks, 1 row-block-plus, 2 flat; -1 not timed yet
   // flat
   int flat_tiles = -1;
   FlatPlan flat;
@@ -610,6 +613,10 @@ int policy_for(const Plan &p) {
   return p.stream_policy >= 0 ? p.stream_policy : kStreamPolicyNt;
 }
 
+// While adaptive compares the families it runs each with its default sub-choices (flat: carries + fix-up unless pinned;
+// row-block-plus: MIN_NNZ 1536); the family that wins refines its own sub-choice on its next call.
+thread_local bool t_coarse_tuning = false;
+
 // Shared by the per-matrix timings below: average milliseconds of fn() in the cache state fn itself leaves behind.  The
 // first launch is timed alone and sizes the rest, so tuning a matrix whose SpMV takes milliseconds costs 2 launches per
 // candidate, not 8: under 0.5 ms per launch 2 more warm-ups + 5 timed, under 2 ms 2 + 2, else the one warm-up + 1 timed.
@@ -694,6 +701,10 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
   }
   if (F.mode_tuned) {
     F.needs_fixup = F.tuned_fixup;
+    return true;
+  }
+  if (t_coarse_tuning) {
+    F.needs_fixup = true;
     return true;
   }
   double *scratch = nullptr;
@@ -832,6 +843,9 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
     return ensure_plus(p, h_rowptr, st, forced > 0 ? forced : kPlusMinNnz) && autotune_policy(p, st, launch);
   }
   if (p.plus_tuned_min > 0) return ensure_plus(p, h_rowptr, st, p.plus_tuned_min) && autotune_policy(p, st, launch);
+  // (coarse: 1024 where the balance probe found hub rows -- the block size that wins on power-law matrices -- else 1536)
+  if (t_coarse_tuning)
+    return ensure_plus(p, h_rowptr, st, p.rowblock_ok == 0 ? kPlusMinNnz : 1536) && autotune_policy(p, st, launch);
   // first call on this matrix: cache policy on the middle candidate, then the three block sizes under that policy
   if (!ensure_plus(p, h_rowptr, st, 1536) || !autotune_policy(p, st, launch)) return false;
   double *scratch = nullptr;
@@ -863,6 +877,46 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
   launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, get_tunable("xcd_chunk_tiles"),
               policy_for(p), p.d_ppartial, alpha, beta, x, y);
   return true;
+}
+
+// adaptive, measured: the reference decides from four rowptr samples which kernel family a matrix gets (adaptive.cpp:16-67).
+// Which family wins depends on more than those samples say -- fixed row blocks on evenly filled matrices, blocks cut by
+// non-zero count where the density varies (quarters, stripes), non-zero-cut tiles where many rows are hundreds to thousands
+// long (lognormal row lengths with sigma >= 1: flat 116 us, row blocks 127-130 us; 2000 rows of 3000 nnz in an FEM-like matrix:
+// 125 vs 149 us, tools/rowlaw_bench.py) -- so the three are timed once per matrix, each after its own first call has built
+// and tuned its plan, and the fastest is kept.  The sample-based rules remain as the untimed form (tunable adaptive_timed 0).
+bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y) {
+  auto run_family = [&](int f, double a, double b, double *yy) {
+    switch (f) {
+    case 0: return run_rowblock(st, p, h_rowptr, a, b, x, yy);
+    case 1: return run_plus(st, p, h_rowptr, a, b, x, yy);
+    default: return run_flat(st, p, a, b, x, yy);
+    }
+  };
+  if (p.adaptive_family < 0) {
+    double *scratch = nullptr;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
+      return false;
+    TuneTimer timer;
+    bool ok = timer.ok;
+    float ms[3] = {1e30f, 1e30f, 1e30f};
+    t_coarse_tuning = true;
+    for (int f = 0; ok && f < 3; ++f) {
+      ok = run_family(f, 1.0, 0.0, scratch); // builds this family's plan (sub-choices at their defaults)
+      if (!ok) break;
+      if (f == 0 && p.rowblock_ok == 0) continue; // fixed row blocks were rescued: that run WAS family 1
+      ok = timer.time(st, [&] { (void)run_family(f, 1.0, 0.0, scratch); }, &ms[f]);
+    }
+    t_coarse_tuning = false;
+    // fixed row blocks unless another family is at least 3 % faster (short kernels time within ~2 %)
+    int best_family = ms[0] < 1e29f ? 0 : 1;
+    for (int f = 1; f < 3; ++f)
+      if (ms[f] < (best_family == 0 ? 0.97f * ms[0] : ms[best_family])) best_family = f;
+    (void)hipFree(scratch);
+    if (!ok) return false;
+    p.adaptive_family = best_family;
+  }
+  return run_family(p.adaptive_family, alpha, beta, y);
 }
 
 } // namespace
@@ -925,6 +979,11 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     break;
   case kAdaptive: {
     if (!fetch_samples(*p, h_rowptr)) return;
+    if (get_tunable("adaptive_timed") && !get_tunable("adaptive_split")) {
+      run_adaptive_timed(st, *p, h_rowptr, alpha, beta, dx, dy);
+      break;
+    }
+    // untimed form: the reference's decision tree on four rowptr samples, re-targeted at this library's kernels
     switch (adaptive_branch(m, p->samples)) {
     case 1:
       // The two row halves differ >= 4x in non-zeros.  The reference answers with two lane widths, one per half
@@ -990,6 +1049,7 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->aligned16 = p.A.aligned16 ? 1 : 0;
       out->stream_policy = p.stream_policy;
       out->flat_fixup = p.flat_tiles > 0 ? (p.flat.needs_fixup ? 1 : 0) : -1;
+      out->adaptive_family = p.adaptive_family;
       return true;
     }
   }

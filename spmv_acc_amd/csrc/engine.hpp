@@ -108,6 +108,7 @@ struct PlanInfo {
   int aligned16 = 0;
   int stream_policy = -1; // kStreamPolicy* chosen by the plan-time timing, -1 = not tuned yet
   int flat_fixup = -1;    // 1: flat folds cut rows with the fix-up kernel, 0: tiles finish them, -1: no flat plan yet
+  int adaptive_family = -1; // adaptive's timed choice: 0 fixed row blocks, 1 row-block-plus, 2 flat, -1 not timed
 };
 bool query_plan(const int *d_rowptr, int m, PlanInfo *out);
 int cached_plan_count();

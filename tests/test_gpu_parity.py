@@ -482,8 +482,8 @@ def test_rmat_power_law_parity(torch_dev, oracle):
     for rescue_flat, built, not_built in ((0, "plus_blocks", "flat_tiles"), (1, "flat_tiles", "plus_blocks")):
         assert lib.spmv_acc_set_tunable(b"rescue_flat", rescue_flat) == 0
         try:
-            # (adaptive sends a matrix with quarters this uneven to row-block-plus by its own rule, whatever the rescue is)
-            for strat in (("line_enhance", "adaptive") if rescue_flat == 0 else ("line_enhance", "line")):
+            # (adaptive times every family on the matrix and so builds both plans, whatever the rescue is)
+            for strat in ("line_enhance", "line"):
                 y = y0.clone()
                 spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
                 torch.cuda.synchronize()
@@ -914,3 +914,37 @@ def test_prepare_then_first_call_is_capturable(torch_dev, oracle, hiplib):
             spmv_acc_amd.release_plans(drp)
     finally:
         hiplib.spmv_acc_set_stream(None)
+
+
+def test_adaptive_times_the_kernel_families(torch_dev, oracle, hiplib):
+    """adaptive keeps the fastest of fixed row blocks / row-block-plus / flat, timed on the matrix (query_plan reports the family);
+    `adaptive_timed` 0 decides from the rowptr samples and the balance probe alone.  Both forms, three row-length laws, parity."""
+    torch = torch_dev
+    rng = np.random.default_rng(55)
+    m = 60000
+    laws = {"even": rng.integers(20, 31, m), "halves": np.concatenate([rng.integers(30, 50, m // 2), rng.integers(3, 7, m - m // 2)]),
+            "lognormal": np.minimum(np.exp(rng.normal(np.log(20.0), 1.2, m)).astype(np.int64), 20000)}
+    for name, lens in laws.items():
+        rowptr, cols, vals = synth.csr_from_row_lengths(lens, m, rng)
+        nnz = int(rowptr[-1])
+        x, y0 = rng.standard_normal(m), rng.standard_normal(m)
+        ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+        for timed in (1, 0):
+            assert hiplib.spmv_acc_set_tunable(b"adaptive_timed", timed) == 0
+            try:
+                drp, dci, dv, dx, dy = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+                spmv_acc_amd.csr_spmv(1.0, 1.0, m, m, nnz, drp, dci, dv, dx, dy, strategy="adaptive")
+                torch.cuda.synchronize()
+                info = spmv_acc_amd.query_plan(drp, m)
+                got = dy.cpu().numpy()
+                dy2 = dev(torch, y0)  # steady state: the kept family only
+                spmv_acc_amd.csr_spmv(1.0, 1.0, m, m, nnz, drp, dci, dv, dx, dy2, strategy="adaptive")
+                torch.cuda.synchronize()
+                assert np.array_equal(dy2.cpu().numpy(), got), (name, timed)
+                spmv_acc_amd.release_plans(drp)
+            finally:
+                hiplib.spmv_acc_reset_tunables()
+            assert info["adaptive_family"] == (-1 if timed == 0 else info["adaptive_family"]) and (timed == 0 or info["adaptive_family"] in (0, 1, 2))
+            if timed:
+                assert info["flat_tiles"] > 0 and info["plus_blocks"] > 0, (name, info)  # every family was built and timed
+            assert oracle.scaled_error(got, ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, (name, timed)
