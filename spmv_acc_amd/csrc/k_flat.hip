@@ -66,10 +66,15 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
                                                              int xcd_chunk, int reach) {
   // reach: a tile finishes its last row itself when it ends at most `reach` (0 or kFlatFinish) non-zeros past the tile
   constexpr int STRIDE = kThreads * NPT;
+  static_assert(STRIDE / 64 <= kTileSpans, "TileSpans must hold every >= 64-product span of one tile");
   __shared__ __attribute__((aligned(16))) double lds[STRIDE]; // written 16 B at a time
   __shared__ double sh_tail_sum, sh_tail_yold;                 // partial (and old y) of the row this tile will finish itself
   __shared__ int sh_tail_row, sh_tail_end;
-  if (threadIdx.x == 0) sh_tail_row = -1;
+  __shared__ TileSpans spans;
+  if (threadIdx.x == 0) {
+    sh_tail_row = -1;
+    spans.n = 0;
+  }
   const int t = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, ntiles, xcd_chunk) : static_cast<int>(blockIdx.x);
   const int t0 = t * STRIDE; // host guarantees nnz + stride fits in int
   const int t1 = (nnz - t0 > STRIDE) ? t0 + STRIDE : nnz;
@@ -118,8 +123,7 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
     }
     const int lo = (a > t0 ? a : t0) - t0;
     const int hi = (b < t1 ? b : t1) - t0;
-    double s = 0.0;
-    for (int j = lo + lane; j < hi; j += w) s += lds[j];
+    double s = tile_row_sum<kThreads>(lds, spans, lo, hi > lo ? hi : lo, lane, w); // long spans go to whole waves
     s = group_sum_dyn(s, w);
     if (live && lane == 0) {
       if (a >= t0 && b <= t1) {

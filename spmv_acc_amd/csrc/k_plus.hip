@@ -76,6 +76,8 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
                                                         double *__restrict__ partial) {
   __shared__ __attribute__((aligned(16))) double lds[kPlusTile]; // written 16 B at a time
   __shared__ double row_acc[kPlusMaxRows];
+  __shared__ TileSpans spans;
+  if (threadIdx.x == 0) spans.n = 0; // published by the barrier that follows the first staging
   const int g = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, nblocks, xcd_chunk) : static_cast<int>(blockIdx.x);
   const int4v rec = blk[g]; // wave-uniform: one scalar 16-B load
   const int row_begin = rec.x;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
       __syncthreads();
       const int lo = (r0 > off ? r0 : off) - off;
       const int hi = (r1 < off + kPlusTile ? r1 : off + kPlusTile) - off;
-      for (int j = lo + lane; j < hi; j += w) acc += lds[j];
+      acc += tile_row_sum<kThreads>(lds, spans, lo, hi > lo ? hi : lo, lane, w); // long spans go to whole waves
       if (off + kPlusTile < s1) __syncthreads(); // the next round overwrites the tile
     }
     acc = group_sum_dyn(acc, w);

@@ -36,6 +36,8 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   // rpb rows per workgroup, rpb <= kThreads / VEC (not necessarily a power of two: it is chosen so that
   // rpb * average row length fills most of one LDS tile)
   __shared__ __attribute__((aligned(16))) double lds[kTile]; // written 16 B at a time
+  __shared__ TileSpans spans;
+  if (threadIdx.x == 0) spans.n = 0; // published by the barrier that follows the first staging
 
   int b = blockIdx.x;
   if (flags & 1) b = xcd_contiguous_block(b, nblocks);
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
     __syncthreads();
     const int lo = (r0 > off ? r0 : off) - off;
     const int hi = (r1 < off + kTile ? r1 : off + kTile) - off;
-    for (int j = lo + lane; j < hi; j += VEC) acc += lds[j];
+    acc += tile_row_sum<kThreads>(lds, spans, lo, hi > lo ? hi : lo, lane, VEC); // long spans go to whole waves
     if (off + kTile < s1) __syncthreads(); // next round overwrites the tile
   }
   acc = group_sum<VEC>(acc);

@@ -144,5 +144,61 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
   }
 }
 
+
+// ---- per-row sums over a staged tile ---------------------------------------------------------------------------------------
+// Every lane group (w lanes, w wave-uniform or compile-time) sums its row's span [lo, hi) of the tile.  A span of more than
+// max(63, 16 w) products would keep w lanes busy for dozens of dependent LDS reads while the rest of the workgroup idles (a
+// 600-non-zero row among rows of 5: ~11 us for that one lane, measured 2.5x on a circuit-like matrix), so such spans are
+// handed to whole waves instead: the group leader posts (lo, hi), after a barrier the workgroup's waves take the posted spans
+// round-robin (64 lanes each, DPP butterfly), and the leader picks its sum up after a second barrier.  Spans are disjoint
+// pieces of one tile of at most 4096 products, so at most kTileSpans = 4096 / 64 are ever posted.
+//
+// Contract: called by all threads of the workgroup from uniform control flow, after the barrier that follows staging;
+// sh.n must be 0 on entry (zero it once before that barrier) and is 0 again on return.  Returns the span's sum in the
+// leader lane (lane == 0) when the span was posted, the lane's strided partial otherwise; the caller's later group_sum over
+// the w lanes is unaffected (non-leader lanes of a posted span contribute 0).  Costs one barrier when nothing is posted.
+constexpr int kTileSpans = 64; // the largest tile any caller stages is 4096 products (flat_npt 16)
+struct TileSpans {
+  int n;
+  int lo[kTileSpans], hi[kTileSpans];
+  double sum[kTileSpans];
+};
+
+template <int THREADS>
+__device__ __forceinline__ double tile_row_sum(const double *__restrict__ lds, TileSpans &sh, int lo, int hi, int lane, int w) {
+  const int span = hi - lo;
+  const bool posted = w < kWave && span >= 64 && span > 16 * w;
+  int slot = -1;
+  double s = 0.0;
+  if (posted) {
+    if (lane == 0) {
+      slot = atomicAdd(&sh.n, 1);
+      sh.lo[slot] = lo;
+      sh.hi[slot] = hi;
+    }
+  } else {
+    for (int j = lo + lane; j < hi; j += w) s += lds[j];
+  }
+  // the barrier itself tells every thread how many spans were posted (no shared variable to read after it, so a thread
+  // that is late here cannot see a post from a later call)
+  const int n = __syncthreads_count(posted && lane == 0);
+  if (n > 0) {
+    const int wave = threadIdx.x / kWave, l = threadIdx.x & (kWave - 1);
+    for (int e = wave; e < n; e += THREADS / kWave) {
+      double t = 0.0;
+      const int b = sh.hi[e];
+      for (int j = sh.lo[e] + l; j < b; j += kWave) t += lds[j];
+      t = group_sum<64>(t);
+      if (l == 0) sh.sum[e] = t;
+    }
+    __syncthreads();
+    if (slot >= 0) s = sh.sum[slot];
+    __syncthreads(); // every leader has its sum: the posts are consumed
+    if (threadIdx.x == 0) sh.n = 0;
+    __syncthreads(); // ... and the counter is back at 0 before anyone can post in a later call
+  }
+  return s;
+}
+
 } // namespace dev
 } // namespace spmv_acc

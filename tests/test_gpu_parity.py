@@ -174,16 +174,34 @@ def test_unaligned_views_and_device_only_rowptr(torch_dev, oracle, strat):
     spmv_acc_amd.release_plans(drp)
 
 
-def test_bitwise_reproducible(torch_dev):
-    """No atomics anywhere: two runs give identical bits for every strategy."""
+def test_bitwise_reproducible(torch_dev, hiplib):
+    """No atomics anywhere: on one plan every call gives identical bits, for every strategy; with the timed per-matrix choices
+    pinned (they may fall differently when candidates are within noise) a rebuilt plan does too."""
     torch = torch_dev
     rowptr, cols, vals = synth.random_csr(20000, 20000, 12, seed=9, kind="powerlaw")
     rng = np.random.default_rng(3)
     x, y0 = rng.standard_normal(20000), rng.standard_normal(20000)
+    m = n = 20000
+    nnz = int(rowptr[-1])
+    drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
     for strat in ALL:
-        a = run(torch, strat, 1.0, 1.0, rowptr, cols, vals, x, y0)
-        b = run(torch, strat, 1.0, 1.0, rowptr, cols, vals, x, y0)
-        assert np.array_equal(a, b), strat
+        outs = []
+        for _ in range(3):
+            dy = dev(torch, y0)
+            spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat)
+            torch.cuda.synchronize()
+            outs.append(dy.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), strat
+    spmv_acc_amd.release_plans(drp)
+    try:
+        for k, val in (("adaptive_timed", 0), ("stream_plain", 0), ("flat_finish", 0), ("plus_min_nnz", 1024)):
+            assert hiplib.spmv_acc_set_tunable(k.encode(), val) == 0
+        for strat in ALL:
+            a = run(torch, strat, 1.0, 1.0, rowptr, cols, vals, x, y0)  # run() releases the plan: b is computed on a new one
+            b = run(torch, strat, 1.0, 1.0, rowptr, cols, vals, x, y0)
+            assert np.array_equal(a, b), strat
+    finally:
+        hiplib.spmv_acc_reset_tunables()
 
 
 def test_trans_is_reported_not_applied(torch_dev, oracle, hiplib):
@@ -948,3 +966,37 @@ def test_adaptive_times_the_kernel_families(torch_dev, oracle, hiplib):
             if timed:
                 assert info["flat_tiles"] > 0 and info["plus_blocks"] > 0, (name, info)  # every family was built and timed
             assert oracle.scaled_error(got, ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, (name, timed)
+
+
+def test_long_spans_among_short_rows(torch_dev, oracle, hiplib):
+    """Rows of hundreds of non-zeros among rows of 5 (circuit-like): inside a tile such a row's span is summed by whole waves
+    instead of its own 1..16 lanes (tile_stage.hpp tile_row_sum).  Span lengths around every threshold (63/64/65 products, 16 w),
+    spans cut by tile boundaries, several posted spans per tile, all tile kernels and every flat tile size, against the oracle."""
+    torch = torch_dev
+    rng = np.random.default_rng(91)
+    m = 30000
+    lens = rng.integers(3, 8, m)
+    special = [63, 64, 65, 100, 127, 128, 129, 255, 256, 600, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 4096, 5000]
+    where = rng.choice(m, size=8 * len(special), replace=False)
+    lens[where] = np.tile(special, 8)
+    lens[1000:1012] = 70          # twelve posted spans in one tile
+    lens[5000:5003] = [2000, 2100, 64]
+    rowptr, cols, vals = synth.csr_from_row_lengths(lens, m, rng)
+    nnz = int(rowptr[-1])
+    x, y0 = rng.standard_normal(m), rng.standard_normal(m)
+    ref = oracle.host_spmv(-0.5, 2.0, rowptr, cols, vals, x, y0)
+    variants = [("adaptive", {}), ("line_enhance", {}), ("adaptive_plus", {}), ("adaptive_plus", {"plus_min_nnz": 1024}),
+                ("adaptive_plus", {"plus_min_nnz": 1920}), ("flat", {}), ("flat", {"flat_npt": 4}), ("flat", {"flat_npt": 16}),
+                ("flat", {"flat_finish": 0}), ("line_enhance", {"rowblock_guard": 0}), ("line_enhance", {"rowblock_vec": 4}),
+                ("line_enhance", {"rowblock_vec": 16})]
+    for strat, knobs in variants:
+        try:
+            for k, val in knobs.items():
+                assert hiplib.spmv_acc_set_tunable(k.encode(), val) == 0, k
+            got = run(torch, strat, -0.5, 2.0, rowptr, cols, vals, x, y0)
+        finally:
+            hiplib.spmv_acc_reset_tunables()
+        err = oracle.scaled_error(got, ref, -0.5, 2.0, rowptr, cols, vals, x, y0)
+        assert err <= SCALED_TOL, (strat, knobs, err)
+        if not knobs and strat != "adaptive":  # (a fresh adaptive plan may settle on another family: same result to rounding only)
+            assert np.array_equal(got, run(torch, strat, -0.5, 2.0, rowptr, cols, vals, x, y0)), (strat, "not reproducible")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Row-length laws the named stand-ins do not cover (real SuiteSparse matrices are less regular than they are):
   lognormal SIGMA    row lengths ~ lognormal with mean ~30 and the given sigma
-  spikes K LEN       FEM-like rows of 25..35 plus K rows of LEN non-zeros scattered through the matrix
+  spikes K LEN [B]   rows of about B (default 30) non-zeros plus K rows of LEN non-zeros scattered through the matrix
   empty FRAC         rows of 20..40, a fraction FRAC of the rows empty
 Per-launch hipEvent medians for the kernel families + what adaptive chose."""
 import os, sys
@@ -18,7 +18,8 @@ if law == "lognormal":
     lens = torch.exp(torch.randn(m, generator=g, device="cuda") * sigma + (np.log(30.0) - sigma * sigma / 2)).long().clamp_(0, 200000)
 elif law == "spikes":
     k, length = int(sys.argv[2]), int(sys.argv[3])
-    lens = torch.randint(25, 36, (m,), generator=g, device="cuda")
+    base = int(sys.argv[4]) if len(sys.argv) >= 5 else 30  # mean length of the ordinary rows
+    lens = torch.randint(base - base // 6, base + base // 6 + 1, (m,), generator=g, device="cuda")
     lens[torch.randint(0, m, (k,), generator=g, device="cuda")] = length
 else:
     frac = float(sys.argv[2])
