@@ -113,8 +113,29 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
   } else {
     // ---- slice [rec.z, rec.w) of the long row `row_begin` ----
     double s = 0.0;
-    for (int j = rec.z + threadIdx.x; j < rec.w; j += kThreads) {
-      s += load_stream(v + j) * x[load_stream(ci + j)];
+    const int j0 = rec.z, j1 = rec.w;
+    if (ALIGNED) {
+      // 4 consecutive non-zeros per lane per step (one 16-B colindex load, two 16-B value loads), all steps of the slice
+      // issued back to back; the slice start is aligned down to a multiple of 4 and the (at most 3 + 3) foreign elements
+      // at its ends are masked out of the sum.  (One 4-/8-byte load per lane per step ran a matrix made of long rows only
+      // at 4.9 TB/s against 6.0-6.4 for the tile kernels.)
+      for (int base = (j0 & ~3) + 4 * static_cast<int>(threadIdx.x); base < j1; base += 4 * kThreads) {
+        if (base + 4 <= nnz) {
+          const int4v c = load_stream_i4<NTC>(ci + base);
+          const double2v a0 = load_stream_d2<NTV>(v + base);
+          const double2v a1 = load_stream_d2<NTV>(v + base + 2);
+          const double p0 = a0.x * x[c.x], p1 = a0.y * x[c.y], p2 = a1.x * x[c.z], p3 = a1.y * x[c.w];
+          s += (base + 0 >= j0 && base + 0 < j1) ? p0 : 0.0;
+          s += (base + 1 >= j0 && base + 1 < j1) ? p1 : 0.0;
+          s += (base + 2 >= j0 && base + 2 < j1) ? p2 : 0.0;
+          s += (base + 3 >= j0 && base + 3 < j1) ? p3 : 0.0;
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (base + e >= j0 && base + e < j1) s += v[base + e] * x[ci[base + e]];
+        }
+      }
+    } else {
+      for (int j = j0 + threadIdx.x; j < j1; j += kThreads) s += load_stream(v + j) * x[load_stream(ci + j)];
     }
     s = group_sum<64>(s);
     constexpr int kWaves = kThreads / kWave;

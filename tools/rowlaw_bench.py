@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Row-length laws the named stand-ins do not cover (real SuiteSparse matrices are less regular than they are):
-  lognormal SIGMA    row lengths ~ lognormal with mean ~30 and the given sigma
+  lognormal SIGMA [MEAN]  row lengths ~ lognormal with the given sigma and mean (default 30); ROWLAW_M=rows (default 1.5 M)
   spikes K LEN [B]   rows of about B (default 30) non-zeros plus K rows of LEN non-zeros scattered through the matrix
   empty FRAC         rows of 20..40, a fraction FRAC of the rows empty
 Per-launch hipEvent medians for the kernel families + what adaptive chose."""
@@ -10,12 +10,13 @@ import numpy as np, torch
 import spmv_acc_amd
 from spmv_acc_amd import synth
 
-m = n = 1_500_000
+m = n = int(os.environ.get("ROWLAW_M", "1500000"))
 g = torch.Generator(device="cuda"); g.manual_seed(9)
 law = sys.argv[1]
 if law == "lognormal":
     sigma = float(sys.argv[2])
-    lens = torch.exp(torch.randn(m, generator=g, device="cuda") * sigma + (np.log(30.0) - sigma * sigma / 2)).long().clamp_(0, 200000)
+    mean = float(sys.argv[3]) if len(sys.argv) >= 4 else 30.0
+    lens = torch.exp(torch.randn(m, generator=g, device="cuda") * sigma + (np.log(mean) - sigma * sigma / 2)).long().clamp_(0, 2000000)
 elif law == "spikes":
     k, length = int(sys.argv[2]), int(sys.argv[3])
     base = int(sys.argv[4]) if len(sys.argv) >= 5 else 30  # mean length of the ordinary rows
