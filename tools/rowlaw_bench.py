@@ -29,7 +29,14 @@ else:
 rp = torch.zeros(m + 1, dtype=torch.int64, device="cuda"); torch.cumsum(lens, 0, out=rp[1:])
 nnz = int(rp[-1].item())
 rows = torch.repeat_interleave(torch.arange(m, device="cuda"), lens, output_size=nnz)
-ci = (rows + torch.randint(-40, 41, (nnz,), generator=g, device="cuda")).clamp_(0, n - 1)
+cols_law = os.environ.get("ROWLAW_COLS", "near")  # near: +-40 of the diagonal; clusters: three such windows n/3 apart; uniform: anywhere
+if cols_law == "uniform":
+    ci = torch.randint(0, n, (nnz,), generator=g, device="cuda")
+else:
+    ci = rows + torch.randint(-40, 41, (nnz,), generator=g, device="cuda")
+    if cols_law == "clusters":
+        ci = (ci + torch.randint(0, 3, (nnz,), generator=g, device="cuda") * (n // 3)) % n
+    ci = ci.clamp_(0, n - 1)
 key, _ = torch.sort(rows * n + ci); ci = (key % n).to(torch.int32); del key, rows
 v = torch.rand(nnz, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
 rp = rp.to(torch.int32)
