@@ -311,6 +311,7 @@ namespace {
 
 struct Plan {
   int device = 0;
+  unsigned long long last_use = 0; // plan-cache clock at the last call that used this plan
   CsrDev A;
   bool have_samples = false;
   RowptrSamples samples;
@@ -362,7 +363,8 @@ struct Plan {
 
 typedef std::tuple<int, const void *, const void *, const void *, int, int> PlanKey;
 std::map<PlanKey, std::shared_ptr<Plan>> g_plans; // a running call keeps its plan alive through its own reference
-constexpr size_t kMaxPlans = 256;
+constexpr size_t kMaxPlans = 1024; // beyond this the least recently used plan is dropped
+unsigned long long g_use_clock = 0;
 
 // Is p readable by the host?  The reference's sparse_spmv hands the SAME device pointer in as "host"
 // rowptr (api/spmv_imp.cpp:14-17), which only works with host-visible device memory.
@@ -411,11 +413,19 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_plans.find(key);
   if (it != g_plans.end()) {
-    if (nnz < 0 || nnz == it->second->A.nnz) return it->second;
+    if (nnz < 0 || nnz == it->second->A.nnz) {
+      it->second->last_use = ++g_use_clock;
+      return it->second;
+    }
     // same buffers, different nnz: the caller rebuilt the matrix in place
     g_plans.erase(it);
   }
-  if (g_plans.size() >= kMaxPlans) g_plans.clear();
+  if (g_plans.size() >= kMaxPlans) {
+    auto oldest = g_plans.begin();
+    for (auto jt = g_plans.begin(); jt != g_plans.end(); ++jt)
+      if (jt->second->last_use < oldest->second->last_use) oldest = jt;
+    g_plans.erase(oldest);
+  }
   if (nnz < 0) {
     if ((h_rowptr = host_view(h_rowptr)) != nullptr) {
       nnz = h_rowptr[m];
@@ -437,6 +447,7 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
   p->A.v = v;
   p->A.aligned16 = (reinterpret_cast<uintptr_t>(ci) % 16 == 0) && (reinterpret_cast<uintptr_t>(v) % 16 == 0) &&
                    nnz >= 8;
+  p->last_use = ++g_use_clock;
   g_plans[key] = p;
   return p;
 }

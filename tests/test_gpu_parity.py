@@ -1000,3 +1000,34 @@ def test_long_spans_among_short_rows(torch_dev, oracle, hiplib):
         assert err <= SCALED_TOL, (strat, knobs, err)
         if not knobs and strat != "adaptive":  # (a fresh adaptive plan may settle on another family: same result to rounding only)
             assert np.array_equal(got, run(torch, strat, -0.5, 2.0, rowptr, cols, vals, x, y0)), (strat, "not reproducible")
+
+
+def test_plan_cache_is_lru_bounded(torch_dev, hiplib):
+    """More live matrices than the plan cache holds (1024): the least recently used plans go, the cache never grows past its
+    bound, recently used matrices keep their plans, and results stay right throughout."""
+    torch = torch_dev
+    spmv_acc_amd.release_plans()
+    rng = np.random.default_rng(12)
+    m = 64
+    mats = []
+    for i in range(1040):
+        rowptr = torch.arange(0, 2 * m + 1, 2, dtype=torch.int32, device="cuda")           # 2 non-zeros per row
+        cols = torch.stack([torch.arange(m, device="cuda"), (torch.arange(m, device="cuda") + 1 + i) % m], 1).reshape(-1).to(torch.int32)
+        vals = torch.full((2 * m,), float(i + 1), dtype=torch.float64, device="cuda")
+        mats.append((rowptr, cols, vals))
+    x = torch.ones(m, dtype=torch.float64, device="cuda")
+    y = torch.zeros(m, dtype=torch.float64, device="cuda")
+    for i, (rp, ci, v) in enumerate(mats):
+        spmv_acc_amd.csr_spmv(1.0, 0.0, m, m, 2 * m, rp, ci, v, x, y, strategy="line_enhance")
+        if i % 97 == 0:
+            torch.cuda.synchronize()
+            assert float(y.min().item()) == float(y.max().item()) == 2.0 * (i + 1)
+        if i == 1000:  # touch matrix 0 again: it becomes the most recently used and must survive the evictions that follow
+            spmv_acc_amd.csr_spmv(1.0, 0.0, m, m, 2 * m, *mats[0], x, y, strategy="line_enhance")
+    torch.cuda.synchronize()
+    assert hiplib.spmv_acc_cached_plans() == 1024
+    assert spmv_acc_amd.query_plan(mats[0][0], m) is not None      # re-used late: kept
+    assert spmv_acc_amd.query_plan(mats[1][0], m) is None          # oldest: evicted
+    assert spmv_acc_amd.query_plan(mats[1039][0], m) is not None
+    spmv_acc_amd.release_plans()
+    assert hiplib.spmv_acc_cached_plans() == 0
