@@ -58,6 +58,12 @@ struct Tunable {
   int def;
   int val;
 };
+// indices into g_tunables, in table order (the kernels' hot path reads tunables by index, not by name)
+enum TunableId {
+  kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
+  kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kTunableCount
+};
 Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
     {"xcd_chunk", 16, 16},     // row-block family: each XCD takes this many consecutive blocks per super-chunk (0 = off)
@@ -74,14 +80,18 @@ Tunable g_tunables[] = {
                                // 0 = decide from the four rowptr samples and the balance probe only
     {"adaptive_split", 0, 0},  // adaptive, halves differing >= 4x: 1 = the reference's two-width vector-row split
     {"rescue_flat", 0, 0},     // 1: the rescue is flat (nnz-cut tiles) instead of the row-block-plus kernel
-    {"plus_ref_vec", 0, 0},
+    {"plus_ref_vec", 0, 0},    // 1: row-block-plus analysis with the reference's VEC_SIZE pick (pow2 >= avg/2)
     {"plus_min_nnz", 0, 0},    // adaptive-plus analysis: MIN_NNZ_PER_BLOCK; 0 = time 1024 (the reference's instance) / 1536 /
                                // 1920 on the matrix and keep the fastest
-    {"plus_host_analysis", 0, 0}, // 1: run the row-block analysis on the host (the reference's form)    // 1: row-block-plus analysis with the reference's VEC_SIZE pick
+    {"plus_host_analysis", 0, 0}, // 1: run the row-block analysis on the host (the reference's form)
     {"flat_finish", -1, -1},   // flat cut rows: -1 time both forms per matrix, 0 carries + fix-up kernel, 1 tiles finish them (when legal)
-    {"flat_npt", 8, 8},
-    {"validate", 0, 0},        // 1: check rowptr / colindex of every new matrix on the device before the first launch        // non-zeros per lane per flat tile: 4, 8 or 16 (tile = 256 lanes x this)
+    {"flat_npt", 8, 8},        // non-zeros per lane per flat tile: 4, 8 or 16 (tile = 256 lanes x this)
+    {"validate", 0, 0},        // 1: check rowptr / colindex of every new matrix on the device before the first launch
 };
+static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
+void apply_env_tunables();
+inline int tun(TunableId id) { return g_tunables[id].val; } // apply_env_tunables() has run: run_spmv calls it first
+
 } // namespace
 
 namespace {
@@ -453,7 +463,7 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
 }
 
 bool ensure_flat(Plan &p, hipStream_t stream) {
-  const int npt = get_tunable("flat_npt");
+  const int npt = tun(kT_flat_npt);
   const int stride = kThreads * ((npt == 4 || npt == 16) ? npt : kNnzPerThread);
   if (p.flat_tiles >= 0 && p.flat.stride == stride) return true;
   p.free_flat();
@@ -553,7 +563,7 @@ namespace {
 bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) {
   if (min_nnz < 256 || min_nnz > kTile) min_nnz = kPlusMinNnz;
   const int want_vec =
-      get_tunable("plus_ref_vec") ? plus_pick_vec(p.A.m, p.A.nnz) : plus_pick_vec_tuned(p.A.m, p.A.nnz, min_nnz);
+      tun(kT_plus_ref_vec) ? plus_pick_vec(p.A.m, p.A.nnz) : plus_pick_vec_tuned(p.A.m, p.A.nnz, min_nnz);
   if (p.plus_blocks >= 0 && p.plus_vec == want_vec && p.plus_min == min_nnz) return true;
   if (p.plus_blocks >= 0) { // analysis parameters changed (measurement switch): rebuild
     if (p.d_pbp) (void)hipFree(p.d_pbp);
@@ -571,7 +581,7 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) 
   const int m = p.A.m;
   const int vec = want_vec;
   int blocks = -1;
-  if (get_tunable("plus_host_analysis")) {
+  if (tun(kT_plus_host_analysis)) {
     // host form (the reference's): needs rowptr on the host
     std::vector<int> staged;
     const int *hrp = host_view(h_rowptr);
@@ -619,7 +629,7 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) 
 }
 
 int policy_for(const Plan &p) {
-  const int forced = get_tunable("stream_plain");
+  const int forced = tun(kT_stream_plain);
   if (forced >= 0) return forced & 3;
   return p.stream_policy >= 0 ? p.stream_policy : kStreamPolicyNt;
 }
@@ -663,7 +673,7 @@ struct TuneTimer {
 // no side effects on the caller's y) and keep the fastest.  Up to eight launches per candidate (TuneTimer: 3 to reach
 // that policy's cache steady state + 5 timed; 2 in all when a launch takes milliseconds), once per matrix.
 template <typename Launch> bool autotune_policy(Plan &p, hipStream_t st, Launch &&launch) {
-  if (p.stream_policy >= 0 || get_tunable("stream_plain") >= 0 || !p.A.aligned16) {
+  if (p.stream_policy >= 0 || tun(kT_stream_plain) >= 0 || !p.A.aligned16) {
     if (p.stream_policy < 0) p.stream_policy = kStreamPolicyNt;
     return true;
   }
@@ -691,7 +701,7 @@ template <typename Launch> bool autotune_policy(Plan &p, hipStream_t st, Launch 
 }
 
 void launch_flat_with(hipStream_t st, Plan &p, int policy, double alpha, double beta, const double *x, double *y) {
-  p.flat.xcd_chunk = get_tunable("stage_fast") ? get_tunable("xcd_chunk_tiles") : -1; // -1: per-lane predicated staging (A/B)
+  p.flat.xcd_chunk = tun(kT_stage_fast) ? tun(kT_xcd_chunk_tiles) : -1; // -1: per-lane predicated staging (A/B)
   p.flat.stream_policy = policy;
   launch_flat(st, p.A, p.flat, alpha, beta, x, y);
 }
@@ -701,7 +711,7 @@ void launch_flat_with(hipStream_t st, Plan &p, int policy, double alpha, double 
 // kernels) but saves the fix-up launch (+5..20 % on kernels under 30 us).  Timed once per matrix like the cache policy.
 bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
   FlatPlan &F = p.flat;
-  const int forced = get_tunable("flat_finish");
+  const int forced = tun(kT_flat_finish);
   if (!F.can_finish || F.ntiles <= 1) {
     F.needs_fixup = !F.can_finish;
     return true;
@@ -810,28 +820,28 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
 bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y,
                   bool allow_uneven_switch = false) {
   int vec = 1, rpb = kThreads;
-  pick_rowblock_shape(p.A.m, p.A.nnz, get_tunable("rowblock_target"), &vec, &rpb);
-  const int forced = get_tunable("rowblock_vec");
+  pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
+  const int forced = tun(kT_rowblock_vec);
   if (forced > 0) {
     vec = forced;
     rpb = kThreads / forced;
   }
-  if (get_tunable("rowblock_guard")) {
+  if (tun(kT_rowblock_guard)) {
     if (!probe_rowblock(p, rpb, st)) return false;
     // Imbalanced (power-law) matrix: fixed row blocks would leave a few workgroups with most of the work.  The rescue
     // is the row-block-PLUS kernel -- the reference's own answer to this (hip-csr-adaptive-plus is its line-enhance
     // kernel over analysed row blocks, long rows cut into dedicated blocks) -- which measures 1 % (R-MAT scale 25),
     // 5 % (scale 22) and 17 % (scale 20) faster than the nnz-cut tiles of flat; `rescue_flat` keeps the older choice.
     if (p.rowblock_ok == 0)
-      return get_tunable("rescue_flat") ? run_flat(st, p, alpha, beta, x, y) : run_plus(st, p, h_rowptr, alpha, beta, x, y);
+      return tun(kT_rescue_flat) ? run_flat(st, p, alpha, beta, x, y) : run_plus(st, p, h_rowptr, alpha, beta, x, y);
     // Uneven but not pathological (striped densities: 60 / 20 nnz per row alternating every 300 or 5000 rows ran 196 us here and
     // 177 us in row-block-plus; 30 / 10 every 64 rows 108 vs 97 us): same answer, for the strategies that leave the choice to
     // the engine.  line / line-enhance / thread_row keep their fixed row blocks.
-    if (p.rowblock_uneven && allow_uneven_switch && !get_tunable("rescue_flat")) return run_plus(st, p, h_rowptr, alpha, beta, x, y);
+    if (p.rowblock_uneven && allow_uneven_switch && !tun(kT_rescue_flat)) return run_plus(st, p, h_rowptr, alpha, beta, x, y);
   }
-  const int chunk = get_tunable("xcd_chunk");
-  const int base_flags = (get_tunable("xcd_remap") ? 1 : 0) | (get_tunable("early_y") ? 2 : 0) |
-                         (chunk > 0 ? (4 | (chunk << 8)) : 0) | (get_tunable("stage_fast") ? 0 : 8);
+  const int chunk = tun(kT_xcd_chunk);
+  const int base_flags = (tun(kT_xcd_remap) ? 1 : 0) | (tun(kT_early_y) ? 2 : 0) |
+                         (chunk > 0 ? (4 | (chunk << 8)) : 0) | (tun(kT_stage_fast) ? 0 : 8);
   if (!autotune_policy(p, st, [&](int pol, double *ys) {
         launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (pol << 4), 1.0, 0.0, x, ys);
       }))
@@ -846,11 +856,11 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
 // so the candidates are timed once per matrix like the cache policy.
 bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double *x) {
   auto launch = [&](int pol, double *ys) {
-    launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, get_tunable("xcd_chunk_tiles"), pol,
+    launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk_tiles), pol,
                 p.d_ppartial, 1.0, 0.0, x, ys);
   };
-  const int forced = get_tunable("plus_min_nnz");
-  if (forced > 0 || get_tunable("plus_ref_vec")) {
+  const int forced = tun(kT_plus_min_nnz);
+  if (forced > 0 || tun(kT_plus_ref_vec)) {
     return ensure_plus(p, h_rowptr, st, forced > 0 ? forced : kPlusMinNnz) && autotune_policy(p, st, launch);
   }
   if (p.plus_tuned_min > 0) return ensure_plus(p, h_rowptr, st, p.plus_tuned_min) && autotune_policy(p, st, launch);
@@ -885,7 +895,7 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
 
 bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y) {
   if (!run_plus_prepare(p, h_rowptr, st, x)) return false;
-  launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, get_tunable("xcd_chunk_tiles"),
+  launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk_tiles),
               policy_for(p), p.d_ppartial, alpha, beta, x, y);
   return true;
 }
@@ -939,6 +949,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     // the non-transposed product.  Same here, but the mismatch is reported out of band.
     set_error(kErrUnsupportedTrans, "only operation_none is supported; computed y = alpha*A*x + beta*y");
   }
+  apply_env_tunables();
   if (m <= 0) return;
   if (!d_rowptr || !dy || (n > 0 && !dx)) {
     set_error(kErrBadArgument, "null rowptr / x / y");
@@ -960,7 +971,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     set_error(kErrBadArgument, "null colindex / value with nnz > 0");
     return;
   }
-  if (get_tunable("validate") && !validate_plan(*p, st)) return;
+  if (tun(kT_validate) && !validate_plan(*p, st)) return;
 
   const long long avg = static_cast<long long>(p->A.nnz) / m;
   switch (strategy) {
@@ -968,7 +979,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   case kVectorRow:
   {
     const int w = classic_vec(avg);
-    if (get_tunable("rowblock_guard") && !probe_rowblock(*p, kThreads / w, st)) return;
+    if (tun(kT_rowblock_guard) && !probe_rowblock(*p, kThreads / w, st)) return;
     launch_vector_row(st, p->A, m, w, 1, alpha, beta, dx, dy, p->rowblock_ok == 0);
     break;
   }
@@ -990,7 +1001,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     break;
   case kAdaptive: {
     if (!fetch_samples(*p, h_rowptr)) return;
-    if (get_tunable("adaptive_timed") && !get_tunable("adaptive_split")) {
+    if (tun(kT_adaptive_timed) && !tun(kT_adaptive_split)) {
       run_adaptive_timed(st, *p, h_rowptr, alpha, beta, dx, dy);
       break;
     }
@@ -1001,7 +1012,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
       // (vector_row.cpp:30-38; still available as adaptive_vec_row_sparse_spmv / tunable adaptive_split).  Blocks cut by
       // non-zero count with lanes per row chosen per block fit such a matrix better: on a 2 M-row matrix with halves of 40
       // and 5 nnz/row the split took 185 us, row-block-plus 110 us, flat 110 us, fixed row blocks 120 us.
-      if (get_tunable("adaptive_split")) {
+      if (tun(kT_adaptive_split)) {
         const int half_rows = m / 2;
         const long long a0 = half_rows > 0 ? p->samples.half / half_rows : 0;
         const long long a1 = (static_cast<long long>(p->samples.last) - p->samples.half) / (m - half_rows);
@@ -1019,7 +1030,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
       // Fixed row blocks are sized from the matrix-wide average row length; where the four row quarters (the samples the
       // decision already holds) differ 1.75x or more in non-zeros, blocks cut by non-zero count fit better: row-block-plus
       // measures 3-7 % faster at 2x-3x (tools/halves_bench.py), the same within 1 % at 1.5x.
-      if (quarters_uneven(p->samples) && !get_tunable("adaptive_split")) run_plus(st, *p, h_rowptr, alpha, beta, dx, dy);
+      if (quarters_uneven(p->samples) && !tun(kT_adaptive_split)) run_plus(st, *p, h_rowptr, alpha, beta, dx, dy);
       else run_rowblock(st, *p, h_rowptr, alpha, beta, dx, dy, true);
       break;
     }
@@ -1053,7 +1064,7 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->nnz = p.A.nnz;
       out->adaptive_branch = p.have_samples ? adaptive_branch(m, p.samples) : 0;
       int rb_vec = 1, rb_rows = kThreads;
-      pick_rowblock_shape(m, p.A.nnz, get_tunable("rowblock_target"), &rb_vec, &rb_rows);
+      pick_rowblock_shape(m, p.A.nnz, tun(kT_rowblock_target), &rb_vec, &rb_rows);
       out->vec = rb_vec; // lanes per row of the row-block family for this matrix
       out->flat_tiles = p.flat_tiles;
       out->plus_blocks = p.plus_blocks;
