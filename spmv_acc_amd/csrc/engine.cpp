@@ -673,7 +673,7 @@ struct TuneTimer {
 // no side effects on the caller's y) and keep the fastest.  Up to eight launches per candidate (TuneTimer: 3 to reach
 // that policy's cache steady state + 5 timed; 2 in all when a launch takes milliseconds), once per matrix.
 template <typename Launch> bool autotune_policy(Plan &p, hipStream_t st, Launch &&launch) {
-  if (p.stream_policy >= 0 || tun(kT_stream_plain) >= 0 || !p.A.aligned16) {
+  if (p.stream_policy >= 0 || tun(kT_stream_plain) >= 0) {
     if (p.stream_policy < 0) p.stream_policy = kStreamPolicyNt;
     return true;
   }

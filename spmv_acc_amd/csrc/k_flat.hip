@@ -248,20 +248,17 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
                  double *y) {
   if (P.ntiles <= 0) return;
   const int npt = P.stride / kThreads;
-  if (!A.aligned16) {
-    if (npt == 4) launch_flat_variant<4, false, true, true>(stream, A, P, alpha, beta, x, y);
-    else if (npt == 16) launch_flat_variant<16, false, true, true>(stream, A, P, alpha, beta, x, y);
-    else launch_flat_variant<8, false, true, true>(stream, A, P, alpha, beta, x, y);
-  } else if (npt == 4) {
-    launch_flat_variant<4, true, true, true>(stream, A, P, alpha, beta, x, y);
+  // ALIGNED = false everywhere: under-aligned vector loads serve every base-pointer alignment (device_utils.hpp)
+  if (npt == 4) {
+    launch_flat_variant<4, false, true, true>(stream, A, P, alpha, beta, x, y);
   } else if (npt == 16) {
-    launch_flat_variant<16, true, true, true>(stream, A, P, alpha, beta, x, y);
+    launch_flat_variant<16, false, true, true>(stream, A, P, alpha, beta, x, y);
   } else {
     switch (P.stream_policy & 3) { // cache policy of the stream loads, see kernels.hpp
-    case 1: launch_flat_variant<8, true, false, false>(stream, A, P, alpha, beta, x, y); break;
-    case 2: launch_flat_variant<8, true, false, true>(stream, A, P, alpha, beta, x, y); break;
-    case 3: launch_flat_variant<8, true, true, false>(stream, A, P, alpha, beta, x, y); break;
-    default: launch_flat_variant<8, true, true, true>(stream, A, P, alpha, beta, x, y); break;
+    case 1: launch_flat_variant<8, false, false, false>(stream, A, P, alpha, beta, x, y); break;
+    case 2: launch_flat_variant<8, false, false, true>(stream, A, P, alpha, beta, x, y); break;
+    case 3: launch_flat_variant<8, false, true, false>(stream, A, P, alpha, beta, x, y); break;
+    default: launch_flat_variant<8, false, true, true>(stream, A, P, alpha, beta, x, y); break;
     }
   }
   if (P.ntiles > 1 && P.needs_fixup) {

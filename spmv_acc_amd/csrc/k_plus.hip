@@ -114,16 +114,16 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
     // ---- slice [rec.z, rec.w) of the long row `row_begin` ----
     double s = 0.0;
     const int j0 = rec.z, j1 = rec.w;
-    if (ALIGNED) {
+    {
       // 4 consecutive non-zeros per lane per step (one 16-B colindex load, two 16-B value loads), all steps of the slice
       // issued back to back; the slice start is aligned down to a multiple of 4 and the (at most 3 + 3) foreign elements
       // at its ends are masked out of the sum.  (One 4-/8-byte load per lane per step ran a matrix made of long rows only
       // at 4.9 TB/s against 6.0-6.4 for the tile kernels.)
       for (int base = (j0 & ~3) + 4 * static_cast<int>(threadIdx.x); base < j1; base += 4 * kThreads) {
         if (base + 4 <= nnz) {
-          const int4v c = load_stream_i4<NTC>(ci + base);
-          const double2v a0 = load_stream_d2<NTV>(v + base);
-          const double2v a1 = load_stream_d2<NTV>(v + base + 2);
+          const int4v c = load_stream_i4<NTC, ALIGNED>(ci + base);
+          const double2v a0 = load_stream_d2<NTV, ALIGNED>(v + base);
+          const double2v a1 = load_stream_d2<NTV, ALIGNED>(v + base + 2);
           const double p0 = a0.x * x[c.x], p1 = a0.y * x[c.y], p2 = a1.x * x[c.z], p3 = a1.y * x[c.w];
           s += (base + 0 >= j0 && base + 0 < j1) ? p0 : 0.0;
           s += (base + 1 >= j0 && base + 1 < j1) ? p1 : 0.0;
@@ -134,8 +134,6 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
             if (base + e >= j0 && base + e < j1) s += v[base + e] * x[ci[base + e]];
         }
       }
-    } else {
-      for (int j = j0 + threadIdx.x; j < j1; j += kThreads) s += load_stream(v + j) * x[load_stream(ci + j)];
     }
     s = group_sum<64>(s);
     constexpr int kWaves = kThreads / kWave;
@@ -183,15 +181,11 @@ void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *
 #define SPMV_ACC_LAUNCH_PLUS(AL, NC, NV)                                                                                \
   hipLaunchKernelGGL((plus_kernel<AL, NC, NV>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk,   \
                      alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial)
-  if (!A.aligned16) {
-    SPMV_ACC_LAUNCH_PLUS(false, true, true);
-  } else {
-    switch (stream_policy & 3) {
-    case 1: SPMV_ACC_LAUNCH_PLUS(true, false, false); break;
-    case 2: SPMV_ACC_LAUNCH_PLUS(true, false, true); break;
-    case 3: SPMV_ACC_LAUNCH_PLUS(true, true, false); break;
-    default: SPMV_ACC_LAUNCH_PLUS(true, true, true); break;
-    }
+  switch (stream_policy & 3) { // ALIGNED = false: under-aligned vector loads serve every base-pointer alignment
+  case 1: SPMV_ACC_LAUNCH_PLUS(false, false, false); break;
+  case 2: SPMV_ACC_LAUNCH_PLUS(false, false, true); break;
+  case 3: SPMV_ACC_LAUNCH_PLUS(false, true, false); break;
+  default: SPMV_ACC_LAUNCH_PLUS(false, true, true); break;
   }
 #undef SPMV_ACC_LAUNCH_PLUS
   if (has_long_rows) {

@@ -123,15 +123,13 @@ void launch_vec(hipStream_t stream, const CsrDev &A, int rpb, int xcd, double al
 #define SPMV_ACC_LAUNCH_RB(AL, NC, NV)                                                                                  \
   hipLaunchKernelGGL((rowblock_stream_kernel<VEC, AL, NC, NV>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,  \
                      nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y)
-  if (!A.aligned16) {
-    SPMV_ACC_LAUNCH_RB(false, true, true);
-  } else {
-    switch ((xcd >> 4) & 3) {
-    case 1: SPMV_ACC_LAUNCH_RB(true, false, false); break;
-    case 2: SPMV_ACC_LAUNCH_RB(true, false, true); break;
-    case 3: SPMV_ACC_LAUNCH_RB(true, true, false); break;
-    default: SPMV_ACC_LAUNCH_RB(true, true, true); break;
-    }
+  // one set of kernels for every base-pointer alignment: their 16-B loads go through under-aligned vector types
+  // (device_utils.hpp), the same instruction with the same cache policy whether or not the caller's arrays are 16-B aligned
+  switch ((xcd >> 4) & 3) {
+  case 1: SPMV_ACC_LAUNCH_RB(false, false, false); break;
+  case 2: SPMV_ACC_LAUNCH_RB(false, false, true); break;
+  case 3: SPMV_ACC_LAUNCH_RB(false, true, false); break;
+  default: SPMV_ACC_LAUNCH_RB(false, true, true); break;
   }
 #undef SPMV_ACC_LAUNCH_RB
 }

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kThreads) void wave_row_kernel(int m, int nnz, doub
   if (live) {
     const int j0 = rp[row];
     const int j1 = rp[row + 1];
-    if (ALIGNED) {
+    {
       for (int base = (j0 & ~3) + 4 * lane; base < j1; base += 2 * 4 * kWave) {
         const int ia = base, ib = base + 4 * kWave;
         const bool fa = ia + 4 <= nnz;             // whole 16-B group inside the arrays
@@ -131,14 +131,14 @@ __global__ __launch_bounds__(kThreads) void wave_row_kernel(int m, int nnz, doub
         int4v ca, cb;
         double2v a0, a1, b0, b1;
         if (fa) {
-          ca = load_stream_i4(ci + ia);
-          a0 = load_stream_d2(v + ia);
-          a1 = load_stream_d2(v + ia + 2);
+          ca = load_stream_i4<true, ALIGNED>(ci + ia);
+          a0 = load_stream_d2<true, ALIGNED>(v + ia);
+          a1 = load_stream_d2<true, ALIGNED>(v + ia + 2);
         }
         if (fb) {
-          cb = load_stream_i4(ci + ib);
-          b0 = load_stream_d2(v + ib);
-          b1 = load_stream_d2(v + ib + 2);
+          cb = load_stream_i4<true, ALIGNED>(ci + ib);
+          b0 = load_stream_d2<true, ALIGNED>(v + ib);
+          b1 = load_stream_d2<true, ALIGNED>(v + ib + 2);
         }
         if (fa) {
           const double p0 = a0.x * x[ca.x], p1 = a0.y * x[ca.y], p2 = a1.x * x[ca.z], p3 = a1.y * x[ca.w];
@@ -161,8 +161,6 @@ __global__ __launch_bounds__(kThreads) void wave_row_kernel(int m, int nnz, doub
             if (ib + e < j1) s += v[ib + e] * x[ci[ib + e]];
         }
       }
-    } else {
-      for (int j = j0 + lane; j < j1; j += kWave) s += load_stream(v + j) * x[load_stream(ci + j)];
     }
   }
   s = group_sum<64>(s);
@@ -242,13 +240,8 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
 void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y) {
   if (A.m <= 0) return;
   const int grid = ceil_div_ll(A.m, kThreads / kWave);
-  if (A.aligned16) {
-    hipLaunchKernelGGL((wave_row_kernel<true>), dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci,
-                       A.v, x, y);
-  } else {
-    hipLaunchKernelGGL((wave_row_kernel<false>), dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp,
-                       A.ci, A.v, x, y);
-  }
+  hipLaunchKernelGGL((wave_row_kernel<false>), dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci, A.v,
+                     x, y);
 }
 
 void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes, bool non_temporal) {

@@ -34,7 +34,7 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
   // so hipcc places exact s_waitcnt counts: all stream loads of the wave, then all its gathers in flight.  (With
   // per-lane branches it waited for half of the first step's gathers before issuing the second step's.)  Products of
   // re-loaded groups land in slots >= hi - a0 that no reader touches.
-  if (ALIGNED && allow_fast && ((hi + 3) & ~3) <= nnz) {
+  if (allow_fast && ((hi + 3) & ~3) <= nnz) {
     int4v c[K];
     double2v va[K], vb[K];
     bool wave_has[K]; // wave-uniform: does any lane of this wave have a group below hi in step k?
@@ -45,9 +45,9 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
       if (wave_has[k]) {
         const int j = a0 + 4 * (threadIdx.x + k * THREADS);
         const int jc = (j < hi) ? j : a0; // lanes past hi in the boundary wave re-read the tile's first group (L1 hit)
-        c[k] = load_stream_i4<NTC>(ci + jc);
-        va[k] = load_stream_d2<NTV>(v + jc);
-        vb[k] = load_stream_d2<NTV>(v + jc + 2);
+        c[k] = load_stream_i4<NTC, ALIGNED>(ci + jc);
+        va[k] = load_stream_d2<NTV, ALIGNED>(v + jc);
+        vb[k] = load_stream_d2<NTV, ALIGNED>(v + jc + 2);
       }
     }
     double xg[K][4];
@@ -76,7 +76,7 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
     }
     return;
   }
-  if (ALIGNED) {
+  {
     int4v c[K];
     double2v va[K], vb[K];
     bool full[K];
@@ -85,9 +85,9 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
       const int j = a0 + 4 * (threadIdx.x + k * THREADS);
       full[k] = (j < hi) && (j + 4 <= nnz);
       if (full[k]) {
-        c[k] = load_stream_i4(ci + j);
-        va[k] = load_stream_d2(v + j);
-        vb[k] = load_stream_d2(v + j + 2);
+        c[k] = load_stream_i4<NTC, ALIGNED>(ci + j);
+        va[k] = load_stream_d2<NTV, ALIGNED>(v + j);
+        vb[k] = load_stream_d2<NTV, ALIGNED>(v + j + 2);
       }
     }
     double xg[K][4];
@@ -123,27 +123,8 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
         }
       }
     }
-  } else {
-    // unaligned base pointers (e.g. a sub-array view): element-per-lane loads, still phase-separated
-    constexpr int E = NPT;
-    int cc[E];
-    double vv[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int j = a0 + threadIdx.x + e * THREADS;
-      if (j < hi) {
-        cc[e] = load_stream(ci + j);
-        vv[e] = load_stream(v + j);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int j = a0 + threadIdx.x + e * THREADS;
-      if (j < hi) lds[threadIdx.x + e * THREADS] = vv[e] * x[cc[e]];
-    }
   }
 }
-
 
 // ---- per-row sums over a staged tile ---------------------------------------------------------------------------------------
 // Every lane group (w lanes, w wave-uniform or compile-time) sums its row's span [lo, hi) of the tile.  A span of more than
