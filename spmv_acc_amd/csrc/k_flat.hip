@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void break_points_kernel(const int *__restrict
       const int mid = lo + (hi - lo) / 2;
       if (rp[mid] < target) lo = mid + 1; else hi = mid;
     }
-    out = (rp[lo] == target) ? lo : lo - 1;
+    // (lo == 0 only when rowptr[0] > 0 -- a row shard passed without rebasing: every tile before its first non-zero
+    // then points at row 0 and owns no rows)
+    out = (rp[lo] == target) ? lo : (lo > 0 ? lo - 1 : 0);
   }
   bp[j] = out;
 }

@@ -1031,3 +1031,27 @@ def test_plan_cache_is_lru_bounded(torch_dev, hiplib):
     assert spmv_acc_amd.query_plan(mats[1039][0], m) is not None
     spmv_acc_amd.release_plans()
     assert hiplib.spmv_acc_cached_plans() == 0
+
+
+def test_row_shard_without_rebasing(torch_dev, oracle):
+    """A row shard handed over as views of the whole matrix -- rowptr + r0 (so rowptr[0] > 0), the complete colindex / value
+    arrays, y + r0 -- as a caller slicing a larger CSR in place would: every strategy computes exactly the shard's rows and
+    touches nothing outside them."""
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(30000, 30000, 11, seed=4, kind="powerlaw")
+    rng = np.random.default_rng(1)
+    x, y0 = rng.standard_normal(30000), rng.standard_normal(30000)
+    ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+    drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+    for r0, r1 in ((12345, 27001), (1, 30000), (29990, 30000), (7, 8)):
+        for strat in ALL:
+            dy = dev(torch, y0)
+            spmv_acc_amd.csr_spmv(1.0, 1.0, r1 - r0, 30000, int(rowptr[r1]), drp[r0:], dci, dv, dx, dy[r0:], strategy=strat)
+            torch.cuda.synchronize()
+            got = dy.cpu().numpy()
+            assert np.array_equal(got[:r0], y0[:r0]) and np.array_equal(got[r1:], y0[r1:]), (strat, r0, r1, "wrote outside the shard")
+            sl = slice(r0, r1)
+            err = oracle.scaled_error(got[sl], ref[sl], 1.0, 1.0, (rowptr[r0:r1 + 1] - rowptr[r0]).astype(np.int32),
+                                      cols[rowptr[r0]:rowptr[r1]], vals[rowptr[r0]:rowptr[r1]], x, y0[sl])
+            assert err <= SCALED_TOL, (strat, r0, r1, err)
+            spmv_acc_amd.release_plans(drp[r0:])
