@@ -951,6 +951,10 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   }
   apply_env_tunables();
   if (m <= 0) return;
+  if (m > INT_MAX - (1 << 16)) { // row arithmetic in the kernels is int32 with a workgroup's worth of slack, like nnz
+    set_error(kErrTooLarge, "row count does not leave room for block arithmetic in int32; shard the matrix");
+    return;
+  }
   if (!d_rowptr || !dy || (n > 0 && !dx)) {
     set_error(kErrBadArgument, "null rowptr / x / y");
     return;
