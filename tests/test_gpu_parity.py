@@ -1055,3 +1055,43 @@ def test_row_shard_without_rebasing(torch_dev, oracle):
                                       cols[rowptr[r0]:rowptr[r1]], vals[rowptr[r0]:rowptr[r1]], x, y0[sl])
             assert err <= SCALED_TOL, (strat, r0, r1, err)
             spmv_acc_amd.release_plans(drp[r0:])
+
+
+def test_billion_rows(torch_dev):
+    """Row-count extreme: 1,000,000,000 rows with one non-zero each (plus two long rows), columns a fixed stride walk; y has a
+    closed form.  Exercises the int32 row arithmetic of every kernel family a long way past 2^29."""
+    torch = torch_dev
+    m = 1_000_000_000
+    n = 1 << 20
+    rp = torch.arange(m + 1, dtype=torch.int32, device="cuda")           # one non-zero per row ...
+    extra = 5000
+    rp[m // 2 + 1:] += extra                                             # ... except row m/2: 5001 non-zeros
+    nnz = m + extra
+    idx = torch.arange(nnz, dtype=torch.int64, device="cuda")
+    ci = ((idx * 7919) % n).to(torch.int32)
+    v = torch.ones(nnz, dtype=torch.float64, device="cuda")
+    del idx
+    x = torch.arange(n, dtype=torch.float64, device="cuda") % 13.0 - 6.0
+    def expected(rows):  # rows: int64 tensor of row ids (not m/2)
+        j = torch.where(rows > m // 2, rows + extra, rows)
+        return 2.0 * x[(j * 7919) % n] + 1.0
+    probe = torch.tensor([0, 1, 12345, m // 2 - 1, m // 2 + 1, m - 2, m - 1], dtype=torch.int64, device="cuda")
+    big = torch.arange(m // 2, m // 2 + extra + 1, dtype=torch.int64, device="cuda")
+    want_big = 2.0 * float(x[(big * 7919) % n].sum().item()) + 1.0
+    for strat in ("adaptive", "line_enhance", "flat", "adaptive_plus", "vector_row"):
+        y = torch.ones(m, dtype=torch.float64, device="cuda")
+        spmv_acc_amd.csr_spmv(2.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
+        torch.cuda.synchronize()
+        assert torch.equal(y[probe], expected(probe)), strat
+        assert abs(float(y[m // 2].item()) - want_big) <= 1e-9 * abs(want_big) + 1e-9, strat
+        # whole-vector check in chunks (exact: one product per row)
+        for a in range(0, m, 1 << 28):
+            b = min(m, a + (1 << 28))
+            rows = torch.arange(a, b, dtype=torch.int64, device="cuda")
+            ok = y[a:b] == expected(rows)
+            if a <= m // 2 < b:
+                ok[m // 2 - a] = True
+            assert bool(ok.all().item()), (strat, a)
+            del rows, ok
+        del y
+    spmv_acc_amd.release_plans(rp)
