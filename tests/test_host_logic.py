@@ -185,3 +185,14 @@ def test_env_tunables_seed_defaults():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-1000:]
     assert r.stdout.split() == ["1", "0", "16", "1"], r.stdout
+
+
+def test_c_header_is_plain_c(tmp_path):
+    """include/spmv_acc.h is the FFI surface: it must compile as C99 (and C++11) with nothing but the standard headers, and
+    every prototype it declares must link against the library (the loader test checks the symbols, this one the declarations)."""
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "spmv_acc.h"\n'
+                   'int main(void) { int out[9]; (void)out; return spmv_acc_break_points_len(4096, 1024) == 5 ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99"], ["g++", "-std=c++11", "-x", "c++"]):
+        subprocess.run(cmd + ["-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], check=True)
