@@ -66,26 +66,19 @@ __device__ __forceinline__ double group_sum_dyn(double v, int w) {
 // values / colindex are read exactly once per SpMV, 16 B per lane.  Whether they should be non-temporal is a
 // per-matrix question on MI355X (measured, kernels.hpp kStreamPolicy*): the templated forms below let the tile
 // kernels carry both and the engine picks by timing.  The untemplated forms (non-temporal) serve the scalar paths.
-__device__ __forceinline__ int4v load_stream_i4(const int *p) {
-  return __builtin_nontemporal_load(reinterpret_cast<const int4v *>(p));
-}
-__device__ __forceinline__ double2v load_stream_d2(const double *p) {
-  return __builtin_nontemporal_load(reinterpret_cast<const double2v *>(p));
-}
 __device__ __forceinline__ int load_stream(const int *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ double load_stream(const double *p) { return __builtin_nontemporal_load(p); }
 // NT = false: default cache policy, for matrices small enough to stay in the 256 MB Infinity Cache between SpMVs.
-// A16 = false: the base pointer is only element-aligned (a sub-array view: colindex 4-byte, values 8-byte aligned).  gfx950
-// runs global memory in unaligned-access mode, so the same global_load_dwordx4 (with the same cache policy) is issued through an under-aligned vector
-// type (hipcc keeps it one instruction); it costs a second cache-line access where 16 bytes straddle two lines, nothing else.
+// The vector types are UNDER-aligned on purpose (colindex 4-byte, values 8-byte: the elements' own alignment): gfx950 runs
+// global memory in unaligned-access mode, hipcc still emits ONE global_load_dwordx4 with the chosen cache policy, and the same
+// kernels serve fresh allocations and sub-array views (a row shard cut out of a larger CSR) at the same speed -- a load whose
+// 16 bytes straddle two cache lines costs a second line access, nothing else.
 typedef int4v int4v_a4 __attribute__((aligned(4)));
 typedef double2v double2v_a8 __attribute__((aligned(8)));
-template <bool NT, bool A16 = true> __device__ __forceinline__ int4v load_stream_i4(const int *p) {
-  if (A16) return NT ? __builtin_nontemporal_load(reinterpret_cast<const int4v *>(p)) : *reinterpret_cast<const int4v *>(p);
+template <bool NT> __device__ __forceinline__ int4v load_stream_i4(const int *p) {
   return NT ? __builtin_nontemporal_load(reinterpret_cast<const int4v_a4 *>(p)) : *reinterpret_cast<const int4v_a4 *>(p);
 }
-template <bool NT, bool A16 = true> __device__ __forceinline__ double2v load_stream_d2(const double *p) {
-  if (A16) return NT ? __builtin_nontemporal_load(reinterpret_cast<const double2v *>(p)) : *reinterpret_cast<const double2v *>(p);
+template <bool NT> __device__ __forceinline__ double2v load_stream_d2(const double *p) {
   return NT ? __builtin_nontemporal_load(reinterpret_cast<const double2v_a8 *>(p)) : *reinterpret_cast<const double2v_a8 *>(p);
 }
 

@@ -57,7 +57,7 @@ __device__ __forceinline__ int tile_end_excl(const int *__restrict__ rp, const i
   return (e < m && rp[e] < t1) ? e + 1 : e;
 }
 
-template <int NPT, bool ALIGNED, bool NTC, bool NTV>
+template <int NPT, bool NTC, bool NTV>
 __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int ntiles, double alpha, double beta,
                                                              const int *__restrict__ rp, const int *__restrict__ bp,
                                                              const int *__restrict__ ci,
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
   double y_old0 = 0.0;
   if (early_y && live0 && lane == 0) y_old0 = y[first + vec_id]; // read for cut rows too (<= 2 per tile): harmless
 
-  stage_products<kThreads, NPT, ALIGNED, NTC, NTV>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
+  stage_products<kThreads, NPT, NTC, NTV>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
 
   __syncthreads();
 
@@ -231,10 +231,10 @@ void launch_break_points(hipStream_t stream, const int *rp, int m, int nnz, int 
 }
 
 namespace {
-template <int NPT, bool ALIGNED, bool NTC, bool NTV>
+template <int NPT, bool NTC, bool NTV>
 void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                          double *y) {
-  hipLaunchKernelGGL((flat_tile_kernel<NPT, ALIGNED, NTC, NTV>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
+  hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                      P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
                      P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish);
 }
@@ -250,17 +250,16 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
                  double *y) {
   if (P.ntiles <= 0) return;
   const int npt = P.stride / kThreads;
-  // ALIGNED = false everywhere: under-aligned vector loads serve every base-pointer alignment (device_utils.hpp)
   if (npt == 4) {
-    launch_flat_variant<4, false, true, true>(stream, A, P, alpha, beta, x, y);
+    launch_flat_variant<4, true, true>(stream, A, P, alpha, beta, x, y);
   } else if (npt == 16) {
-    launch_flat_variant<16, false, true, true>(stream, A, P, alpha, beta, x, y);
+    launch_flat_variant<16, true, true>(stream, A, P, alpha, beta, x, y);
   } else {
     switch (P.stream_policy & 3) { // cache policy of the stream loads, see kernels.hpp
-    case 1: launch_flat_variant<8, false, false, false>(stream, A, P, alpha, beta, x, y); break;
-    case 2: launch_flat_variant<8, false, false, true>(stream, A, P, alpha, beta, x, y); break;
-    case 3: launch_flat_variant<8, false, true, false>(stream, A, P, alpha, beta, x, y); break;
-    default: launch_flat_variant<8, false, true, true>(stream, A, P, alpha, beta, x, y); break;
+    case 1: launch_flat_variant<8, false, false>(stream, A, P, alpha, beta, x, y); break;
+    case 2: launch_flat_variant<8, false, true>(stream, A, P, alpha, beta, x, y); break;
+    case 3: launch_flat_variant<8, true, false>(stream, A, P, alpha, beta, x, y); break;
+    default: launch_flat_variant<8, true, true>(stream, A, P, alpha, beta, x, y); break;
     }
   }
   if (P.ntiles > 1 && P.needs_fixup) {

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void plus_digest_kernel(int m, int nblocks, in
   blk[g] = rec;
 }
 
-template <bool ALIGNED, bool NTC, bool NTV>
+template <bool NTC, bool NTV>
 __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, int xcd_chunk, double alpha, double beta,
                                                         const int4v *__restrict__ blk, const int *__restrict__ rp,
                                                         const int *__restrict__ ci, const double *__restrict__ v,
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
     }
     double acc = 0.0;
     for (int off = a0; off < s1; off += kPlusTile) {
-      stage_products<kThreads, kPlusNpt, ALIGNED, NTC, NTV>(lds, off, s1, nnz, ci, v, x);
+      stage_products<kThreads, kPlusNpt, NTC, NTV>(lds, off, s1, nnz, ci, v, x);
       __syncthreads();
       const int lo = (r0 > off ? r0 : off) - off;
       const int hi = (r1 < off + kPlusTile ? r1 : off + kPlusTile) - off;
@@ -121,9 +121,9 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
       // at 4.9 TB/s against 6.0-6.4 for the tile kernels.)
       for (int base = (j0 & ~3) + 4 * static_cast<int>(threadIdx.x); base < j1; base += 4 * kThreads) {
         if (base + 4 <= nnz) {
-          const int4v c = load_stream_i4<NTC, ALIGNED>(ci + base);
-          const double2v a0 = load_stream_d2<NTV, ALIGNED>(v + base);
-          const double2v a1 = load_stream_d2<NTV, ALIGNED>(v + base + 2);
+          const int4v c = load_stream_i4<NTC>(ci + base);
+          const double2v a0 = load_stream_d2<NTV>(v + base);
+          const double2v a1 = load_stream_d2<NTV>(v + base + 2);
           const double p0 = a0.x * x[c.x], p1 = a0.y * x[c.y], p2 = a1.x * x[c.z], p3 = a1.y * x[c.w];
           s += (base + 0 >= j0 && base + 0 < j1) ? p0 : 0.0;
           s += (base + 1 >= j0 && base + 1 < j1) ? p1 : 0.0;
@@ -178,14 +178,14 @@ void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *
                  bool has_long_rows, int xcd_chunk, int stream_policy, double *partial, double alpha, double beta,
                  const double *x, double *y) {
   if (nblocks <= 0) return;
-#define SPMV_ACC_LAUNCH_PLUS(AL, NC, NV)                                                                                \
-  hipLaunchKernelGGL((plus_kernel<AL, NC, NV>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk,   \
+#define SPMV_ACC_LAUNCH_PLUS(NC, NV)                                                                                \
+  hipLaunchKernelGGL((plus_kernel<NC, NV>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk,   \
                      alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial)
-  switch (stream_policy & 3) { // ALIGNED = false: under-aligned vector loads serve every base-pointer alignment
-  case 1: SPMV_ACC_LAUNCH_PLUS(false, false, false); break;
-  case 2: SPMV_ACC_LAUNCH_PLUS(false, false, true); break;
-  case 3: SPMV_ACC_LAUNCH_PLUS(false, true, false); break;
-  default: SPMV_ACC_LAUNCH_PLUS(false, true, true); break;
+  switch (stream_policy & 3) {
+  case 1: SPMV_ACC_LAUNCH_PLUS(false, false); break;
+  case 2: SPMV_ACC_LAUNCH_PLUS(false, true); break;
+  case 3: SPMV_ACC_LAUNCH_PLUS(true, false); break;
+  default: SPMV_ACC_LAUNCH_PLUS(true, true); break;
   }
 #undef SPMV_ACC_LAUNCH_PLUS
   if (has_long_rows) {

@@ -25,7 +25,7 @@ namespace {
 
 using namespace dev;
 
-template <int VEC, bool ALIGNED, bool NTC, bool NTV>
+template <int VEC, bool NTC, bool NTV>
 __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nnz, int nblocks, int rpb, int flags,
                                                                    double alpha, double beta,
                                                                    const int *__restrict__ rp,
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   double acc = 0.0;
   // tile origin aligned down so 16-B loads stay aligned; the (at most 3) extra leading products are never read
   for (int off = s0 & ~3; off < s1; off += kTile) {
-    stage_products<kThreads, kNnzPerThread, ALIGNED, NTC, NTV>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0);
+    stage_products<kThreads, kNnzPerThread, NTC, NTV>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0);
     __syncthreads();
     const int lo = (r0 > off ? r0 : off) - off;
     const int hi = (r1 < off + kTile ? r1 : off + kTile) - off;
@@ -120,16 +120,16 @@ void launch_vec(hipStream_t stream, const CsrDev &A, int rpb, int xcd, double al
   const int remap = ((xcd & 1) && nblocks >= 64 ? 1 : 0) | (xcd & ~1);
   // bits 4-5 of the flags: cache policy of the stream loads (0 nt/nt, 1 plain/plain, 2 colindex plain + values nt,
   // 3 colindex nt + values plain)
-#define SPMV_ACC_LAUNCH_RB(AL, NC, NV)                                                                                  \
-  hipLaunchKernelGGL((rowblock_stream_kernel<VEC, AL, NC, NV>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,  \
+#define SPMV_ACC_LAUNCH_RB(NC, NV)                                                                                  \
+  hipLaunchKernelGGL((rowblock_stream_kernel<VEC, NC, NV>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,  \
                      nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y)
   // one set of kernels for every base-pointer alignment: their 16-B loads go through under-aligned vector types
   // (device_utils.hpp), the same instruction with the same cache policy whether or not the caller's arrays are 16-B aligned
   switch ((xcd >> 4) & 3) {
-  case 1: SPMV_ACC_LAUNCH_RB(false, false, false); break;
-  case 2: SPMV_ACC_LAUNCH_RB(false, false, true); break;
-  case 3: SPMV_ACC_LAUNCH_RB(false, true, false); break;
-  default: SPMV_ACC_LAUNCH_RB(false, true, true); break;
+  case 1: SPMV_ACC_LAUNCH_RB(false, false); break;
+  case 2: SPMV_ACC_LAUNCH_RB(false, true); break;
+  case 3: SPMV_ACC_LAUNCH_RB(true, false); break;
+  default: SPMV_ACC_LAUNCH_RB(true, true); break;
   }
 #undef SPMV_ACC_LAUNCH_RB
 }

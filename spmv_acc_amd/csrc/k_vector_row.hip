@@ -110,7 +110,6 @@ __global__ __launch_bounds__(kThreads) void vector_row_kernel(int m, int row_spl
 // consecutive non-zeros per step (one 16-B colindex load, two 16-B value loads) and two steps are in flight, so a
 // wave keeps 512 non-zeros = 6 KB of stream + 512 gathers outstanding; the row start is aligned down to a multiple
 // of 4 and the (at most 3 + 3) foreign elements at the row's ends are masked out of the sum.
-template <bool ALIGNED>
 __global__ __launch_bounds__(kThreads) void wave_row_kernel(int m, int nnz, double alpha, double beta,
                                                             const int *__restrict__ rp, const int *__restrict__ ci,
                                                             const double *__restrict__ v,
@@ -131,14 +130,14 @@ __global__ __launch_bounds__(kThreads) void wave_row_kernel(int m, int nnz, doub
         int4v ca, cb;
         double2v a0, a1, b0, b1;
         if (fa) {
-          ca = load_stream_i4<true, ALIGNED>(ci + ia);
-          a0 = load_stream_d2<true, ALIGNED>(v + ia);
-          a1 = load_stream_d2<true, ALIGNED>(v + ia + 2);
+          ca = load_stream_i4<true>(ci + ia);
+          a0 = load_stream_d2<true>(v + ia);
+          a1 = load_stream_d2<true>(v + ia + 2);
         }
         if (fb) {
-          cb = load_stream_i4<true, ALIGNED>(ci + ib);
-          b0 = load_stream_d2<true, ALIGNED>(v + ib);
-          b1 = load_stream_d2<true, ALIGNED>(v + ib + 2);
+          cb = load_stream_i4<true>(ci + ib);
+          b0 = load_stream_d2<true>(v + ib);
+          b1 = load_stream_d2<true>(v + ib + 2);
         }
         if (fa) {
           const double p0 = a0.x * x[ca.x], p1 = a0.y * x[ca.y], p2 = a1.x * x[ca.z], p3 = a1.y * x[ca.w];
@@ -240,7 +239,7 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
 void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y) {
   if (A.m <= 0) return;
   const int grid = ceil_div_ll(A.m, kThreads / kWave);
-  hipLaunchKernelGGL((wave_row_kernel<false>), dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci, A.v,
+  hipLaunchKernelGGL(wave_row_kernel, dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci, A.v,
                      x, y);
 }
 

@@ -15,12 +15,12 @@ namespace spmv_acc {
 namespace dev {
 
 // Stage products of non-zeros [a0, a0 + THREADS*NPT) that lie below `hi` into lds[0 .. THREADS*NPT).
-//   a0  : first non-zero of the tile, multiple of 4 (so 16-B loads are aligned when ALIGNED)
+//   a0  : first non-zero of the tile, multiple of 4 (16-B loads of a 16-B-aligned array are then aligned too)
 //   hi  : exclusive bound of the non-zeros this block needs (hi <= nnz); groups at or above it are skipped
 //   nnz : total non-zeros (array length) -- only the last, ragged group of the arrays takes the scalar path
 // Slots of lds whose non-zero index is < a-block's-first-nnz or >= hi hold unspecified values; no
 // reader touches them.
-template <int THREADS, int NPT, bool ALIGNED, bool NTC = true, bool NTV = true>
+template <int THREADS, int NPT, bool NTC = true, bool NTV = true>
 __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0, int hi, int nnz,
                                                const int *__restrict__ ci, const double *__restrict__ v,
                                                const double *__restrict__ x, bool allow_fast = true) {
@@ -45,9 +45,9 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
       if (wave_has[k]) {
         const int j = a0 + 4 * (threadIdx.x + k * THREADS);
         const int jc = (j < hi) ? j : a0; // lanes past hi in the boundary wave re-read the tile's first group (L1 hit)
-        c[k] = load_stream_i4<NTC, ALIGNED>(ci + jc);
-        va[k] = load_stream_d2<NTV, ALIGNED>(v + jc);
-        vb[k] = load_stream_d2<NTV, ALIGNED>(v + jc + 2);
+        c[k] = load_stream_i4<NTC>(ci + jc);
+        va[k] = load_stream_d2<NTV>(v + jc);
+        vb[k] = load_stream_d2<NTV>(v + jc + 2);
       }
     }
     double xg[K][4];
@@ -85,9 +85,9 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
       const int j = a0 + 4 * (threadIdx.x + k * THREADS);
       full[k] = (j < hi) && (j + 4 <= nnz);
       if (full[k]) {
-        c[k] = load_stream_i4<NTC, ALIGNED>(ci + j);
-        va[k] = load_stream_d2<NTV, ALIGNED>(v + j);
-        vb[k] = load_stream_d2<NTV, ALIGNED>(v + j + 2);
+        c[k] = load_stream_i4<NTC>(ci + j);
+        va[k] = load_stream_d2<NTV>(v + j);
+        vb[k] = load_stream_d2<NTV>(v + j + 2);
       }
     }
     double xg[K][4];
