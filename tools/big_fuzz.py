@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Large randomised parity run on the GPU (matrices of up to ~150 M non-zeros, far beyond what the CPU oracle checks in seconds): random
+row-length laws x column laws x sizes through every kernel family, against an independent fp64 evaluation on the device
+(index_add of the products, a different summation order), error scaled by sum_j |a_ij x_j| + |beta y0_i|.
+    python tools/big_fuzz.py [cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import spmv_acc_amd
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+g = torch.Generator(device="cuda"); g.manual_seed(int(rng.integers(1 << 30)))
+worst = 0.0
+for case in range(cases):
+    m = int(10 ** rng.uniform(3, 6.7))
+    mean = float(rng.choice([1.5, 4, 12, 40, 300, 4000]))
+    law = rng.choice(["lognormal", "spikes", "stripes", "empty"])
+    m = max(16, min(m, int(1.5e8 / mean)))
+    if law == "lognormal":
+        sigma = float(rng.uniform(0, 2.0))
+        lens = torch.exp(torch.randn(m, generator=g, device="cuda") * sigma + (np.log(mean) - sigma * sigma / 2)).long()
+    elif law == "spikes":
+        lens = torch.randint(0, int(2 * mean) + 1, (m,), generator=g, device="cuda")
+        k = int(rng.integers(1, max(2, m // 200)))
+        lens[torch.randint(0, m, (k,), generator=g, device="cuda")] = int(rng.choice([64, 65, 300, 2047, 2048, 2049, 5000, 40000]))
+    elif law == "stripes":
+        stripe = int(rng.choice([7, 64, 300, 5000]))
+        dense = ((torch.arange(m, device="cuda") // stripe) % 2) == 0
+        lens = torch.where(dense, torch.randint(0, int(3 * mean) + 1, (m,), generator=g, device="cuda"),
+                           torch.randint(0, int(mean) + 1, (m,), generator=g, device="cuda"))
+    else:
+        lens = torch.randint(0, int(2 * mean) + 1, (m,), generator=g, device="cuda")
+        lens[torch.rand(m, generator=g, device="cuda") < float(rng.uniform(0.3, 0.99))] = 0
+    total = int(lens.sum().item())
+    if total > 160_000_000:
+        lens = (lens.double() * (1.5e8 / total)).long()
+    rp = torch.zeros(m + 1, dtype=torch.int64, device="cuda"); torch.cumsum(lens, 0, out=rp[1:])
+    nnz = int(rp[-1].item())
+    n = int(rng.choice([m, max(1, m // 7), 3 * m + 5, 1000]))
+    rows = torch.repeat_interleave(torch.arange(m, device="cuda"), lens, output_size=nnz)
+    cols_law = rng.choice(["near", "clusters", "uniform"])
+    if cols_law == "uniform":
+        ci = torch.randint(0, n, (nnz,), generator=g, device="cuda")
+    else:
+        ci = (rows * n // max(m, 1)) + torch.randint(-40, 41, (nnz,), generator=g, device="cuda")
+        if cols_law == "clusters":
+            ci = ci + torch.randint(0, 3, (nnz,), generator=g, device="cuda") * (n // 3)
+        ci = ci % n
+    ci = ci.to(torch.int32)
+    v = torch.rand(nnz, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    x = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    y0 = torch.rand(m, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    alpha, beta = [(1.0, 1.0), (0.5, -2.0), (1.0, 0.0), (-1.25, 0.5)][case % 4]
+    prod = v * x[ci.long()]
+    ref = (beta * y0).index_add_(0, rows, alpha * prod)
+    scale = (abs(beta) * y0.abs()).index_add_(0, rows, abs(alpha) * prod.abs()) + 1e-300
+    del prod, rows
+    rp32 = rp.to(torch.int32)
+    line = f"case {case:3d}: m={m} n={n} nnz={nnz} law={law} cols={cols_law} mean={mean} a/b={alpha}/{beta}"
+    for strat in ("adaptive", "line_enhance", "flat", "adaptive_plus", "default", "vector_row"):
+        y = y0.clone()
+        spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, rp32, ci, v, x, y, strategy=strat)
+        torch.cuda.synchronize()
+        err = float(((y - ref).abs() / scale).max().item()) if m else 0.0
+        worst = max(worst, err)
+        if not err <= 1e-12:
+            print(line); print("   FAIL", strat, err); sys.exit(1)
+    fam = spmv_acc_amd.query_plan(rp32, m)["adaptive_family"]
+    print(line, f"-> ok (adaptive family {fam})", flush=True)
+    spmv_acc_amd.release_plans(rp32)
+    del rp, rp32, ci, v, x, y0, ref, scale, lens
+    torch.cuda.empty_cache()
+print(f"all {cases} cases within 1e-12 scaled error (worst {worst:.2e})")
