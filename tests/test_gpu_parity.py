@@ -1095,3 +1095,40 @@ def test_billion_rows(torch_dev):
             del rows, ok
         del y
     spmv_acc_amd.release_plans(rp)
+
+
+def test_against_rocsparse_as_second_opinion(torch_dev):
+    """The reference's optional device-side verifier compares against rocSPARSE instead of the CPU loop (cli/verification.cpp:81-112,
+    DEVICE_SIDE_VERIFY).  Same here, as a second, independent implementation: rocsparse_dcsrmv (the librocsparse bundled with torch)
+    on a 400 K-row power-law matrix against every hot strategy.  Comparison only -- the product never links rocSPARSE."""
+    import sys
+
+    torch = torch_dev
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from rocsparse_row import RocsparseCsrmv
+        roc = RocsparseCsrmv()
+    except (OSError, AssertionError) as ex:
+        pytest.skip(f"librocsparse not loadable: {ex}")
+    import ctypes
+
+    m, n, nnz, rp, ci, v = synth.rmat_torch(17, device="cuda", seed=0xC4)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    x = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    y0 = torch.rand(m, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    alpha, beta = ctypes.c_double(0.75), ctypes.c_double(-1.5)
+    y_roc = y0.clone()
+    rc = roc.lib.rocsparse_dcsrmv(roc.handle, 111, m, n, nnz, ctypes.addressof(alpha), roc.descr, v.data_ptr(), rp.data_ptr(),
+                                  ci.data_ptr(), None, x.data_ptr(), ctypes.addressof(beta), y_roc.data_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0
+    rows = torch.repeat_interleave(torch.arange(m, device="cuda"), (rp[1:] - rp[:-1]).long(), output_size=nnz)
+    scale = (1.5 * y0.abs()).index_add_(0, rows, 0.75 * (v * x[ci.long()]).abs()) + 1e-300
+    for strat in spmv_acc_amd.HOT_STRATEGIES:
+        y = y0.clone()
+        spmv_acc_amd.csr_spmv(0.75, -1.5, m, n, nnz, rp, ci, v, x, y, strategy=strat)
+        torch.cuda.synchronize()
+        err = float(((y - y_roc).abs() / scale).max().item())
+        assert err <= SCALED_TOL, (strat, err)
+    spmv_acc_amd.release_plans(rp)
