@@ -196,3 +196,13 @@ def test_c_header_is_plain_c(tmp_path):
     inc = os.path.join(ROOT, "include")
     for cmd in (["gcc", "-std=c99"], ["g++", "-std=c++11", "-x", "c++"]):
         subprocess.run(cmd + ["-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], check=True)
+
+
+def test_library_links_only_the_hip_runtime(hiplib):
+    """north_star: 'not a wrapper over rocSPARSE'.  The shared library's NEEDED entries are the HIP runtime and the C/C++
+    runtimes, nothing else (rocPRIM, used by the device-side row-block analysis, is header-only)."""
+    lib = os.path.join(ROOT, "spmv_acc_amd", "lib", "libspmv_acc.so")
+    out = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True, check=True).stdout
+    needed = re.findall(r"NEEDED\)\s+Shared library: \[([^\]]+)\]", out)
+    allowed = ("libamdhip64", "libstdc++", "libm.", "libgcc_s", "libc.", "ld-linux", "libdl", "libpthread", "librt")
+    assert needed and all(n.startswith(allowed) for n in needed), needed
