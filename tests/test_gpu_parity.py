@@ -1132,3 +1132,38 @@ def test_against_rocsparse_as_second_opinion(torch_dev):
         err = float(((y - y_roc).abs() / scale).max().item())
         assert err <= SCALED_TOL, (strat, err)
     spmv_acc_amd.release_plans(rp)
+
+
+def test_benchmark_flat_copy_surface(torch_dev, oracle, tmp_path):
+    """The reference benchmark keeps a private copy of flat (benchmark/flat/spmv_acc_flat.cpp) that launches the break-point
+    kernels itself and expands the FLAT_KERNEL*_WRAPPER macros.  tests/cxx/bench_flat_driver.cpp does the same against
+    include/hip-flat/ + include/common/macros.h: both break-point tables must equal the oracle's restatements bit for bit (with
+    empty rows, where v1 and v2 differ) and every wrapper's y must match the oracle."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    exe = str(tmp_path / "bench_flat_driver")
+    libdir = os.path.dirname(spmv_acc_amd.LIB_PATH)
+    subprocess.run([hipcc, "-O2", "-std=c++14", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cxx", "bench_flat_driver.cpp"), "-L", libdir, "-lspmv_acc",
+                    f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    for kind, m, avg, seed in (("powerlaw", 6000, 9, 5), ("empty_rows", 5000, 6, 6), ("dense_rows", 60, 700, 7)):
+        rowptr, cols, vals = synth.random_csr(m, m, avg, seed=seed, kind=kind)
+        nnz = int(rowptr[-1])
+        rng = np.random.default_rng(seed)
+        x, y0 = rng.standard_normal(m), rng.standard_normal(m)
+        inp, outp = str(tmp_path / f"in_{kind}.bin"), str(tmp_path / f"out_{kind}.bin")
+        with open(inp, "wb") as f:
+            np.array([m, m, nnz], dtype=np.int32).tofile(f)
+            for a in (rowptr, cols, vals, x, y0):
+                a.tofile(f)
+        subprocess.run([exe, inp, outp], check=True)
+        raw = open(outp, "rb").read()
+        blen = int(np.frombuffer(raw, dtype=np.int32, count=1)[0])
+        assert blen == -(-nnz // 1024) + 1
+        t1 = np.frombuffer(raw, dtype=np.int32, count=blen, offset=4)
+        t2 = np.frombuffer(raw, dtype=np.int32, count=blen, offset=4 + 4 * blen)
+        ys = np.frombuffer(raw, dtype=np.float64, offset=4 + 8 * blen).reshape(3, m)
+        want1, want2 = oracle.break_points(rowptr, 1024), oracle.break_points(rowptr, 1024, v2=True)
+        assert want1.size == blen and np.array_equal(t1, want1), kind
+        assert np.array_equal(t2, want2), kind
+        for k, y in enumerate(ys):
+            check(oracle, y, 1.0, 1.0, rowptr, cols, vals, x, y0, ("bench-flat", kind, k))
