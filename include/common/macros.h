@@ -1,14 +1,6 @@
-// common/macros.h -- at the reference's include path (src/acc/common/macros.h): unpacks a csr_desc into the local names
-// its flat sources use (m, rowptr, colindex, value).
-#ifndef SPMV_ACC_AMD_COMMON_MACROS_H
-#define SPMV_ACC_AMD_COMMON_MACROS_H
-
-#include "../api/types.h"
-
-#define VAR_FROM_CSR_DESC(d)                                                                                           \
-  const int m = (d).rows;                                                                                              \
-  const int *rowptr = (d).row_ptr;                                                                                     \
-  const int *colindex = (d).col_index;                                                                                 \
-  const double *value = (d).values;
-
+// Forwarding header at the reference's include path src/acc/common/macros.h.  VAR_FROM_CSR_DESC -- the four locals (m, rowptr,
+// colindex, value) the reference's flat sources pull out of a csr_desc -- is defined with the other flat compatibility pieces.
+#ifndef SPMV_ACC_AMD_FWD_COMMON_MACROS_H
+#define SPMV_ACC_AMD_FWD_COMMON_MACROS_H
+#include "../hip-flat/flat_locals.hpp"
 #endif
