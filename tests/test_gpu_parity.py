@@ -1167,3 +1167,32 @@ def test_benchmark_flat_copy_surface(torch_dev, oracle, tmp_path):
         assert np.array_equal(t2, want2), kind
         for k, y in enumerate(ys):
             check(oracle, y, 1.0, 1.0, rowptr, cols, vals, x, y0, ("bench-flat", kind, k))
+
+
+def test_nan_stays_in_its_row(torch_dev, oracle):
+    """A NaN (or Inf) in one matrix value must reach exactly the rows that hold it: the kernels load whole 16-byte groups and
+    staged tiles that contain neighbouring rows' elements, and mask or ignore the foreign ones rather than multiply them by zero.
+    Also beta = 0 must not read y (BLAS convention): a y full of NaN comes back finite."""
+    torch = torch_dev
+    rng = np.random.default_rng(77)
+    lens = rng.integers(1, 9, 20000)
+    lens[[100, 5000, 5001, 19999]] = [700, 3000, 1, 2500]       # long rows next to short ones (slices, cooperative sums)
+    rowptr, cols, vals = synth.csr_from_row_lengths(lens, 20000, rng)
+    nnz = int(rowptr[-1])
+    x = rng.standard_normal(20000)
+    poisoned = {99: np.nan, 100: np.inf, 101: np.nan, 5000: np.nan, 5001: -np.inf, 12345: np.nan, 19999: np.nan, 0: np.nan}
+    vals = vals.copy()
+    for r, bad in poisoned.items():
+        j = rowptr[r] + (rowptr[r + 1] - rowptr[r]) // 2   # some element inside the row
+        vals[j] = bad
+        x[cols[j]] = 1.0                                    # keep inf * x from turning into NaN by accident of sign only
+    y_nan = np.full(20000, np.nan)
+    clean = np.ones(20000, dtype=bool)
+    clean[list(poisoned)] = False
+    for strat in ALL:
+        got = run(torch, strat, 1.0, 0.0, rowptr, cols, vals, x, y_nan)
+        assert np.all(np.isfinite(got[clean])), (strat, np.nonzero(~np.isfinite(got) & clean)[0][:5])
+        assert not np.any(np.isfinite(got[~clean])), strat
+    ref = oracle.host_spmv(1.0, 0.0, rowptr, cols, np.where(np.isfinite(vals), vals, 0.0), x, np.zeros(20000))
+    got = run(torch, "adaptive", 1.0, 0.0, rowptr, cols, vals, x, y_nan)
+    assert np.allclose(got[clean], ref[clean], rtol=1e-12, atol=1e-12)
