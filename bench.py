@@ -295,6 +295,9 @@ def main():
         "gflops_kernel_only_per_gpu": round(2.0 * nnz / (ev_ms * 1e-3) / 1e9, 3),
     }
     result.update(out_extra)
+    info = spmv_acc_amd.query_plan(W["rp"], m) if args.exchange != "ghost" else None
+    if info:  # what the first call measured and kept for this matrix (kernel family: 0 fixed row blocks, 1 row-block-plus, 2 flat)
+        result["plan"] = {k: info[k] for k in ("stream_policy", "adaptive_family", "flat_fixup", "plus_blocks", "flat_tiles")}
     if rank == 0:
         result["copy_ceiling_gbs"] = round(copy_ceiling_gbs(torch, device), 1)
     if rank == 0 and world == 1 and args.workload == "hardesty3" and args.scale == 1.0 and not args.no_sensitivity:
