@@ -206,3 +206,20 @@ def test_library_links_only_the_hip_runtime(hiplib):
     needed = re.findall(r"NEEDED\)\s+Shared library: \[([^\]]+)\]", out)
     allowed = ("libamdhip64", "libstdc++", "libm.", "libgcc_s", "libc.", "ld-linux", "libdl", "libpthread", "librt")
     assert needed and all(n.startswith(allowed) for n in needed), needed
+
+
+def test_cmake_build_exports_the_same_symbols(tmp_path):
+    """The top-level CMakeLists.txt (for consumers that add_subdirectory() this repository, as the reference's CMake would) builds
+    target `spmv-acc-kernels` = libspmv_acc.so with the same exported C ABI as the Makefile build."""
+    import shutil
+
+    if not shutil.which("cmake") or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("cmake / hipcc not available")
+    gen = ["-G", "Ninja"] if shutil.which("ninja") else []
+    subprocess.run(["cmake", "-S", ROOT, "-B", str(tmp_path)] + gen + ["-DCMAKE_CXX_COMPILER=/opt/rocm/bin/hipcc",
+                   "-DCMAKE_BUILD_TYPE=Release", "-DKERNEL_STRATEGY=flat"], check=True, capture_output=True)
+    subprocess.run(["cmake", "--build", str(tmp_path), "-j", "8"], check=True, capture_output=True)
+    out = subprocess.run(["nm", "-D", "--defined-only", str(tmp_path / "libspmv_acc.so")], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    missing = [s for s in spmv_acc_amd.C_ABI_SYMBOLS if s not in exported]
+    assert not missing, missing
