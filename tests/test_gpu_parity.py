@@ -1196,3 +1196,45 @@ def test_nan_stays_in_its_row(torch_dev, oracle):
     ref = oracle.host_spmv(1.0, 0.0, rowptr, cols, np.where(np.isfinite(vals), vals, 0.0), x, np.zeros(20000))
     got = run(torch, "adaptive", 1.0, 0.0, rowptr, cols, vals, x, y_nan)
     assert np.allclose(got[clean], ref[clean], rtol=1e-12, atol=1e-12)
+
+
+def test_host_threads_on_different_matrices(torch_dev, oracle):
+    """host threads may call concurrently on DIFFERENT matrices (first calls included: plans are built and timed
+    under the cache's lock discipline, kernels share the library stream).  Six threads, six matrices, every hot strategy, 40 calls
+    each, all against the oracle."""
+    import threading
+
+    torch = torch_dev
+    problems = []
+    for t in range(6):
+        rowptr, cols, vals = synth.random_csr(6000 + 700 * t, 5000, 5 + 2 * t, seed=300 + t, kind=("powerlaw", "uniform", "short")[t % 3])
+        rng = np.random.default_rng(400 + t)
+        x, y0 = rng.standard_normal(5000), rng.standard_normal(rowptr.size - 1)
+        ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+        problems.append((rowptr, cols, vals, x, y0, ref, [dev(torch, a) for a in (rowptr, cols, vals, x, y0)]))
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(t):
+        rowptr, cols, vals, x, y0, ref, (drp, dci, dv, dx, dy0) = problems[t]
+        m, nnz = rowptr.size - 1, int(rowptr[-1])
+        try:
+            for it in range(40):
+                strat = spmv_acc_amd.HOT_STRATEGIES[(it + t) % len(spmv_acc_amd.HOT_STRATEGIES)]
+                dy = dy0.clone()
+                spmv_acc_amd.csr_spmv(1.0, 1.0, m, 5000, nnz, drp, dci, dv, dx, dy, strategy=strat)
+                torch.cuda.synchronize()
+                err = oracle.scaled_error(dy.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, vals, x, y0)
+                if not err <= SCALED_TOL:
+                    errors.append((t, it, strat, err))
+        except Exception as ex:  # noqa: BLE001
+            errors.append((t, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for p in problems:
+        spmv_acc_amd.release_plans(p[6][0])
+    assert not errors, errors[:5]
