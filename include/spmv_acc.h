@@ -157,7 +157,7 @@ void spmv_acc_set_stream(void *hip_stream); /* hipStream_t; NULL = the NULL stre
                                              * (plan: allocations, synchronisation, timings) must run outside a capture. */
 void *spmv_acc_get_stream(void);
 
-int spmv_acc_last_error(void); /* 0 = ok; see enum below */
+int spmv_acc_last_error(void); /* 0 = ok; see enum below.  Per host thread, like errno. */
 const char *spmv_acc_last_error_string(void);
 void spmv_acc_clear_error(void);
 enum spmv_acc_error {
