@@ -107,6 +107,30 @@ __device__ __forceinline__ int xcd_chunked_block(int b, int nblocks, int chunk) 
   return s * super + (r % kXcds) * chunk + r / kXcds;
 }
 
+// Sum src[k0 .. k1) per lane, for the fix-up kernels (one lane = one cut / sliced row, its carries contiguous in src).
+// Ranges of up to 64 entries are added by the lane itself in index order; a longer range -- a row of millions of non-zeros
+// cut into thousands of tiles or slices -- would be thousands of dependent loads in one lane (a 2 M-non-zero row: ~80 us),
+// so the wave takes such lanes one at a time (ballot order) and sums the range with all 64 lanes + the DPP butterfly.
+// Deterministic; every lane of the wave must call it (lanes without a row pass k0 == k1).
+__device__ __forceinline__ double wave_range_sum(const double *__restrict__ src, int k0, int k1) {
+  const bool giant = k1 - k0 > kWave;
+  double s = 0.0;
+  if (!giant)
+    for (int k = k0; k < k1; ++k) s += src[k];
+  unsigned long long todo = __ballot(giant);
+  const int lane = threadIdx.x & (kWave - 1);
+  while (todo) { // wave-uniform
+    const int owner = __ffsll(static_cast<long long>(todo)) - 1;
+    todo &= todo - 1;
+    const int a = __shfl(k0, owner, kWave), b = __shfl(k1, owner, kWave);
+    double part = 0.0;
+    for (int k = a + lane; k < b; k += kWave) part += src[k];
+    part = group_sum<64>(part);
+    if (lane == owner) s = part;
+  }
+  return s;
+}
+
 // y update with the documented semantics y = alpha*A*x + beta*y (api/spmv.h:14).  beta == 0 does
 // not read y (BLAS convention; for finite y it equals the reference's alpha*s + 0*y).
 __device__ __forceinline__ void store_y(double *y, int row, double alpha, double beta, double s) {

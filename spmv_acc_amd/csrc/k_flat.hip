@@ -210,16 +210,20 @@ __global__ __launch_bounds__(256) void flat_fixup_kernel(int ntiles, int stride,
                                                          const int *__restrict__ tail_row,
                                                          const int *__restrict__ tail_end, double *__restrict__ y) {
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= ntiles - 1) return; // the last tile cannot have a row that continues
-  const int r = tail_row[t];
-  if (r < 0) return;
-  const int b = tail_end[t];
-  double s = tail[t];
-  for (int k = t + 1; k < ntiles; ++k) {
-    s += head[k];
-    if (b <= static_cast<long long>(k + 1) * stride) break;
+  // no early return: every lane of a wave takes part in wave_range_sum
+  int r = -1;
+  if (t < ntiles - 1) r = tail_row[t]; // the last tile cannot have a row that continues
+  int k0 = 0, k1 = 0;
+  double s = 0.0;
+  if (r >= 0) {
+    const long long b = tail_end[t];
+    k0 = t + 1;                                            // heads of the tiles the row runs through:
+    k1 = static_cast<int>((b + stride - 1) / stride);      // ... up to the tile that holds its last non-zero
+    k1 = k1 < ntiles ? k1 : ntiles;
+    s = tail[t];
   }
-  store_y(y, r, alpha, beta, s);
+  s += wave_range_sum(head, k0, k1);
+  if (r >= 0) store_y(y, r, alpha, beta, s);
 }
 
 } // namespace

@@ -154,15 +154,27 @@ __global__ __launch_bounds__(256) void plus_fixup_kernel(int m, int nblocks, dou
                                                          const double *__restrict__ partial,
                                                          double *__restrict__ y) {
   const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= nblocks) return;
-  const int r = bp[g];
-  if (r >= m) return;
-  const int flag = fbr[r];
-  if ((flag & 1) == 0) return;
-  if (g != first_block_at_row(bp, flag, r)) return;
-  double s = 0.0;
-  for (int k = g; k < nblocks && bp[k] == r; ++k) s += partial[k];
-  store_y(y, r, alpha, beta, s);
+  // no early return: every lane of a wave takes part in wave_range_sum
+  int r = -1, k0 = 0, k1 = 0;
+  if (g < nblocks) {
+    const int row = bp[g];
+    if (row < m) {
+      const int flag = fbr[row];
+      if ((flag & 1) != 0 && g == first_block_at_row(bp, flag, row)) {
+        r = row;
+        // the row's slices are the blocks [g, e) with bp[.] == row; bp is non-decreasing: e by binary search
+        int lo = g + 1, hi = nblocks;
+        while (lo < hi) {
+          const int mid = lo + (hi - lo) / 2;
+          if (bp[mid] == row) lo = mid + 1; else hi = mid;
+        }
+        k0 = g;
+        k1 = lo;
+      }
+    }
+  }
+  const double s = wave_range_sum(partial, k0, k1);
+  if (r >= 0) store_y(y, r, alpha, beta, s);
 }
 
 } // namespace

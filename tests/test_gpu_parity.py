@@ -1238,3 +1238,47 @@ def test_host_threads_on_different_matrices(torch_dev, oracle):
     for p in problems:
         spmv_acc_amd.release_plans(p[6][0])
     assert not errors, errors[:5]
+
+
+def test_giant_rows(torch_dev):
+    """Rows of millions of non-zeros: flat cuts them into thousands of tiles, row-block-plus into thousands of slices, and the
+    fix-up kernels add those carries with the whole wave instead of one lane walking them (device_utils.hpp wave_range_sum).
+    Three rows of 3 M / 5 M / 70 non-zeros between ordinary rows; y against an fp64 index_add evaluation on the device."""
+    torch = torch_dev
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    m, n = 5000, 200000
+    lens = torch.randint(3, 12, (m,), generator=g, device="cuda")
+    lens[7], lens[2500], lens[2501], lens[4999] = 3_000_000, 5_000_000, 70, 2_200_000
+    rp = torch.zeros(m + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(lens, 0, out=rp[1:])
+    nnz = int(rp[-1].item())
+    ci = torch.randint(0, n, (nnz,), generator=g, device="cuda").to(torch.int32)
+    v = torch.rand(nnz, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    x = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    y0 = torch.rand(m, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    # reference on the host with numpy's pairwise row sums (a device index_add would serialise millions of fp64 atomics on
+    # three addresses); every row here has at least 3 non-zeros, so reduceat needs no empty-row handling
+    prod = (v * x[ci.long()]).cpu().numpy()
+    starts = rp[:-1].cpu().numpy()
+    ref = torch.from_numpy(-0.5 * y0.cpu().numpy() + 1.5 * np.add.reduceat(prod, starts)).cuda()
+    scale = torch.from_numpy(0.5 * np.abs(y0.cpu().numpy()) + 1.5 * np.add.reduceat(np.abs(prod), starts)).cuda()
+    rp32 = rp.to(torch.int32)
+    lib = spmv_acc_amd.load_library()
+    for strat, knobs in (("flat", {"flat_finish": 0}), ("flat", {}), ("adaptive_plus", {}), ("adaptive_plus", {"plus_min_nnz": 1024}),
+                         ("line_enhance", {}), ("adaptive", {}), ("default", {})):
+        try:
+            for k, val in knobs.items():
+                assert lib.spmv_acc_set_tunable(k.encode(), val) == 0
+            outs = []
+            for _ in range(2):
+                y = y0.clone()
+                spmv_acc_amd.csr_spmv(1.5, -0.5, m, n, nnz, rp32, ci, v, x, y, strategy=strat)
+                torch.cuda.synchronize()
+                outs.append(y)
+        finally:
+            lib.spmv_acc_reset_tunables()
+            spmv_acc_amd.release_plans(rp32)
+        err = float(((outs[0] - ref).abs() / scale).max().item())
+        assert err <= SCALED_TOL, (strat, knobs, err)
+        assert torch.equal(outs[0], outs[1]), (strat, "not reproducible on one plan")
