@@ -484,17 +484,20 @@ bool ensure_flat(Plan &p, hipStream_t stream) {
   launch_break_points(stream, p.A.rp, p.A.m, nnz, stride, F.bp, static_cast<int>(n1));
   // does this matrix need the carry fix-up kernel at all? (only rows longer than a tile's finishing reach do)
   int *d_flag = nullptr;
-  int h_flag = 1;
-  if (hip_ok(hipMalloc(reinterpret_cast<void **>(&d_flag), sizeof(int)), "hipMalloc flat flag")) {
-    if (hip_ok(hipMemsetAsync(d_flag, 0, sizeof(int), stream), "memset flat flag")) {
+  int h_flag[2] = {1, 0};
+  if (hip_ok(hipMalloc(reinterpret_cast<void **>(&d_flag), 2 * sizeof(int)), "hipMalloc flat flag")) {
+    if (hip_ok(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), stream), "memset flat flag")) {
       launch_flat_needs_fixup(stream, p.A, F, d_flag);
-      if (!hip_ok(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream), "read flat flag") ||
-          !hip_ok(hipStreamSynchronize(stream), "sync flat flag"))
-        h_flag = 1;
+      if (!hip_ok(hipMemcpyAsync(h_flag, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, stream), "read flat flag") ||
+          !hip_ok(hipStreamSynchronize(stream), "sync flat flag")) {
+        h_flag[0] = 1;
+        h_flag[1] = 0;
+      }
     }
     (void)hipFree(d_flag);
   }
-  F.can_finish = h_flag == 0;
+  F.max_tile_rows = h_flag[1];
+  F.can_finish = h_flag[0] == 0;
   F.needs_fixup = true; // until run_flat has timed both forms on this matrix
   F.mode_tuned = false;
   p.flat_tiles = tiles;
@@ -744,8 +747,21 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
   return ok;
 }
 
+bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y,
+                  bool allow_uneven_switch);
+
+// A flat tile is one workgroup and walks its rows 256 at a time.  Where a tile owns tens of thousands of rows (hypersparse
+// matrices: 50 M rows with 6000 non-zeros put all of them into ONE tile, 96 ms) the rows, not the non-zeros, need cutting: such
+// matrices run the fixed row blocks instead (0.27 ms) -- the mirror image of the row-block family's rescue.
+constexpr int kFlatMaxTileRows = 16384;
+
 bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *x, double *y) {
   if (!ensure_flat(p, st)) return false;
+  if (p.flat.max_tile_rows > kFlatMaxTileRows && tun(kT_rowblock_guard)) {
+    // (guard against mutual recursion: the row-block rescue goes to row-block-plus unless rescue_flat is set, and a matrix with
+    // such tiles has no row-block imbalance of the hub-row kind)
+    if (!(tun(kT_rescue_flat) && p.rowblock_ok == 0)) return run_rowblock(st, p, nullptr, alpha, beta, x, y, false);
+  }
   if (!autotune_policy(p, st, [&](int pol, double *ys) { launch_flat_with(st, p, pol, 1.0, 0.0, x, ys); })) return false;
   if (!autotune_flat_mode(p, st, x)) return false;
   launch_flat_with(st, p, policy_for(p), alpha, beta, x, y);

@@ -184,19 +184,22 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
   }
 }
 
-// Plan time: does any row run more than kFlatFinish non-zeros past the end of the tile it starts in?  (Only then
-// does the fix-up kernel have anything to fold.)
+// Plan time, one thread per tile:  flag[0] = 1 if any row runs more than kFlatFinish non-zeros past the end of the tile it
+// starts in (only then does the fix-up kernel have anything to fold);  flag[1] = the largest number of rows any tile owns
+// (a tile is one workgroup: tens of thousands of -- mostly empty -- rows in one tile serialise there).
 __global__ __launch_bounds__(256) void flat_needs_fixup_kernel(const int *__restrict__ rp, const int *__restrict__ bp,
                                                                int ntiles, int m, int nnz, int stride,
                                                                int *__restrict__ flag) {
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= ntiles - 1) return;
+  if (t >= ntiles) return;
   const int t0 = t * stride;
-  const int t1 = t0 + stride;
+  const int t1 = (nnz - t0 > stride) ? t0 + stride : nnz;
   int first = bp[t];
   first = first < m ? first : m;
   const int end_excl = tile_end_excl(rp, bp, t, ntiles, m, t1);
   if (end_excl <= first) return;
+  atomicMax(flag + 1, end_excl - first);
+  if (t == ntiles - 1) return; // the last tile cannot have a row that continues
   const int r = end_excl - 1;
   if (rp[r] >= t0 && rp[r + 1] - t1 > kFlatFinish) *flag = 1; // idempotent store
 }
@@ -245,8 +248,8 @@ void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P,
 } // namespace
 
 void launch_flat_needs_fixup(hipStream_t stream, const CsrDev &A, const FlatPlan &P, int *d_flag) {
-  if (P.ntiles <= 1) return;
-  hipLaunchKernelGGL(flat_needs_fixup_kernel, dim3((P.ntiles - 1 + 255) / 256), dim3(256), 0, stream, A.rp, P.bp, P.ntiles,
+  if (P.ntiles <= 0) return;
+  hipLaunchKernelGGL(flat_needs_fixup_kernel, dim3((P.ntiles + 255) / 256), dim3(256), 0, stream, A.rp, P.bp, P.ntiles,
                      A.m, A.nnz, P.stride, d_flag);
 }
 

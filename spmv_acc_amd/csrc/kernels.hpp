@@ -80,6 +80,7 @@ struct FlatPlan {
   bool can_finish = false;  // no row runs more than kFlatFinish non-zeros past the tile it starts in (plan-time probe)
   bool needs_fixup = true;  // true: every cut row is folded from carries by the fix-up kernel; false (only when
                             // can_finish): tiles finish their cut rows themselves.  Chosen by timing, engine.cpp.
+  int max_tile_rows = 0;    // most rows any one tile (= workgroup) owns (plan-time probe)
   bool mode_tuned = false;  // tuned_fixup holds the timed choice
   bool tuned_fixup = true;
 };
@@ -90,7 +91,7 @@ struct FlatPlan {
 // (by the finishing tile and by the next one), so the reach is kept small: <= 6% of a tile.  Measured with a reach of
 // 2048 the TSOPF-like matrix (424 nnz/row) lost 15%: ~10% extra traffic plus a serial tail per block.
 constexpr int kFlatFinish = 128;
-void launch_flat_needs_fixup(hipStream_t stream, const CsrDev &A, const FlatPlan &P, int *d_flag); // *d_flag pre-zeroed
+void launch_flat_needs_fixup(hipStream_t stream, const CsrDev &A, const FlatPlan &P, int *d_flag); // d_flag[2] pre-zeroed
 void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                  double *y);
 

@@ -1282,3 +1282,38 @@ def test_giant_rows(torch_dev):
         err = float(((outs[0] - ref).abs() / scale).max().item())
         assert err <= SCALED_TOL, (strat, knobs, err)
         assert torch.equal(outs[0], outs[1]), (strat, "not reproducible on one plan")
+
+
+def test_hypersparse_rows(torch_dev, hiplib):
+    """Five million rows, 3000 non-zeros: every non-zero falls into one or two flat tiles, which would own millions of (empty)
+    rows each -- flat hands such matrices to the fixed row blocks (engine.cpp kFlatMaxTileRows).  All strategies against a
+    device-side evaluation; beta != 0 so every empty row must still be scaled."""
+    import time
+
+    torch = torch_dev
+    g = torch.Generator(device="cuda")
+    g.manual_seed(8)
+    m, n = 5_000_000, 1000
+    lens = torch.zeros(m, dtype=torch.int64, device="cuda")
+    lens[torch.randint(0, m, (150,), generator=g, device="cuda")] = 20
+    rp = torch.zeros(m + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(lens, 0, out=rp[1:])
+    nnz = int(rp[-1].item())
+    rows = torch.repeat_interleave(torch.arange(m, device="cuda"), lens, output_size=nnz)
+    ci = torch.randint(0, n, (nnz,), generator=g, device="cuda").to(torch.int32)
+    v = torch.rand(nnz, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    x = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    y0 = torch.rand(m, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    ref = (0.25 * y0).index_add_(0, rows, 2.0 * (v * x[ci.long()]))
+    rp32 = rp.to(torch.int32)
+    for strat in ("flat", "adaptive", "line_enhance", "adaptive_plus", "default", "vector_row"):
+        y = y0.clone()
+        spmv_acc_amd.csr_spmv(2.0, 0.25, m, n, nnz, rp32, ci, v, x, y, strategy=strat)
+        torch.cuda.synchronize()
+        assert float((y - ref).abs().max().item()) <= 1e-13, strat
+        t0 = time.perf_counter()
+        for _ in range(5):
+            spmv_acc_amd.csr_spmv(2.0, 0.25, m, n, nnz, rp32, ci, v, x, y, strategy=strat)
+        torch.cuda.synchronize()
+        assert (time.perf_counter() - t0) / 5 < 5e-3, (strat, "steady-state call slower than 5 ms on a 100 MB problem")
+    spmv_acc_amd.release_plans(rp32)
