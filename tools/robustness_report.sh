@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/robustness.txt
 mkdir -p $R/gpurun_out; : > $O
-run() { echo "\$ $*" >> $O; timeout -k 10 200 "$@" 2>&1 | grep -v amdgpu.ids >> $O; echo >> $O; }
+run() { echo "\$ ${ROWLAW_M:+ROWLAW_M=$ROWLAW_M }${ROWLAW_COLS:+ROWLAW_COLS=$ROWLAW_COLS }$*" >> $O; timeout -k 10 200 "$@" 2>&1 | grep -v amdgpu.ids >> $O; echo >> $O; }
 run python3 $R/tools/halves_bench.py 12 8
 run python3 $R/tools/halves_bench.py 40 5
 run python3 $R/tools/halves_bench.py 60 20
@@ -20,6 +20,9 @@ run python3 $R/tools/rowlaw_bench.py empty 0.5
 ROWLAW_M=8000000 run python3 $R/tools/rowlaw_bench.py empty 0.97
 ROWLAW_M=20000 run python3 $R/tools/rowlaw_bench.py lognormal 0.3 5000
 ROWLAW_M=300 run python3 $R/tools/rowlaw_bench.py lognormal 0.2 300000
+ROWLAW_M=8 run python3 $R/tools/rowlaw_bench.py lognormal 0.01 20000000
+ROWLAW_M=1 run python3 $R/tools/rowlaw_bench.py lognormal 0.01 100000000
+ROWLAW_M=50000000 run python3 $R/tools/rowlaw_bench.py spikes 200 30 0
 ROWLAW_COLS=clusters run python3 $R/tools/rowlaw_bench.py lognormal 0.3
 ROWLAW_COLS=uniform run python3 $R/tools/rowlaw_bench.py lognormal 0.3
 run python3 $R/tools/unaligned_bench.py
