@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Large randomised parity run on the GPU (matrices of up to ~150 M non-zeros, far beyond what the CPU oracle checks in seconds): random
 row-length laws x column laws x sizes through every kernel family, against an independent fp64 evaluation on the device
-(index_add of the products, a different summation order), error scaled by sum_j |a_ij x_j| + |beta y0_i|.
+(torch.segment_reduce of the products, a different summation order), error scaled by sum_j |a_ij x_j| + |beta y0_i|.
     python tools/big_fuzz.py [cases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,7 @@ worst = 0.0
 for case in range(cases):
     m = int(10 ** rng.uniform(3, 6.7))
     mean = float(rng.choice([1.5, 4, 12, 40, 300, 4000]))
-    law = rng.choice(["lognormal", "spikes", "stripes", "empty"])
+    law = rng.choice(["lognormal", "spikes", "stripes", "empty", "giant", "hypersparse"])
     m = max(16, min(m, int(1.5e8 / mean)))
     if law == "lognormal":
         sigma = float(rng.uniform(0, 2.0))
@@ -29,6 +29,15 @@ for case in range(cases):
         dense = ((torch.arange(m, device="cuda") // stripe) % 2) == 0
         lens = torch.where(dense, torch.randint(0, int(3 * mean) + 1, (m,), generator=g, device="cuda"),
                            torch.randint(0, int(mean) + 1, (m,), generator=g, device="cuda"))
+    elif law == "giant":  # a few rows of millions of non-zeros among ordinary ones
+        m = max(16, min(m, 200000))
+        lens = torch.randint(0, 12, (m,), generator=g, device="cuda")
+        for r in rng.integers(0, m, int(rng.integers(1, 5))):
+            lens[int(r)] = int(rng.integers(500_000, 8_000_000))
+    elif law == "hypersparse":  # almost every row empty
+        m = int(10 ** rng.uniform(5, 7.5))
+        lens = torch.zeros(m, dtype=torch.int64, device="cuda")
+        lens[torch.randint(0, m, (int(rng.integers(1, 3000)),), generator=g, device="cuda")] = int(rng.integers(1, 40))
     else:
         lens = torch.randint(0, int(2 * mean) + 1, (m,), generator=g, device="cuda")
         lens[torch.rand(m, generator=g, device="cuda") < float(rng.uniform(0.3, 0.99))] = 0
@@ -53,8 +62,10 @@ for case in range(cases):
     y0 = torch.rand(m, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
     alpha, beta = [(1.0, 1.0), (0.5, -2.0), (1.0, 0.0), (-1.25, 0.5)][case % 4]
     prod = v * x[ci.long()]
-    ref = (beta * y0).index_add_(0, rows, alpha * prod)
-    scale = (abs(beta) * y0.abs()).index_add_(0, rows, abs(alpha) * prod.abs()) + 1e-300
+    # independent evaluation: torch's segmented reduction over the row lengths (its own summation order; no atomics, so rows of
+    # millions of non-zeros do not serialise the way an index_add on three addresses would)
+    ref = beta * y0 + alpha * torch.segment_reduce(prod, "sum", lengths=lens, unsafe=True)
+    scale = abs(beta) * y0.abs() + abs(alpha) * torch.segment_reduce(prod.abs(), "sum", lengths=lens, unsafe=True) + 1e-300
     del prod, rows
     rp32 = rp.to(torch.int32)
     # how the arrays are handed over: fresh allocations, views offset by 1..3 elements (no 16-byte alignment), or a row shard
