@@ -129,7 +129,7 @@ int spmv_acc_free_device(void *p);
 /* ---- explicit preprocessing (new) ---------------------------------------------------------------------------------------
  * Builds everything the FIRST call on a matrix would build for `strategy` -- the structural passes (break points, row-block
  * analysis, balance probe) and the per-matrix timings (cache policy, flat's cut-row form, adaptive-plus block size) -- by
- * running that first call into a scratch y (beta = 0), then synchronises.  The caller's y is not touched; x is read.
+ * running that first call into a zeroed scratch y (alpha = beta = 1, the reference's protocol), then synchronises.  The caller's y is not touched; x is read.
  * After it every spmv call on the matrix is kernel launches only (capturable into a hipGraph).  ms_out (may be NULL):
  * device time of the preparation, the figure the reference's benchmark reports as `pre` (benchmark_time.cpp:23-43;
  * there it is the per-call break-point / analysis cost, here it is paid once).

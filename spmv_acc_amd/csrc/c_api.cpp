@@ -261,8 +261,10 @@ int spmv_acc_prepare(int strategy, int m, int n, int nnz, const int *h_rowptr, c
   const bool timed = ms_out && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
   clear_error();
   if (timed) (void)hipEventRecord(e0, st);
-  // beta = 0: y is written, never read -- the scratch needs no initial value and the caller's y is not involved
-  run_spmv(strategy, 0, 1.0, 0.0, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, scratch);
+  // the caller's y is not involved: the first call runs into a zeroed scratch, with beta = 1 (the reference's protocol and the
+  // usual case) so that choices which depend on whether y is read (adaptive's kernel family) are made for that case
+  (void)hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(m), st);
+  run_spmv(strategy, 0, 1.0, 1.0, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, scratch);
   if (timed) (void)hipEventRecord(e1, st);
   int rc = hipStreamSynchronize(st) == hipSuccess ? kOk : kErrHip;
   if (timed && rc == kOk && hipEventElapsedTime(ms_out, e0, e1) != hipSuccess) rc = kErrHip;

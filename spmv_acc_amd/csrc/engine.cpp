@@ -935,14 +935,18 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
       return false;
     TuneTimer timer;
-    bool ok = timer.ok;
+    bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
     float ms[3] = {1e30f, 1e30f, 1e30f};
+    // The families are compared in the caller's beta class: with beta != 0 every row also reads its old y, which is a large
+    // share of the traffic where rows hold one or two non-zeros and ranks the families differently (15 M rows of ~1 nnz:
+    // flat looked 3 % faster than the row blocks at beta = 0 and is 9 % slower at beta = 1).
+    const double beta_trial = beta != 0.0 ? 1.0 : 0.0;
     t_coarse_tuning = true;
     for (int f = 0; ok && f < 3; ++f) {
-      ok = run_family(f, 1.0, 0.0, scratch); // builds this family's plan (sub-choices at their defaults)
+      ok = run_family(f, 1.0, beta_trial, scratch); // builds this family's plan (sub-choices at their defaults)
       if (!ok) break;
       if (f == 0 && p.rowblock_ok == 0) continue; // fixed row blocks were rescued: that run WAS family 1
-      ok = timer.time(st, [&] { (void)run_family(f, 1.0, 0.0, scratch); }, &ms[f]);
+      ok = timer.time(st, [&] { (void)run_family(f, 1.0, beta_trial, scratch); }, &ms[f]);
     }
     t_coarse_tuning = false;
     // fixed row blocks unless another family is at least 3 % faster (short kernels time within ~2 %)

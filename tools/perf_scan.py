@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 g = torch.Generator(device="cuda"); g.manual_seed(int(rng.integers(1 << 30)))
 out = []
 for case in range(cases):
-    m = int(10 ** rng.uniform(4.5, 7))
+    m = int(10 ** rng.uniform(float(os.environ.get("PERF_SCAN_LOG_M_MIN", "4.5")), 7.3))
     mean = float(rng.choice([1.5, 4, 12, 40, 150, 1000]))
     m = max(1000, min(m, int(1.2e8 / mean)))
     law = rng.choice(["lognormal", "spikes", "stripes", "empty", "bimodal", "ramp"])
