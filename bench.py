@@ -40,6 +40,8 @@ def parse():
     p.add_argument("--scale", type=float, default=1.0, help="shrink the workload (for rehearsals only)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-sensitivity", action="store_true", help="skip the far_fraction=0 variant of the N=1 workload")
+    p.add_argument("--no-legs", action="store_true",
+                   help="N = 1: skip the extra live legs (configs[2] sweep, configs[3] R-MAT 25, configs[4] banded shard)")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--exchange", default="auto", choices=["auto", "allgather", "p2p", "ghost"],
                    help="N > 1: how the y slices travel -- RCCL all_gather_into_tensor, a direct point-to-point fan-out "
@@ -120,13 +122,165 @@ def cpu_baseline(W, x, y0, seconds):
     }
 
 
-def pmc_traffic(workload, strategy):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), or None."""
+def pmc_traffic(workload, strategy, key="corrected_bytes"):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, regenerated from the PMC
+    text by tools/profile_round.sh), or None.  `corrected_bytes` is the guide's (2*FETCH + WRITE)*1024 -- an upper bound
+    where gathers miss L2 --, `lower_bound_bytes` counts every L2-missing gather at its 64-B sector."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return table[f"{workload}|{strategy}"]["corrected_bytes"]
+        return table[f"{workload}|{strategy}"][key]
     except (OSError, KeyError, ValueError):
         return None
+
+
+def timed_leg(torch, strat, A, x, y0, iters, warm=10, beta=1.0):
+    """One extra leg: `warm` untimed launches (the first builds the plan), then `iters` back-to-back launches between one
+    hipEvent pair on the library stream.  us = mean launch duration; frac = algorithmic bytes / us / 8 TB/s."""
+    import spmv_acc_amd
+    from spmv_acc_amd import synth
+
+    m, n, nnz, rp, ci, v = A
+    y = y0.clone()
+    for _ in range(warm):
+        spmv_acc_amd.csr_spmv(1.0, beta, m, n, nnz, rp, ci, v, x, y, strategy=strat)
+    torch.cuda.synchronize()
+    y.copy_(y0)
+    ms = spmv_acc_amd.time_spmv_total(strat, iters, 1.0, beta, m, n, nnz, rp, ci, v, x, y) / iters
+    b = synth.algorithmic_bytes(m, n, nnz, beta_nonzero=beta != 0.0)
+    info = spmv_acc_amd.query_plan(rp, m) or {}
+    return {"us": round(ms * 1e3, 2), "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "gflops": round(2.0 * nnz / (ms * 1e-3) / 1e9, 1),
+            "plan": [info.get(k, -1) for k in ("stream_policy", "adaptive_family", "flat_fixup")]}
+
+
+def extra_legs(torch, device, headline):
+    """BASELINE configs[2..4] measured live in the same run (rank 0, N = 1): the 12-matrix sweep under flat (the strategy
+    BASELINE names) and adaptive, R-MAT scale 25 under line_enhance, one 32 M-row banded shard.  Keys are additions to the
+    one JSON line; the headline value is untouched."""
+    import spmv_acc_amd
+    from spmv_acc_amd import synth
+
+    def vectors(m, n):
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1234)
+        return (torch.rand(n, generator=gen, device=device, dtype=torch.float64) * 2 - 1,
+                torch.rand(m, generator=gen, device=device, dtype=torch.float64) * 2 - 1)
+
+    def progress(msg):  # stderr: the one JSON line on stdout stays alone (and a long run is seen to be alive)
+        print(f"[bench legs] {msg}", file=sys.stderr, flush=True)
+
+    out = {}
+    sweep = {}
+    for name in synth.SWEEP_NAMES:
+        A = headline if name == "Hardesty3" else synth.sweep_standin_torch(name, device=device)
+        x, y0 = vectors(A[0], A[1])
+        iters = 200 if A[2] < 20_000_000 else 60
+        sweep[name] = {"rows": A[0], "nnz": A[2]}
+        for strat in ("flat", "adaptive"):
+            sweep[name][strat] = timed_leg(torch, strat, A, x, y0, iters)
+        progress(f"sweep {name}: flat {sweep[name]['flat']['us']} us ({sweep[name]['flat']['frac']}), "
+                 f"adaptive {sweep[name]['adaptive']['us']} us ({sweep[name]['adaptive']['frac']})")
+        spmv_acc_amd.release_plans(A[3])
+        del A, x, y0
+        torch.cuda.empty_cache()
+    out["sweep"] = sweep
+    out["sweep_summary"] = {
+        s: {"ge_0.70": sum(1 for r in sweep.values() if r[s]["frac"] >= 0.70),
+            "min_frac": min(r[s]["frac"] for r in sweep.values()),
+            "median_frac": float(np.median([r[s]["frac"] for r in sweep.values()]))} for s in ("flat", "adaptive")}
+    A = synth.rmat_torch(25, device=device, seed=0xC4)
+    x, y0 = vectors(A[0], A[1])
+    out["rmat25"] = {"workload": "R-MAT scale 25, edge factor 16 (BASELINE configs[3])", "rows": A[0], "nnz": A[2],
+                     "line_enhance": timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)}
+    progress(f"rmat25: {out['rmat25']['line_enhance']}")
+    spmv_acc_amd.release_plans(A[3])
+    del A, x, y0
+    torch.cuda.empty_cache()
+    rows, total = 32_000_000, 256_000_000
+    rp, ci, v = synth.banded_torch(rows, first_row=3 * rows, total_rows=total, device=device)
+    A = (rows, total, int(rp[-1].item()), rp, ci, v)
+    x, y0 = vectors(rows, total)
+    out["banded_shard"] = {"workload": "rank 3's 32 M-row shard of the 256 M-row banded matrix (BASELINE configs[4]), beta = 0",
+                           "rows": rows, "nnz": A[2], "adaptive": timed_leg(torch, "adaptive", A, x, y0, iters=30, warm=5, beta=0.0)}
+    progress(f"banded shard: {out['banded_shard']['adaptive']}")
+    spmv_acc_amd.release_plans(rp)
+    return out
+
+
+def sharded_leg(torch, dist, args, W, x, y0, alpha, beta, rank, world, device, backend, force_dist, steps, warmup):
+    """N > 1: one RowShardedSpmv over this rank's shard -- local SpMV on the engine's own stream, ONE exchange of the y slices
+    per step (RCCL allgather or the point-to-point fan-out, whichever the timing on this communicator prefers).  Returns the
+    max-over-ranks wall time of `steps` steps (barrier + synchronize on both sides) and the SpMV-only launch time."""
+    import spmv_acc_amd
+    from spmv_acc_amd.dist import RowShardedSpmv
+
+    m, n, nnz = W["m"], W["n"], W["nnz"]
+    strat = W["strategy"]
+    extra = {}
+    bounds = np.arange(world + 1, dtype=np.int64) * m  # every rank owns m rows of the (world*m) x n matrix
+    eng = RowShardedSpmv(rank, world, bounds, W["rp"], W["ci"], W["v"], n, device, strategy=strat,
+                         always_collective=force_dist,
+                         exchange="allgather" if args.exchange == "auto" else args.exchange)
+    if args.exchange == "auto" and backend == "nccl":  # (gloo rehearsals: no point-to-point on GPU tensors)
+        try:
+            extra["exchange_ms"] = {k: round(v, 4) for k, v in eng.tune_exchange().items()}
+        except Exception as ex:  # noqa: BLE001 -- a backend without grouped point-to-point: keep the collective
+            extra["exchange_tune_error"] = repr(ex)[:200]
+            eng.exchange = "allgather"
+    extra["exchange"] = eng.exchange
+
+    def sync_all():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.set_y(y0)  # like the N = 1 leg, y is iterated in place (no per-step reset inside the timed region)
+    for _ in range(max(warmup, 1)):
+        eng.step(alpha, beta, x, overlap=not args.no_overlap)
+    eng.wait()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step(alpha, beta, x, overlap=not args.no_overlap)
+    eng.wait()
+    sync_all()
+    wall = time.perf_counter() - t0
+    # SpMV-only (no exchange) for the same shard, per-launch hipEvents
+    y = y0.clone()
+    ms = spmv_acc_amd.time_spmv(strat, min(steps, 50), alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y)
+    ev_ms = float(np.mean(ms))
+    t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall, ev_ms_max = float(t[0].item()), float(t[1].item())
+    extra["spmv_only_gflops_per_gpu"] = round(2.0 * nnz / (ev_ms * 1e-3) / 1e9, 3)
+    extra["spmv_only_ms_max_over_ranks"] = round(ev_ms_max, 6)
+    extra["spmv_plus_exchange_ms_per_step"] = round(wall / steps * 1e3, 6)
+    extra["spmv_plus_exchange_gflops_total"] = round(2.0 * nnz * world * steps / wall / 1e9, 3)
+    extra["allgather_bytes_per_rank_per_step"] = 8 * eng.pad * (world - 1)
+    del eng
+    return wall, ev_ms, extra
+
+
+def rccl_debug_summary(rank):
+    """What RCCL itself logged about this job's communicator (NCCL_DEBUG=INFO into a per-rank file): the rank count it
+    saw and, where the build prints them, the algorithm / protocol lines -- so that 'RCCL ran over N ranks' can be checked
+    from the bench line."""
+    import re
+
+    path = os.environ.get("NCCL_DEBUG_FILE", "").replace("%h", os.uname().nodename).replace("%p", str(os.getpid()))
+    out = {"nranks_seen": None, "lines": []}
+    try:
+        text = open(path, errors="replace").read()
+    except OSError:
+        return out
+    m = re.findall(r"nranks (\d+)", text)
+    if m:
+        out["nranks_seen"] = int(m[-1])
+    for line in text.splitlines():
+        if re.search(r"Init COMPLETE|Algo|algorithm|Connected all|Channel 00[ /:]|via P2P|via SHM|via NET", line):
+            out["lines"].append(re.sub(r"^.*NCCL INFO ", "", line)[:160])
+            if len(out["lines"]) >= 8:
+                break
+    return out
 
 
 def copy_ceiling_gbs(torch, device):
@@ -174,6 +328,11 @@ def main():
     if dist_leg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":  # RCCL's own account of the communicator, quoted in the JSON line (rccl_debug_summary)
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING")
+            os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/spmv_acc_bench_rccl_{os.getpid()}_rank{rank}.log")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -243,36 +402,36 @@ def main():
         out_extra["exchanged_bytes_per_rank_per_step"] = eng.exchanged_bytes_per_step
         out_extra["ghost_columns"] = eng.n_ghost
     else:
-        bounds = np.arange(world + 1, dtype=np.int64) * m  # every rank owns m rows of the (world*m) x n matrix
-        eng = RowShardedSpmv(rank, world, bounds, W["rp"], W["ci"], W["v"], n, device, strategy=strat,
-                             always_collective=force_dist,
-                             exchange="allgather" if args.exchange == "auto" else args.exchange)
-        if args.exchange == "auto" and backend == "nccl":  # (gloo rehearsals: no point-to-point on GPU tensors)
-            try:
-                out_extra["exchange_ms"] = {k: round(v, 4) for k, v in eng.tune_exchange().items()}
-            except Exception as ex:  # noqa: BLE001 -- a backend without grouped point-to-point: keep the collective
-                out_extra["exchange_tune_error"] = repr(ex)[:200]
-                eng.exchange = "allgather"
-        out_extra["exchange"] = eng.exchange
-        eng.set_y(y0)  # like the N = 1 leg, y is iterated in place (no per-step reset inside the timed region)
-        for _ in range(max(args.warmup, 1)):
-            eng.step(alpha, beta, x, overlap=not args.no_overlap)
-        eng.wait()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.step(alpha, beta, x, overlap=not args.no_overlap)
-        eng.wait()
-        sync_all()
-        wall = time.perf_counter() - t0
-        # SpMV-only leg (no collective) for the same shard, per-launch hipEvents
-        ms = spmv_acc_amd.time_spmv(strat, min(args.steps, 50), alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y)
-        ev_ms = float(np.mean(ms))
-        t = torch.tensor([wall], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-        out_extra["spmv_only_gflops_per_gpu"] = round(2.0 * nnz / (ev_ms * 1e-3) / 1e9, 3)
-        out_extra["allgather_bytes_per_rank_per_step"] = 8 * eng.pad * (world - 1)
+        wall, ev_ms, extra = sharded_leg(torch, dist, args, W, x, y0, alpha, beta, rank, world, device, backend, force_dist,
+                                         args.steps, args.warmup)
+        out_extra.update(extra)
+        if backend == "nccl":
+            out_extra["rccl"] = rccl_debug_summary(rank)
+        if args.workload == "hardesty3" and args.scale == 1.0 and not args.no_legs:
+            # BASELINE configs[4] as a first-class leg of every N > 1 run: each rank owns 32 M rows of the (N * 32 M)-row banded
+            # matrix (global column ids, x replicated), beta = 0, one exchange of the y slices per step.
+            from spmv_acc_amd import synth as _synth
+
+            rows = 32_000_000
+            brp, bci, bv = _synth.banded_torch(rows, first_row=rank * rows, total_rows=world * rows, device=device)
+            BW = dict(m=rows, n=world * rows, nnz=int(brp[-1].item()), rp=brp, ci=bci, v=bv, strategy="adaptive")
+            gen_b = torch.Generator(device=device)
+            gen_b.manual_seed(4321)
+            bx = torch.rand(world * rows, generator=gen_b, device=device, dtype=torch.float64) * 2 - 1
+            by0 = torch.zeros(rows, dtype=torch.float64, device=device)
+            bsteps = min(args.steps, 50)
+            bwall, bev, bextra = sharded_leg(torch, dist, args, BW, bx, by0, 1.0, 0.0, rank, world, device, backend, force_dist,
+                                             bsteps, min(args.warmup, 5))
+            b_alg_b = _synth.algorithmic_bytes(rows, world * rows, BW["nnz"], beta_nonzero=False)
+            bextra.update({
+                "workload": f"banded offsets -4..+3, {world} x 32 M rows (BASELINE configs[4]; 8 ranks = the 256 M-row matrix), "
+                            "row-range shards, x replicated, beta = 0, allgather(y) per step",
+                "rows_per_gpu": rows, "nnz_per_gpu": BW["nnz"], "steps": bsteps,
+                "spmv_only_frac_of_hbm_peak": round(b_alg_b / (bev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            out_extra["banded"] = bextra
+            spmv_acc_amd.release_plans(brp)
+            del brp, bci, bv, bx, by0, BW
+            torch.cuda.empty_cache()
 
     ms_per_step = wall / args.steps * 1e3
     nnz_total = nnz * world  # weak scaling: every rank processes its own nnz
@@ -290,6 +449,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": pmc_traffic(args.workload, strat) if args.scale == 1.0 else None,
+                     "traffic_lower_bound": pmc_traffic(args.workload, strat, "lower_bound_bytes") if args.scale == 1.0 else None,
                      "algorithmic_bytes_per_launch": b_alg, "launch_ms_mean": round(ev_ms, 6)},
         "ref_formula_gibps": round(synth.reference_bytes(m, nnz) / 2**30 / (ev_ms * 1e-3), 2),
         "gflops_kernel_only_per_gpu": round(2.0 * nnz / (ev_ms * 1e-3) / 1e9, 3),
@@ -314,6 +474,8 @@ def main():
                                  "frac": round(b_alg / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         spmv_acc_amd.release_plans(rp2)
         del rp2, ci2, v2, y2
+    if rank == 0 and world == 1 and args.workload == "hardesty3" and args.scale == 1.0 and not args.no_legs:
+        result.update(extra_legs(torch, device, (m, n, nnz, W["rp"], W["ci"], W["v"])))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(W, x, y0, args.cpu_seconds)
     elif rank == 0:

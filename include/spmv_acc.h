@@ -138,10 +138,27 @@ int spmv_acc_free_device(void *p);
 int spmv_acc_prepare(int strategy, int m, int n, int nnz, const int *h_rowptr, const int *d_rowptr, const int *d_colindex,
                      const double *d_value, const double *dx, float *ms_out);
 
+/* Host microseconds the calling thread's most recent SpMV call spent preparing its matrix (structural passes + per-matrix
+ * timings of the FIRST call on a matrix); 0 when the plan already existed.
+ * replaces: BenchmarkTime::pre of the reference's harness (benchmark/utils/benchmark_time.cpp:23-43,
+ * benchmark/flat/spmv_acc_flat.cpp:20-71: the break-point pass timed on EVERY call there) and
+ * SpMVAccHanele::profile_analyze_time (csr_adaptive_plus_spmv.cpp:98-128). */
+double spmv_acc_last_prepare_us(void);
+
 /* ---- plan cache, stream, errors ------------------------------------------------------------------------------------------
  * Preprocessing results (break points, row blocks, carries) are cached per matrix, keyed by
  * (device, rowptr, colindex, value, m, n).  Release when a matrix' structure changes in place or its
- * buffers are freed; NULL releases everything. */
+ * buffers are freed; NULL releases everything.
+ * Stale-plan guard: the reference recomputes its preprocessing on every call (hip-flat/flat.cpp:39-44), so its callers
+ * never announce a change.  Every plan therefore records 64 strided rowptr entries (rowptr[0] .. rowptr[m] = nnz);
+ * the first wavefront of every SpMV kernel re-reads them and raises a sticky flag (pinned host memory, no
+ * synchronisation) when the matrix behind the pointers is no longer the one the plan was built for -- buffers freed
+ * and re-allocated at the same addresses for another matrix of the same shape, or a structure rewritten in place.
+ * spmv_acc_last_error() (after the caller's synchronisation) and the next call on those pointers then report
+ * SPMV_ACC_ERR_BAD_ARGUMENT ("... changed ..."): the y of the call that ran on the stale plan is invalid, the plan
+ * is dropped and the next call builds a fresh one before it runs.  Values edited in place never trip the guard
+ * (plans hold no copy of colindex or values).  A change that leaves all 64 samples untouched is not seen: callers
+ * that permute a few rows in place still have to call spmv_acc_release_plans. */
 void spmv_acc_release_plans(const int *d_rowptr);
 int spmv_acc_cached_plans(void);
 /* plan introspection: fills out[9] = {nnz, adaptive_branch, vec, flat_tiles, plus_blocks, aligned16, stream_policy,

@@ -36,6 +36,7 @@ C_ABI_SYMBOLS = (
     "spmv_acc_set_stream", "spmv_acc_get_stream", "spmv_acc_last_error", "spmv_acc_last_error_string",
     "spmv_acc_clear_error", "spmv_acc_time_spmv", "spmv_acc_version", "spmv_acc_set_tunable",
     "spmv_acc_get_tunable", "spmv_acc_reset_tunables", "spmv_acc_time_spmv_total", "spmv_acc_copy_ceiling_gbs", "spmv_acc_adaptive_plus_analyze_device", "spmv_acc_prepare",
+    "spmv_acc_last_prepare_us",
 )
 
 _lib = None
@@ -103,6 +104,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_time_spmv_total.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.spmv_acc_copy_ceiling_gbs.argtypes = [vp, vp, ctypes.c_longlong, ci]
     lib.spmv_acc_copy_ceiling_gbs.restype = cd
+    lib.spmv_acc_last_prepare_us.restype = cd
     if path is None:
         _lib = lib
     return lib
@@ -142,10 +144,45 @@ def _require_cuda(*tensors) -> None:
             raise SpmvAccError("device pointers required: tensor is not on the GPU (no CPU fallback)")
 
 
+def _require(lib, **named) -> None:
+    """Torch tensors handed to the C ABI are passed as raw pointers, so what the kernels assume is checked here: on the GPU,
+    all on one device, contiguous, int32 indices / float64 values, and at least as many elements as the shape says.
+    name -> (tensor, "i32" | "f64", minimum element count); raw integer pointers and None pass through unchecked.
+    Also points the library stream at torch's current stream on that device, so the launches are ordered with the caller's
+    other torch work (the default stream is HIP's NULL stream, the reference's behaviour)."""
+    device = None
+    for name, (t, kind, count) in named.items():
+        if t is None or not hasattr(t, "is_cuda"):
+            continue
+        if not t.is_cuda:
+            raise SpmvAccError(f"{name}: device pointers required, tensor is not on the GPU (no CPU fallback)")
+        want = "torch.int32" if kind == "i32" else "torch.float64"
+        if str(t.dtype) != want:
+            raise SpmvAccError(f"{name}: dtype {t.dtype}, the library reads {want} (int32 indices, fp64 values)")
+        if not t.is_contiguous():
+            raise SpmvAccError(f"{name}: tensor is not contiguous")
+        if t.numel() < count:
+            raise SpmvAccError(f"{name}: {t.numel()} elements, the shape needs at least {count}")
+        if device is None:
+            device = t.device
+        elif t.device != device:
+            raise SpmvAccError(f"{name}: on {t.device}, other arguments on {device}")
+    if device is not None:
+        import torch
+
+        lib.spmv_acc_set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _csr_args(lib, m, n, nnz, rowptr, colindex, value, x, y=None, y0=None) -> None:
+    k = max(nnz, 0)
+    _require(lib, rowptr=(rowptr, "i32", m + 1), colindex=(colindex, "i32", k), value=(value, "f64", k),
+             x=(x, "f64", n), y=(y, "f64", m), y0=(y0, "f64", m))
+
+
 def sparse_spmv(trans: int, alpha: float, beta: float, m: int, n: int, rowptr, colindex, value, x, y) -> None:
     """Ten-argument entry with the active strategy; all tensors on the GPU; y updated in place (async)."""
     lib = load_library()
-    _require_cuda(rowptr, colindex, value, x, y)
+    _csr_args(lib, m, n, -1, rowptr, colindex, value, x, y)
     lib.sparse_spmv(trans, alpha, beta, m, n, _ptr(rowptr), _ptr(colindex), _ptr(value), _ptr(x), _ptr(y))
     _check(lib)
 
@@ -154,7 +191,7 @@ def csr_spmv(alpha: float, beta: float, m: int, n: int, nnz: int, rowptr, colind
              strategy=None, h_rowptr=None, trans: int = 0) -> None:
     """Descriptor entry (sparse_csr_spmv flattened).  ``h_rowptr``: optional host (numpy int32) rowptr."""
     lib = load_library()
-    _require_cuda(rowptr, colindex, value, x, y)
+    _csr_args(lib, m, n, nnz, rowptr, colindex, value, x, y)
     args = (trans, alpha, beta, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr), _ptr(colindex), _ptr(value), _ptr(x), _ptr(y))
     if strategy is None:
         lib.spmv_acc_csr_spmv(*args)
@@ -167,7 +204,7 @@ def prepare(m: int, n: int, nnz: int, rowptr, colindex, value, x, strategy=None,
     """Build the plan of ``strategy`` for this matrix (structural passes + per-matrix timings) without touching any y.
     Returns the device milliseconds it took."""
     lib = load_library()
-    _require_cuda(rowptr, colindex, value, x)
+    _csr_args(lib, m, n, nnz, rowptr, colindex, value, x)
     ms = ctypes.c_float(0.0)
     sid = lib.spmv_acc_get_strategy() if strategy is None else strategy_id(strategy)
     rc = lib.spmv_acc_prepare(sid, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr), _ptr(colindex), _ptr(value), _ptr(x), ctypes.byref(ms))
@@ -179,7 +216,7 @@ def prepare(m: int, n: int, nnz: int, rowptr, colindex, value, x, strategy=None,
 def break_points(rowptr, m: int, nnz: int, stride: int, out) -> None:
     """Device form of the row-block preprocessing pass into ``out`` (GPU int32, break_points_len entries)."""
     lib = load_library()
-    _require_cuda(rowptr, out)
+    _require(lib, rowptr=(rowptr, "i32", m + 1), out=(out, "i32", 1))
     rc = lib.spmv_acc_break_points(_ptr(rowptr), m, nnz, stride, _ptr(out), out.numel())
     if rc != 0:
         _check(lib)
@@ -212,7 +249,7 @@ def adaptive_plus_analyze_device(rowptr, m: int, nnz: int, min_nnz_per_block: in
     import torch
 
     lib = load_library()
-    _require_cuda(rowptr)
+    _require(lib, rowptr=(rowptr, "i32", m + 1))
     cap = m + 2 + nnz // (2 * min_nnz_per_block)
     bp = torch.empty(cap, dtype=torch.int32, device=rowptr.device)
     fbr = torch.empty(m + 1, dtype=torch.int32, device=rowptr.device)
@@ -247,7 +284,7 @@ def time_spmv(strategy, iters: int, alpha: float, beta: float, m: int, n: int, n
               x, y, y0=None, h_rowptr=None) -> Sequence[float]:
     """Per-launch durations (ms) from hipEvents recorded on the library stream around each SpMV."""
     lib = load_library()
-    _require_cuda(rowptr, colindex, value, x, y, y0)
+    _csr_args(lib, m, n, nnz, rowptr, colindex, value, x, y, y0)
     out = (ctypes.c_float * iters)()
     rc = lib.spmv_acc_time_spmv(strategy_id(strategy), iters, alpha, beta, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr),
                                 _ptr(colindex), _ptr(value), _ptr(x), _ptr(y), _ptr(y0),
@@ -262,7 +299,7 @@ def time_spmv_total(strategy, iters: int, alpha: float, beta: float, m: int, n: 
                     x, y, h_rowptr=None) -> float:
     """Total milliseconds of `iters` back-to-back SpMVs between ONE hipEvent pair on the library stream."""
     lib = load_library()
-    _require_cuda(rowptr, colindex, value, x, y)
+    _csr_args(lib, m, n, nnz, rowptr, colindex, value, x, y)
     out = ctypes.c_float(0.0)
     rc = lib.spmv_acc_time_spmv_total(strategy_id(strategy), iters, alpha, beta, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr),
                                       _ptr(colindex), _ptr(value), _ptr(x), _ptr(y), ctypes.addressof(out))

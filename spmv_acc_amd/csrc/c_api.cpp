@@ -244,6 +244,8 @@ int spmv_acc_set_tunable(const char *name, int value) { return name ? set_tunabl
 int spmv_acc_get_tunable(const char *name) { return name ? get_tunable(name) : -1; }
 void spmv_acc_reset_tunables(void) { reset_tunables(); }
 
+double spmv_acc_last_prepare_us(void) { return last_prepare_us(); }
+
 int spmv_acc_last_error(void) { return last_error(); }
 const char *spmv_acc_last_error_string(void) { return last_error_string(); }
 void spmv_acc_clear_error(void) { clear_error(); }

@@ -131,6 +131,17 @@ __device__ __forceinline__ double wave_range_sum(const double *__restrict__ src,
   return s;
 }
 
+// Stale-plan guard: called by every SpMV kernel; only the first wave of block 0 does anything (64 4-byte loads, one
+// compare).  `guard` holds the rowptr samples of plan-build time, `stale` is a sticky flag in pinned host memory that the
+// engine reads before the next call on the plan and in spmv_acc_last_error().
+__device__ __forceinline__ void check_plan_guard(const int *__restrict__ rp, int m, const int *__restrict__ guard,
+                                                 int *__restrict__ stale) {
+  if (guard != nullptr && blockIdx.x == 0 && threadIdx.x < kWave) {
+    const int idx = static_cast<int>(static_cast<long long>(threadIdx.x) * m / (kWave - 1));
+    if (rp[idx] != guard[threadIdx.x]) __hip_atomic_store(stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // y update with the documented semantics y = alpha*A*x + beta*y (api/spmv.h:14).  beta == 0 does
 // not read y (BLAS convention; for finite y it equals the reference's alpha*s + 0*y).
 __device__ __forceinline__ void store_y(double *y, int row, double alpha, double beta, double s) {

@@ -11,10 +11,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <climits>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -41,12 +43,29 @@ void set_error(int code, const std::string &what) {
   g_err = code;
   g_err_msg = what;
 }
-int last_error() { return g_err; }
+namespace {
+bool report_stale_plans(); // below, with the plan cache
+}
+// Besides the calling thread's own error this reports a stale plan: a kernel of an earlier call found that the matrix behind a
+// cached plan's pointers is no longer the one the plan was built for (the caller should synchronise first, as it must
+// before reading y anyway).  The stale plan is dropped here; the next call on those pointers rebuilds it.
+int last_error() {
+  if (g_err == kOk) (void)report_stale_plans();
+  return g_err;
+}
 const char *last_error_string() { return g_err_msg.c_str(); }
 void clear_error() {
   g_err = kOk;
   g_err_msg.clear();
 }
+
+namespace {
+int last_error_code_only() { return g_err; }
+thread_local double t_last_prepare_us = 0.0;
+thread_local unsigned t_plan_work = 0; // bumped by every once-per-matrix step (structural pass, probe, timing) that really runs
+} // namespace
+
+double last_prepare_us() { return t_last_prepare_us; }
 
 void set_stream(hipStream_t s) { g_stream = s; }
 hipStream_t get_stream() { return g_stream; }
@@ -62,7 +81,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kTunableCount
 };
 Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
@@ -85,8 +104,13 @@ Tunable g_tunables[] = {
                                // 1920 on the matrix and keep the fastest
     {"plus_host_analysis", 0, 0}, // 1: run the row-block analysis on the host (the reference's form)
     {"flat_finish", -1, -1},   // flat cut rows: -1 time both forms per matrix, 0 carries + fix-up kernel, 1 tiles finish them (when legal)
-    {"flat_npt", 8, 8},        // non-zeros per lane per flat tile: 4, 8 or 16 (tile = 256 lanes x this)
+    {"flat_npt", -1, -1},      // non-zeros per lane per flat tile (tile = 256 lanes x this): 4, 8 or 16; -1 = 8, and below
+                               // kFlatSmallNnz non-zeros 4 and 8 are both timed on the matrix (small grids: more, shorter workgroups)
     {"validate", 0, 0},        // 1: check rowptr / colindex of every new matrix on the device before the first launch
+    {"rowlen", -1, -1},        // row-block family: row extents from the plan's 1-byte row lengths + per-block bases instead of
+                               // rowptr: -1 where rows average <= 16 non-zeros (rowptr is then >= 2 % of the traffic), 0 never, 1 always
+    {"flat_early", -1, -1},    // flat: issue a tile's stream loads before its break point -> rowptr chain: -1 timed per matrix
+                               // below kFlatSmallNnz non-zeros (else off), 0 off, 1 on
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -97,10 +121,7 @@ inline int tun(TunableId id) { return g_tunables[id].val; } // apply_env_tunable
 namespace {
 // SPMV_ACC_TUNABLES="validate=1,flat_finish=0": initial values for a process that cannot call spmv_acc_set_tunable
 // (the reference's executables linked against this library).  Read once, before the first lookup.
-void apply_env_tunables() {
-  static bool done = false;
-  if (done) return;
-  done = true;
+void apply_env_tunables_once() {
   const char *env = std::getenv("SPMV_ACC_TUNABLES");
   if (!env) return;
   std::string s(env);
@@ -117,6 +138,10 @@ void apply_env_tunables() {
     }
     pos = end + 1;
   }
+}
+void apply_env_tunables() {
+  static std::once_flag once; // several host threads may make their first call together
+  std::call_once(once, apply_env_tunables_once);
 }
 } // namespace
 
@@ -319,14 +344,71 @@ int plus_analyze_host(int m, int min_nnz, int threads_per_block, int vec_size, c
 // ---- plans ---------------------------------------------------------------------------------------------------------
 namespace {
 
+// ---- stale-plan guard -------------------------------------------------------------------------------------------
+// The reference recomputes its preprocessing on every call (flat.cpp:39-44), so it can never act on a matrix that has
+// changed; its callers therefore never announce a change.  Plans here are keyed by pointers and shape, and a caller that
+// frees a matrix and gets the same addresses back for another one of the same shape (the norm for hipMalloc after hipFree),
+// or rewrites the structure in place, would meet the old matrix' break points / row blocks.  Every plan therefore records
+// kGuardSamples rowptr entries (device) and owns a sticky flag in pinned host memory; the first wave of block 0 of every
+// SpMV kernel compares (device_utils.hpp::check_plan_guard) and raises the flag.  The host looks at the flag -- an
+// ordinary memory read, no synchronisation -- when the plan is used again and in spmv_acc_last_error(): the plan is
+// dropped, SPMV_ACC_ERR_BAD_ARGUMENT is recorded (the y of the call that raised the flag is not to be trusted) and the
+// matrix gets a fresh plan.  Slots come from one pool per device, recycled first-in first-out so that a kernel of a
+// dropped plan that is still in flight does not meet its slot's next owner.
+constexpr int kGuardSlots = 4096;
+struct GuardPool {
+  int *d_guard = nullptr; // kGuardSlots * kGuardSamples ints
+  int *h_flags = nullptr; // kGuardSlots ints, hipHostMalloc (coherent, device-visible)
+  std::deque<int> free_slots;
+  bool failed = false;
+};
+std::mutex g_guard_mu; // not g_mu: plans die (and return their slot) both under g_mu and outside it
+std::map<int, GuardPool> g_guard_pools;
+
+int guard_acquire(int device, const int **d_guard, int **h_flag) {
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  GuardPool &P = g_guard_pools[device];
+  if (P.failed) return -1;
+  if (!P.d_guard) {
+    if (hipMalloc(reinterpret_cast<void **>(&P.d_guard), sizeof(int) * kGuardSlots * kGuardSamples) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&P.h_flags), sizeof(int) * kGuardSlots,
+                      hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+      (void)hipGetLastError();
+      if (P.d_guard) (void)hipFree(P.d_guard);
+      P.d_guard = nullptr;
+      P.failed = true; // plans of this device run unguarded
+      return -1;
+    }
+    std::memset(P.h_flags, 0, sizeof(int) * kGuardSlots);
+    for (int i = 0; i < kGuardSlots; ++i) P.free_slots.push_back(i);
+  }
+  if (P.free_slots.empty()) return -1;
+  const int slot = P.free_slots.front();
+  P.free_slots.pop_front();
+  __atomic_store_n(&P.h_flags[slot], 0, __ATOMIC_RELAXED);
+  *d_guard = P.d_guard + static_cast<size_t>(slot) * kGuardSamples;
+  *h_flag = P.h_flags + slot;
+  return slot;
+}
+void guard_release(int device, int slot) {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  g_guard_pools[device].free_slots.push_back(slot);
+}
+
+enum Family { kFamRowblock = 0, kFamPlus = 1, kFamFlat = 2, kFamilyCount = 3 };
+
 struct Plan {
   int device = 0;
   unsigned long long last_use = 0; // plan-cache clock at the last call that used this plan
+  std::mutex mu;                   // held by run_spmv for the whole call: plan fields, carry buffers and tunings are per matrix
+  unsigned long long calls = 0;    // SpMV calls served by this plan (the first one builds and tunes it)
   CsrDev A;
+  int guard_slot = -1;
   bool have_samples = false;
   RowptrSamples samples;
-  // cache policy of the stream loads (kStreamPolicy*), timed once per matrix; -1 = not tuned yet
-  int stream_policy = -1;
+  // cache policy of the stream loads (kStreamPolicy*), timed once per matrix AND kernel family; -1 = not tuned yet
+  int stream_policy[kFamilyCount] = {-1, -1, -1};
   // opt-in structural check (tunable `validate`): -1 not run, 0 arrays are consistent, else the failure bits
   int invalid = -1;
   // row-block family: -1 unknown, 1 balanced, 0 some workgroup would need too many LDS rounds
@@ -335,9 +417,12 @@ struct Plan {
   int max_block_nnz = 0;
   bool rowblock_uneven = false; // many row blocks far from the average block (balance probe)
   int adaptive_family = -1;     // adaptive's timed choice: 0 fixed row blocks, 1 row-block-plus, 2 flat; -1 not timed yet
+  RowDigest digest;             // row-block family: 1-byte row lengths + per-block bases (built for digest.rpb rows per block)
   // flat
   int flat_tiles = -1;
   FlatPlan flat;
+  int flat_npt_choice = 0;      // timed tile size (non-zeros per lane), 0 = not timed
+  bool flat_geometry_tuned = false;
   // row-block-plus
   int plus_blocks = -1;
   int plus_vec = 0;
@@ -349,9 +434,19 @@ struct Plan {
   double *d_ppartial = nullptr;
   void *d_pblk = nullptr;
 
-  ~Plan() { free_device(); }
+  ~Plan() {
+    free_device();
+    guard_release(device, guard_slot);
+  }
+  bool is_stale() const { return A.stale && __atomic_load_n(A.stale, __ATOMIC_RELAXED) != 0; }
+  void free_digest() {
+    if (digest.lens) (void)hipFree(digest.lens);
+    if (digest.base) (void)hipFree(digest.base);
+    digest = RowDigest();
+  }
   void free_device() {
     free_flat();
+    free_digest();
     if (d_pbp) (void)hipFree(d_pbp);
     if (d_pfbr) (void)hipFree(d_pfbr);
     if (d_ppartial) (void)hipFree(d_ppartial);
@@ -360,13 +455,16 @@ struct Plan {
     d_ppartial = nullptr;
     d_pbp = d_pfbr = nullptr;
   }
+  static void free_flat_plan(FlatPlan &F) {
+    if (F.bp) (void)hipFree(F.bp);
+    if (F.head) (void)hipFree(F.head);
+    if (F.tail) (void)hipFree(F.tail);
+    if (F.tail_row) (void)hipFree(F.tail_row);
+    if (F.tail_end) (void)hipFree(F.tail_end);
+    F = FlatPlan();
+  }
   void free_flat() {
-    if (flat.bp) (void)hipFree(flat.bp);
-    if (flat.head) (void)hipFree(flat.head);
-    if (flat.tail) (void)hipFree(flat.tail);
-    if (flat.tail_row) (void)hipFree(flat.tail_row);
-    if (flat.tail_end) (void)hipFree(flat.tail_end);
-    flat = FlatPlan();
+    free_flat_plan(flat);
     flat_tiles = -1;
   }
 };
@@ -396,6 +494,7 @@ const int *host_view(const int *h) { return host_readable(h) ? h : nullptr; }
 
 bool fetch_samples(Plan &p, const int *h_rowptr) {
   if (p.have_samples) return true;
+  ++t_plan_work;
   h_rowptr = host_view(h_rowptr);
   const int m = p.A.m;
   const int idx[4] = {m / 4, m / 2, static_cast<int>(3LL * m / 4), m};
@@ -422,6 +521,13 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
   const PlanKey key(dev, rp, ci, v, m, n);
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_plans.find(key);
+  if (it != g_plans.end() && it->second->is_stale()) {
+    set_error(kErrBadArgument,
+              "the matrix behind a cached plan changed (same pointers and shape, different rowptr) without "
+              "spmv_acc_release_plans: the previous result on it is invalid; the plan has been rebuilt");
+    g_plans.erase(it);
+    it = g_plans.end();
+  }
   if (it != g_plans.end()) {
     if (nnz < 0 || nnz == it->second->A.nnz) {
       it->second->last_use = ++g_use_clock;
@@ -458,49 +564,88 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
   p->A.aligned16 = (reinterpret_cast<uintptr_t>(ci) % 16 == 0) && (reinterpret_cast<uintptr_t>(v) % 16 == 0) &&
                    nnz >= 8;
   p->last_use = ++g_use_clock;
+  p->guard_slot = guard_acquire(dev, &p->A.guard, &p->A.stale);
+  if (p->guard_slot >= 0) {
+    launch_guard_fill(g_stream, rp, m, const_cast<int *>(p->A.guard));
+    if (!hip_ok(hipStreamSynchronize(g_stream), "record the plan guard")) return nullptr; // (a later call may use another stream)
+  }
   g_plans[key] = p;
   return p;
 }
 
-bool ensure_flat(Plan &p, hipStream_t stream) {
-  const int npt = tun(kT_flat_npt);
-  const int stride = kThreads * ((npt == 4 || npt == 16) ? npt : kNnzPerThread);
-  if (p.flat_tiles >= 0 && p.flat.stride == stride) return true;
-  p.free_flat();
-  const int nnz = p.A.nnz;
+bool report_stale_plans() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
+    if (it->second->is_stale()) {
+      set_error(kErrBadArgument,
+                "the matrix behind a cached plan changed (same pointers and shape, different rowptr) without "
+                "spmv_acc_release_plans: the last result on it is invalid; the plan has been dropped");
+      g_plans.erase(it);
+      return true;
+    }
+  }
+  return false;
+}
+
+// Break points, carry buffers and the two plan-time probes of a flat plan with `stride` non-zeros per tile.
+bool build_flat_plan(const CsrDev &A, int stride, hipStream_t stream, FlatPlan &F) {
+  ++t_plan_work;
+  Plan::free_flat_plan(F);
+  const int nnz = A.nnz;
   const int tiles = nnz / stride + (nnz % stride ? 1 : 0);
   const size_t n1 = static_cast<size_t>(tiles) + 1;
-  FlatPlan &F = p.flat;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.bp), sizeof(int) * n1), "hipMalloc break points") ||
       !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.head), sizeof(double) * n1), "hipMalloc head carries") ||
       !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail), sizeof(double) * n1), "hipMalloc tail carries") ||
       !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail_row), sizeof(int) * n1), "hipMalloc tail rows") ||
       !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail_end), sizeof(int) * n1), "hipMalloc tail ends")) {
-    p.free_flat(); // nothing half-built stays behind
+    Plan::free_flat_plan(F); // nothing half-built stays behind
     return false;
   }
   F.stride = stride;
   F.ntiles = tiles;
-  launch_break_points(stream, p.A.rp, p.A.m, nnz, stride, F.bp, static_cast<int>(n1));
+  launch_break_points(stream, A.rp, A.m, nnz, stride, F.bp, static_cast<int>(n1));
   // does this matrix need the carry fix-up kernel at all? (only rows longer than a tile's finishing reach do)
   int *d_flag = nullptr;
   int h_flag[2] = {1, 0};
-  if (hip_ok(hipMalloc(reinterpret_cast<void **>(&d_flag), 2 * sizeof(int)), "hipMalloc flat flag")) {
-    if (hip_ok(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), stream), "memset flat flag")) {
-      launch_flat_needs_fixup(stream, p.A, F, d_flag);
-      if (!hip_ok(hipMemcpyAsync(h_flag, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, stream), "read flat flag") ||
-          !hip_ok(hipStreamSynchronize(stream), "sync flat flag")) {
-        h_flag[0] = 1;
-        h_flag[1] = 0;
-      }
-    }
-    (void)hipFree(d_flag);
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d_flag), 2 * sizeof(int)), "hipMalloc flat flag")) {
+    Plan::free_flat_plan(F);
+    return false;
+  }
+  bool probed = hip_ok(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), stream), "memset flat flag");
+  if (probed) {
+    launch_flat_needs_fixup(stream, A, F, d_flag);
+    probed = hip_ok(hipMemcpyAsync(h_flag, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, stream), "read flat flag") &&
+             hip_ok(hipStreamSynchronize(stream), "sync flat flag");
+  }
+  (void)hipFree(d_flag);
+  if (!probed) { // no probe result, an error is recorded: do not compute on guesses
+    Plan::free_flat_plan(F);
+    return false;
   }
   F.max_tile_rows = h_flag[1];
   F.can_finish = h_flag[0] == 0;
   F.needs_fixup = true; // until run_flat has timed both forms on this matrix
   F.mode_tuned = false;
-  p.flat_tiles = tiles;
+  return true;
+}
+
+// Matrices below this many non-zeros launch grids of a few workgroups per CU, where a tile kernel's chain of round trips is
+// not hidden by other workgroups: there the tile size and the stream-first staging are timed per matrix as well.
+constexpr int kFlatSmallNnz = 24 << 20;
+
+int flat_stride_for(const Plan &p) {
+  int npt = tun(kT_flat_npt);
+  if (npt < 0) npt = p.flat_npt_choice > 0 ? p.flat_npt_choice : kNnzPerThread;
+  return kThreads * ((npt == 4 || npt == 16) ? npt : kNnzPerThread);
+}
+
+bool ensure_flat(Plan &p, hipStream_t stream) {
+  const int stride = flat_stride_for(p);
+  if (p.flat_tiles >= 0 && p.flat.stride == stride) return true;
+  p.flat_tiles = -1;
+  if (!build_flat_plan(p.A, stride, stream, p.flat)) return false;
+  p.flat_tiles = p.flat.ntiles;
   return true;
 }
 
@@ -568,7 +713,8 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) 
   const int want_vec =
       tun(kT_plus_ref_vec) ? plus_pick_vec(p.A.m, p.A.nnz) : plus_pick_vec_tuned(p.A.m, p.A.nnz, min_nnz);
   if (p.plus_blocks >= 0 && p.plus_vec == want_vec && p.plus_min == min_nnz) return true;
-  if (p.plus_blocks >= 0) { // analysis parameters changed (measurement switch): rebuild
+  ++t_plan_work;
+  auto drop_tables = [&p] { // also the exit of every failure below: nothing half-built stays behind
     if (p.d_pbp) (void)hipFree(p.d_pbp);
     if (p.d_pfbr) (void)hipFree(p.d_pfbr);
     if (p.d_ppartial) (void)hipFree(p.d_ppartial);
@@ -577,7 +723,9 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) 
     p.d_pbp = p.d_pfbr = nullptr;
     p.d_ppartial = nullptr;
     p.plus_blocks = -1;
-  }
+    return false;
+  };
+  if (p.plus_blocks >= 0) (void)drop_tables(); // analysis parameters changed (measurement switch): rebuild
   // The reference picks VEC_SIZE = pow2 >= avg/2 (plus_pick_vec), which caps a block at THREADS/VEC rows and closes
   // most blocks far below MIN_NNZ_PER_BLOCK.  The analysis is the same function; only its row cap is chosen so
   // that cap * avg >= 1.25 * MIN_NNZ (blocks then close on their non-zero count).
@@ -597,13 +745,12 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) 
     }
     std::vector<int> bp, fbr;
     blocks = plus_analyze_host(m, min_nnz, kPlusThreads, vec, hrp, bp, fbr);
-    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pbp), sizeof(int) * bp.size()), "hipMalloc plus bp")) return false;
-    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pfbr), sizeof(int) * fbr.size()), "hipMalloc plus fbr"))
-      return false;
     // blocking copies: the host vectors die at scope exit (this runs once per matrix)
-    if (!hip_ok(hipMemcpy(p.d_pbp, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice), "copy plus bp")) return false;
-    if (!hip_ok(hipMemcpy(p.d_pfbr, fbr.data(), sizeof(int) * fbr.size(), hipMemcpyHostToDevice), "copy plus fbr"))
-      return false;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pbp), sizeof(int) * bp.size()), "hipMalloc plus bp") ||
+        !hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_pfbr), sizeof(int) * fbr.size()), "hipMalloc plus fbr") ||
+        !hip_ok(hipMemcpy(p.d_pbp, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice), "copy plus bp") ||
+        !hip_ok(hipMemcpy(p.d_pfbr, fbr.data(), sizeof(int) * fbr.size(), hipMemcpyHostToDevice), "copy plus fbr"))
+      return drop_tables();
   } else {
     // device form: no host rowptr, no PCIe traffic beyond one int
     blocks = analyze_on_device(stream, p.A.rp, m, min_nnz, kPlusThreads, vec, &p.d_pbp, &p.d_pfbr);
@@ -611,10 +758,10 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) 
   }
   int *d_flag = nullptr;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_ppartial), sizeof(double) * (static_cast<size_t>(blocks) + 1)),
-              "hipMalloc plus partial"))
-    return false;
-  if (!hip_ok(hipMalloc(&p.d_pblk, 16 * (static_cast<size_t>(blocks) + 1)), "hipMalloc plus digest")) return false;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d_flag), sizeof(int)), "hipMalloc plus flag")) return false;
+              "hipMalloc plus partial") ||
+      !hip_ok(hipMalloc(&p.d_pblk, 16 * (static_cast<size_t>(blocks) + 1)), "hipMalloc plus digest") ||
+      !hip_ok(hipMalloc(reinterpret_cast<void **>(&d_flag), sizeof(int)), "hipMalloc plus flag"))
+    return drop_tables();
   int has_long = 0;
   bool ok = hip_ok(hipMemsetAsync(d_flag, 0, sizeof(int), stream), "memset plus flag");
   if (ok) {
@@ -623,7 +770,7 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) 
          hip_ok(hipStreamSynchronize(stream), "sync plus digest");
   }
   (void)hipFree(d_flag);
-  if (!ok) return false;
+  if (!ok) return drop_tables();
   p.plus_vec = vec;
   p.plus_min = min_nnz;
   p.plus_blocks = blocks;
@@ -631,10 +778,10 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) 
   return true;
 }
 
-int policy_for(const Plan &p) {
+int policy_for(const Plan &p, int fam) {
   const int forced = tun(kT_stream_plain);
   if (forced >= 0) return forced & 3;
-  return p.stream_policy >= 0 ? p.stream_policy : kStreamPolicyNt;
+  return p.stream_policy[fam] >= 0 ? p.stream_policy[fam] : kStreamPolicyNt;
 }
 
 // While adaptive compares the families it runs each with its default sub-choices (flat: carries + fix-up unless pinned;
@@ -675,11 +822,10 @@ struct TuneTimer {
 // Time the stream-load cache policies on THIS matrix with the kernel family that will run it (scratch y, beta = 0:
 // no side effects on the caller's y) and keep the fastest.  Up to eight launches per candidate (TuneTimer: 3 to reach
 // that policy's cache steady state + 5 timed; 2 in all when a launch takes milliseconds), once per matrix.
-template <typename Launch> bool autotune_policy(Plan &p, hipStream_t st, Launch &&launch) {
-  if (p.stream_policy >= 0 || tun(kT_stream_plain) >= 0) {
-    if (p.stream_policy < 0) p.stream_policy = kStreamPolicyNt;
-    return true;
-  }
+template <typename Launch> bool autotune_policy(Plan &p, int fam, hipStream_t st, Launch &&launch) {
+  if (p.stream_policy[fam] >= 0) return true;
+  if (tun(kT_stream_plain) >= 0) return true; // pinned (A/B runs): policy_for follows the tunable, nothing is recorded
+  ++t_plan_work;
   double *scratch = nullptr;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
     return false;
@@ -699,14 +845,20 @@ template <typename Launch> bool autotune_policy(Plan &p, hipStream_t st, Launch 
     }
   }
   (void)hipFree(scratch);
-  if (ok) p.stream_policy = best_policy;
+  if (ok) p.stream_policy[fam] = best_policy;
   return ok;
 }
 
+void launch_flat_plan(hipStream_t st, const CsrDev &A, FlatPlan &F, int policy, double alpha, double beta, const double *x,
+                      double *y) {
+  F.xcd_chunk = tun(kT_stage_fast) ? tun(kT_xcd_chunk_tiles) : -1; // -1: per-lane predicated staging (A/B)
+  F.stream_policy = policy;
+  const int early = tun(kT_flat_early);
+  if (early >= 0) F.early_stream = early != 0; // pinned (A/B runs); otherwise the plan's timed choice
+  launch_flat(st, A, F, alpha, beta, x, y);
+}
 void launch_flat_with(hipStream_t st, Plan &p, int policy, double alpha, double beta, const double *x, double *y) {
-  p.flat.xcd_chunk = tun(kT_stage_fast) ? tun(kT_xcd_chunk_tiles) : -1; // -1: per-lane predicated staging (A/B)
-  p.flat.stream_policy = policy;
-  launch_flat(st, p.A, p.flat, alpha, beta, x, y);
+  launch_flat_plan(st, p.A, p.flat, policy, alpha, beta, x, y);
 }
 
 // Cut rows of a flat plan without long overhangs can be folded two ways (kernels.hpp kFlatFinish).  Which is faster
@@ -727,10 +879,11 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
     F.needs_fixup = F.tuned_fixup;
     return true;
   }
-  if (t_coarse_tuning) {
+  if (t_coarse_tuning && p.A.nnz >= kFlatSmallNnz) { // (small matrices: the timings are cheap and decide the comparison)
     F.needs_fixup = true;
     return true;
   }
+  ++t_plan_work;
   double *scratch = nullptr;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
     return false;
@@ -739,11 +892,72 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
   float ms[2] = {0.f, 0.f};
   for (int mode = 0; ok && mode < 2; ++mode) {
     F.needs_fixup = mode == 0;
-    ok = timer.time(st, [&] { launch_flat_with(st, p, policy_for(p), 1.0, 0.0, x, scratch); }, &ms[mode]);
+    ok = timer.time(st, [&] { launch_flat_with(st, p, policy_for(p, kFamFlat), 1.0, 0.0, x, scratch); }, &ms[mode]);
   }
   (void)hipFree(scratch);
   F.tuned_fixup = F.needs_fixup = !(ok && ms[1] < ms[0]);
   F.mode_tuned = ok;
+  return ok;
+}
+
+// Small grids (kFlatSmallNnz): time {this tile size, the other one} x {stream loads first, break-point chain first} once
+// per matrix and keep the fastest.  The other tile size gets its own break points / carries; its cut rows are finished in
+// the tile whenever that is legal (no second launch: what wins on short kernels).
+bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
+  if (p.flat_geometry_tuned) return true;
+  if (p.A.nnz >= kFlatSmallNnz || p.flat.ntiles <= 1) {
+    p.flat_geometry_tuned = true;
+    return true;
+  }
+  const bool time_npt = tun(kT_flat_npt) < 0, time_early = tun(kT_flat_early) < 0;
+  if (!time_npt && !time_early) return true; // pinned (A/B runs)
+  ++t_plan_work;
+  double *scratch = nullptr;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
+    return false;
+  TuneTimer timer;
+  bool ok = timer.ok;
+  const int pol = policy_for(p, kFamFlat);
+  FlatPlan alt;
+  FlatPlan *plans[2] = {&p.flat, nullptr};
+  if (ok && time_npt) {
+    const int other = p.flat.stride == kThreads * 4 ? kThreads * kNnzPerThread : kThreads * 4;
+    ok = build_flat_plan(p.A, other, st, alt);
+    if (ok) {
+      alt.needs_fixup = alt.tuned_fixup = !alt.can_finish;
+      alt.mode_tuned = true;
+      plans[1] = &alt;
+    }
+  }
+  float best = 1e30f;
+  int best_plan = 0;
+  bool best_early = false;
+  for (int k = 0; ok && k < 2; ++k) {
+    if (!plans[k]) continue;
+    for (int e = 0; ok && e < (time_early ? 2 : 1); ++e) {
+      plans[k]->early_stream = time_early ? e != 0 : plans[k]->early_stream;
+      float ms = 0.f;
+      ok = timer.time(st, [&] { launch_flat_plan(st, p.A, *plans[k], pol, 1.0, 0.0, x, scratch); }, &ms);
+      if (ok && ms < best) {
+        best = ms;
+        best_plan = k;
+        best_early = plans[k]->early_stream;
+      }
+    }
+  }
+  (void)hipFree(scratch);
+  if (ok) {
+    if (best_plan == 1) {
+      Plan::free_flat_plan(p.flat);
+      p.flat = alt;
+      alt = FlatPlan(); // ownership moved
+      p.flat_tiles = p.flat.ntiles;
+    }
+    p.flat.early_stream = best_early;
+    p.flat_npt_choice = p.flat.stride / kThreads;
+    p.flat_geometry_tuned = true;
+  }
+  Plan::free_flat_plan(alt);
   return ok;
 }
 
@@ -762,9 +976,10 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
     // such tiles has no row-block imbalance of the hub-row kind)
     if (!(tun(kT_rescue_flat) && p.rowblock_ok == 0)) return run_rowblock(st, p, nullptr, alpha, beta, x, y, false);
   }
-  if (!autotune_policy(p, st, [&](int pol, double *ys) { launch_flat_with(st, p, pol, 1.0, 0.0, x, ys); })) return false;
+  if (!autotune_policy(p, kFamFlat, st, [&](int pol, double *ys) { launch_flat_with(st, p, pol, 1.0, 0.0, x, ys); })) return false;
   if (!autotune_flat_mode(p, st, x)) return false;
-  launch_flat_with(st, p, policy_for(p), alpha, beta, x, y);
+  if (!autotune_flat_geometry(p, st, x)) return false;
+  launch_flat_with(st, p, policy_for(p, kFamFlat), alpha, beta, x, y);
   return true;
 }
 
@@ -772,6 +987,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
 // and every later call (until its plan is released) instead of sending a kernel out of bounds.
 bool validate_plan(Plan &p, hipStream_t st) {
   if (p.invalid < 0) {
+    ++t_plan_work;
     int *d_flags = nullptr;
     int h = -1;
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d_flags), sizeof(int)), "hipMalloc validate")) return false;
@@ -800,6 +1016,7 @@ bool validate_plan(Plan &p, hipStream_t st) {
 // (power-law matrices: R-MAT hub rows put millions of non-zeros into one workgroup.)
 bool probe_rowblock(Plan &p, int rpb, hipStream_t st) {
   if (p.rowblock_ok >= 0 && p.rowblock_rpb == rpb) return true;
+  ++t_plan_work;
   p.rowblock_rpb = rpb;
   int *d_max = nullptr;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d_max), 2 * sizeof(int)), "hipMalloc probe")) return false;
@@ -826,6 +1043,26 @@ bool probe_rowblock(Plan &p, int rpb, hipStream_t st) {
   }
   (void)hipFree(d_max);
   return ok;
+}
+
+// Row digest of the row-block family (kernels.hpp RowDigest): derived from rowptr alone, like everything else a plan holds.
+bool ensure_digest(Plan &p, int rpb, hipStream_t st) {
+  if (p.digest.lens && p.digest.rpb == rpb) return true;
+  ++t_plan_work;
+  p.free_digest();
+  const size_t nblocks = (static_cast<size_t>(p.A.m) + rpb - 1) / rpb;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p.digest.lens), static_cast<size_t>(p.A.m)), "hipMalloc row lengths") ||
+      !hip_ok(hipMalloc(reinterpret_cast<void **>(&p.digest.base), sizeof(int) * (nblocks + 1)), "hipMalloc row-block bases")) {
+    p.free_digest();
+    return false;
+  }
+  launch_row_digest(st, p.A.rp, p.A.m, rpb, p.digest.lens, p.digest.base);
+  if (!hip_ok(hipStreamSynchronize(st), "build the row digest")) { // (a later call may run on another stream)
+    p.free_digest();
+    return false;
+  }
+  p.digest.rpb = rpb;
+  return true;
 }
 
 // line-enhance family with its imbalance rescue: fixed row blocks while every block stays within a
@@ -855,14 +1092,20 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
     // the engine.  line / line-enhance / thread_row keep their fixed row blocks.
     if (p.rowblock_uneven && allow_uneven_switch && !tun(kT_rescue_flat)) return run_plus(st, p, h_rowptr, alpha, beta, x, y);
   }
+  const RowDigest *dg = nullptr;
+  const int want_lens = tun(kT_rowlen);
+  if (want_lens > 0 || (want_lens < 0 && static_cast<long long>(p.A.nnz) <= 16LL * p.A.m)) {
+    if (!ensure_digest(p, rpb, st)) return false;
+    dg = &p.digest;
+  }
   const int chunk = tun(kT_xcd_chunk);
   const int base_flags = (tun(kT_xcd_remap) ? 1 : 0) | (tun(kT_early_y) ? 2 : 0) |
                          (chunk > 0 ? (4 | (chunk << 8)) : 0) | (tun(kT_stage_fast) ? 0 : 8);
-  if (!autotune_policy(p, st, [&](int pol, double *ys) {
-        launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (pol << 4), 1.0, 0.0, x, ys);
+  if (!autotune_policy(p, kFamRowblock, st, [&](int pol, double *ys) {
+        launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (pol << 4), 1.0, 0.0, x, ys, dg);
       }))
     return false;
-  launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p) << 4), alpha, beta, x, y);
+  launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p, kFamRowblock) << 4), alpha, beta, x, y, dg);
   return true;
 }
 
@@ -877,14 +1120,14 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
   };
   const int forced = tun(kT_plus_min_nnz);
   if (forced > 0 || tun(kT_plus_ref_vec)) {
-    return ensure_plus(p, h_rowptr, st, forced > 0 ? forced : kPlusMinNnz) && autotune_policy(p, st, launch);
+    return ensure_plus(p, h_rowptr, st, forced > 0 ? forced : kPlusMinNnz) && autotune_policy(p, kFamPlus, st, launch);
   }
-  if (p.plus_tuned_min > 0) return ensure_plus(p, h_rowptr, st, p.plus_tuned_min) && autotune_policy(p, st, launch);
+  if (p.plus_tuned_min > 0) return ensure_plus(p, h_rowptr, st, p.plus_tuned_min) && autotune_policy(p, kFamPlus, st, launch);
   // (coarse: 1024 where the balance probe found hub rows -- the block size that wins on power-law matrices -- else 1536)
   if (t_coarse_tuning)
-    return ensure_plus(p, h_rowptr, st, p.rowblock_ok == 0 ? kPlusMinNnz : 1536) && autotune_policy(p, st, launch);
+    return ensure_plus(p, h_rowptr, st, p.rowblock_ok == 0 ? kPlusMinNnz : 1536) && autotune_policy(p, kFamPlus, st, launch);
   // first call on this matrix: cache policy on the middle candidate, then the three block sizes under that policy
-  if (!ensure_plus(p, h_rowptr, st, 1536) || !autotune_policy(p, st, launch)) return false;
+  if (!ensure_plus(p, h_rowptr, st, 1536) || !autotune_policy(p, kFamPlus, st, launch)) return false;
   double *scratch = nullptr;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
     return false;
@@ -897,7 +1140,7 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
     ok = ensure_plus(p, h_rowptr, st, candidates[c]);
     if (!ok) break;
     float ms = 0.f;
-    ok = timer.time(st, [&] { launch(policy_for(p), scratch); }, &ms);
+    ok = timer.time(st, [&] { launch(policy_for(p, kFamPlus), scratch); }, &ms);
     if (ok && ms < best) {
       best = ms;
       best_min = candidates[c];
@@ -912,7 +1155,7 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
 bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y) {
   if (!run_plus_prepare(p, h_rowptr, st, x)) return false;
   launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk_tiles),
-              policy_for(p), p.d_ppartial, alpha, beta, x, y);
+              policy_for(p, kFamPlus), p.d_ppartial, alpha, beta, x, y);
   return true;
 }
 
@@ -931,6 +1174,7 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
     }
   };
   if (p.adaptive_family < 0) {
+    ++t_plan_work;
     double *scratch = nullptr;
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
       return false;
@@ -985,7 +1229,24 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   }
   const std::shared_ptr<Plan> p = get_plan(m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value);
   if (!p) return;
+  // one call at a time per matrix: plan fields, the per-matrix timings and the carry buffers of flat / row-block-plus belong
+  // to the plan (two host threads on DIFFERENT matrices do not meet here; this lock is never held together with g_mu)
+  std::lock_guard<std::mutex> plan_lock(p->mu);
+  // What the reference's harness calls `pre` (its per-call break-point / analysis cost, benchmark_time.cpp:23-43) is paid here
+  // by the FIRST call on a matrix: structural passes + per-matrix timings, all of which end in a synchronisation, so the host
+  // time from here to the return of that call is the preparation time (the final launch itself is asynchronous).
+  // A later call that builds another family's plan (first flat call after adaptive-plus calls, a changed tunable) counts too.
+  struct PrepareClock {
+    unsigned work0;
+    std::chrono::steady_clock::time_point t0;
+    ~PrepareClock() {
+      t_last_prepare_us =
+          t_plan_work != work0 ? std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() : 0.0;
+    }
+  } prepare_clock{t_plan_work, std::chrono::steady_clock::now()};
+  if (p->calls++ == 0) ++t_plan_work; // the plan itself (nnz / guard samples) was just made by get_plan
   hipStream_t st = g_stream;
+  (void)hipGetLastError(); // errors of earlier, unrelated HIP calls of this thread are not this call's
 
   if (p->A.nnz == 0) {
     launch_scale_y(st, m, beta, dy);
@@ -1067,6 +1328,10 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     set_error(kErrUnknownStrategy, "unknown strategy id");
     break;
   }
+  // a launch that failed (bad grid, no code object for this device) leaves y untouched: say so
+  const hipError_t launch_err = hipGetLastError();
+  if (launch_err != hipSuccess && last_error_code_only() == kOk)
+    set_error(kErrHip, std::string("kernel launch failed: ") + hipGetErrorString(launch_err));
 }
 
 void release_plans(const int *d_rowptr) {
@@ -1093,7 +1358,11 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->flat_tiles = p.flat_tiles;
       out->plus_blocks = p.plus_blocks;
       out->aligned16 = p.A.aligned16 ? 1 : 0;
-      out->stream_policy = p.stream_policy;
+      // the policy of the family that runs this matrix: adaptive's choice if it was timed, else the first family tuned
+      int fam = p.adaptive_family >= 0 ? p.adaptive_family : -1;
+      for (int f = 0; fam < 0 && f < kFamilyCount; ++f)
+        if (p.stream_policy[f] >= 0) fam = f;
+      out->stream_policy = fam >= 0 ? p.stream_policy[fam] : -1;
       out->flat_fixup = p.flat_tiles > 0 ? (p.flat.needs_fixup ? 1 : 0) : -1;
       out->adaptive_family = p.adaptive_family;
       return true;

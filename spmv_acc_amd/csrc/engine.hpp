@@ -54,6 +54,10 @@ int set_tunable(const char *name, int value);
 int get_tunable(const char *name);
 void reset_tunables();
 
+// Host microseconds the calling thread's most recent run_spmv spent preparing its matrix (plan build + per-matrix timings);
+// 0 when the plan already existed.
+double last_prepare_us();
+
 void set_stream(hipStream_t s);
 hipStream_t get_stream();
 

@@ -57,7 +57,7 @@ __device__ __forceinline__ int tile_end_excl(const int *__restrict__ rp, const i
   return (e < m && rp[e] < t1) ? e + 1 : e;
 }
 
-template <int NPT, bool NTC, bool NTV>
+template <int NPT, bool NTC, bool NTV, bool EARLY>
 __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int ntiles, double alpha, double beta,
                                                              const int *__restrict__ rp, const int *__restrict__ bp,
                                                              const int *__restrict__ ci,
@@ -65,7 +65,9 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
                                                              const double *__restrict__ x, double *__restrict__ y,
                                                              double *__restrict__ head, double *__restrict__ tail,
                                                              int *__restrict__ tail_row, int *__restrict__ tail_end,
-                                                             int xcd_chunk, int reach) {
+                                                             int xcd_chunk, int reach,
+                                                             const int *__restrict__ guard, int *__restrict__ stale) {
+  check_plan_guard(rp, m, guard, stale);
   // reach: a tile finishes its last row itself when it ends at most `reach` (0 or kFlatFinish) non-zeros past the tile
   constexpr int STRIDE = kThreads * NPT;
   static_assert(STRIDE / 64 <= kTileSpans, "TileSpans must hold every >= 64-product span of one tile");
@@ -80,6 +82,12 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
   const int t = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, ntiles, xcd_chunk) : static_cast<int>(blockIdx.x);
   const int t0 = t * STRIDE; // host guarantees nnz + stride fits in int
   const int t1 = (nnz - t0 > STRIDE) ? t0 + STRIDE : nnz;
+
+  // EARLY (chosen by timing on small grids, engine.cpp): the tile's stream loads go out before anything else, so the
+  // break point -> rowptr chain below overlaps them instead of preceding them.
+  StreamRegs<EARLY ? NPT : 4> early_regs;
+  const bool early = EARLY && xcd_chunk >= 0 && stage_fast_ok(t1, nnz); // (block-uniform)
+  if (EARLY && early) stage_issue<kThreads, EARLY ? NPT : 4, NTC, NTV>(early_regs, t0, t1, ci, v);
 
   // The tile's row range first (scalar chain bp -> rowptr), then each lane group's row extents and old y, THEN the
   // stream: the reduction after the barrier finds everything in registers (no global latency follows the barrier on the
@@ -107,7 +115,8 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
   double y_old0 = 0.0;
   if (early_y && live0 && lane == 0) y_old0 = y[first + vec_id]; // read for cut rows too (<= 2 per tile): harmless
 
-  stage_products<kThreads, NPT, NTC, NTV>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
+  if (EARLY && early) stage_finish<kThreads, EARLY ? NPT : 4>(lds, early_regs, x);
+  else stage_products<kThreads, NPT, NTC, NTV>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
 
   __syncthreads();
 
@@ -241,9 +250,24 @@ namespace {
 template <int NPT, bool NTC, bool NTV>
 void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                          double *y) {
-  hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
-                     P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish);
+  if (P.early_stream)
+    hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
+                       P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale);
+  else
+    hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
+                       P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale);
+}
+template <int NPT>
+void launch_flat_policy(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
+                        double *y) {
+  switch (P.stream_policy & 3) { // cache policy of the stream loads, see kernels.hpp
+  case 1: launch_flat_variant<NPT, false, false>(stream, A, P, alpha, beta, x, y); break;
+  case 2: launch_flat_variant<NPT, false, true>(stream, A, P, alpha, beta, x, y); break;
+  case 3: launch_flat_variant<NPT, true, false>(stream, A, P, alpha, beta, x, y); break;
+  default: launch_flat_variant<NPT, true, true>(stream, A, P, alpha, beta, x, y); break;
+  }
 }
 } // namespace
 
@@ -257,18 +281,9 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
                  double *y) {
   if (P.ntiles <= 0) return;
   const int npt = P.stride / kThreads;
-  if (npt == 4) {
-    launch_flat_variant<4, true, true>(stream, A, P, alpha, beta, x, y);
-  } else if (npt == 16) {
-    launch_flat_variant<16, true, true>(stream, A, P, alpha, beta, x, y);
-  } else {
-    switch (P.stream_policy & 3) { // cache policy of the stream loads, see kernels.hpp
-    case 1: launch_flat_variant<8, false, false>(stream, A, P, alpha, beta, x, y); break;
-    case 2: launch_flat_variant<8, false, true>(stream, A, P, alpha, beta, x, y); break;
-    case 3: launch_flat_variant<8, true, false>(stream, A, P, alpha, beta, x, y); break;
-    default: launch_flat_variant<8, true, true>(stream, A, P, alpha, beta, x, y); break;
-    }
-  }
+  if (npt == 4) launch_flat_policy<4>(stream, A, P, alpha, beta, x, y);
+  else if (npt == 16) launch_flat_policy<16>(stream, A, P, alpha, beta, x, y);
+  else launch_flat_policy<8>(stream, A, P, alpha, beta, x, y);
   if (P.ntiles > 1 && P.needs_fixup) {
     hipLaunchKernelGGL(flat_fixup_kernel, dim3((P.ntiles - 1 + 255) / 256), dim3(256), 0, stream, P.ntiles, P.stride,
                        alpha, beta, P.head, P.tail, P.tail_row, P.tail_end, y);

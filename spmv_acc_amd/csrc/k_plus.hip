@@ -73,7 +73,9 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
                                                         const int4v *__restrict__ blk, const int *__restrict__ rp,
                                                         const int *__restrict__ ci, const double *__restrict__ v,
                                                         const double *__restrict__ x, double *__restrict__ y,
-                                                        double *__restrict__ partial) {
+                                                        double *__restrict__ partial, int m,
+                                                        const int *__restrict__ guard, int *__restrict__ stale) {
+  check_plan_guard(rp, m, guard, stale);
   __shared__ __attribute__((aligned(16))) double lds[kPlusTile]; // written 16 B at a time
   __shared__ double row_acc[kPlusMaxRows];
   __shared__ TileSpans spans;
@@ -192,7 +194,7 @@ void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *
   if (nblocks <= 0) return;
 #define SPMV_ACC_LAUNCH_PLUS(NC, NV)                                                                                \
   hipLaunchKernelGGL((plus_kernel<NC, NV>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk,   \
-                     alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial)
+                     alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial, A.m, A.guard, A.stale)
   switch (stream_policy & 3) {
   case 1: SPMV_ACC_LAUNCH_PLUS(false, false); break;
   case 2: SPMV_ACC_LAUNCH_PLUS(false, true); break;

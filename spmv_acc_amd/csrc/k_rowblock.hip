@@ -25,14 +25,39 @@ namespace {
 
 using namespace dev;
 
-template <int VEC, bool NTC, bool NTV>
+// Row extents from the plan's row digest instead of rowptr (LENS): one byte per row (its length) and one int per row block
+// (the block's first non-zero; bit 31 set = some row of the block is longer than 255, the block then reads rowptr as usual).
+// A row's extent is the block's base plus a scan of the lengths: the lanes of a row all hold its length, the row's leader lane
+// feeds it into a wave scan (DPP row_shr + three lane reads), and the four waves' totals cross through LDS behind the barrier
+// that follows staging -- no barrier is added.  4 B/row of rowptr traffic become 1 B/row + 4 B/block: on the Hardesty3-sized
+// matrix (4.9 nnz/row) that is 24.6 MB of 710 MB per SpMV.
+template <int CTRL> __device__ __forceinline__ int dpp_shr_or_zero(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); // lanes without a source lane get 0
+}
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v += dpp_shr_or_zero<0x111>(v); // row_shr:1
+  v += dpp_shr_or_zero<0x112>(v); // row_shr:2
+  v += dpp_shr_or_zero<0x114>(v); // row_shr:4
+  v += dpp_shr_or_zero<0x118>(v); // row_shr:8 -> inclusive scan inside each row of 16 lanes
+  const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+  const int r = (threadIdx.x & (kWave - 1)) >> 4;
+  return v + (r > 0 ? t0 : 0) + (r > 1 ? t1 : 0) + (r > 2 ? t2 : 0);
+}
+
+template <int VEC, bool NTC, bool NTV, bool LENS>
 __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nnz, int nblocks, int rpb, int flags,
                                                                    double alpha, double beta,
                                                                    const int *__restrict__ rp,
                                                                    const int *__restrict__ ci,
                                                                    const double *__restrict__ v,
                                                                    const double *__restrict__ x,
-                                                                   double *__restrict__ y) {
+                                                                   double *__restrict__ y,
+                                                                   const int *__restrict__ guard,
+                                                                   int *__restrict__ stale,
+                                                                   const unsigned char *__restrict__ lens,
+                                                                   const int *__restrict__ base) {
+  check_plan_guard(rp, m, guard, stale);
+  __shared__ int wave_tot[kThreads / kWave];
   // rpb rows per workgroup, rpb <= kThreads / VEC (not necessarily a power of two: it is chosen so that
   // rpb * average row length fills most of one LDS tile)
   __shared__ __attribute__((aligned(16))) double lds[kTile]; // written 16 B at a time
@@ -47,14 +72,25 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   const int row_base = static_cast<int>(base_ll);
   const int row_end = (base_ll + rpb < m) ? row_base + rpb : m;
   // wave-uniform: the non-zero range of the whole block
-  const int s0 = rp[row_base];
-  const int s1 = rp[row_end];
+  int s0, s1;
+  bool from_lens = false;
+  if (LENS) {
+    const int b0 = base[b];
+    s0 = b0 & 0x7fffffff;
+    s1 = base[b + 1] & 0x7fffffff;
+    from_lens = b0 >= 0;
+  } else {
+    s0 = rp[row_base];
+    s1 = rp[row_end];
+  }
 
   const int lane = threadIdx.x % VEC;
   const int row = row_base + threadIdx.x / VEC;
   const bool live = row < row_end; // lanes beyond rpb * VEC only help staging
-  int r0 = 0, r1 = 0;
-  if (live) {
+  int r0 = 0, r1 = 0, len = 0;
+  if (LENS && from_lens) {
+    if (live) len = lens[row];
+  } else if (live) {
     r0 = rp[row];
     r1 = rp[row + 1];
   }
@@ -65,10 +101,23 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   if (early_y && writer) y_old = y[row];
 
   double acc = 0.0;
+  int incl = 0;
+  if (LENS && from_lens) { // (block-uniform branch; the scan needs every lane of the wave)
+    incl = wave_inclusive_scan(lane == 0 ? len : 0);
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1) wave_tot[threadIdx.x / kWave] = incl;
+  }
   // tile origin aligned down so 16-B loads stay aligned; the (at most 3) extra leading products are never read
   for (int off = s0 & ~3; off < s1; off += kTile) {
     stage_products<kThreads, kNnzPerThread, NTC, NTV>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0);
     __syncthreads();
+    if (LENS && from_lens && off == (s0 & ~3)) {
+      const int w = threadIdx.x / kWave;
+      int before = s0;
+#pragma unroll
+      for (int k = 0; k < kThreads / kWave - 1; ++k) before += (k < w) ? wave_tot[k] : 0;
+      r1 = before + incl; // lanes of one row hold the same inclusive sum: the row's leader is the row's first lane
+      r0 = r1 - len;
+    }
     const int lo = (r0 > off ? r0 : off) - off;
     const int hi = (r1 < off + kTile ? r1 : off + kTile) - off;
     acc += tile_row_sum<kThreads>(lds, spans, lo, hi > lo ? hi : lo, lane, VEC); // long spans go to whole waves
@@ -111,18 +160,45 @@ __global__ __launch_bounds__(256) void max_block_nnz_kernel(const int *__restric
   }
 }
 
+// Plan time: lens[r] = min(rowptr[r+1] - rowptr[r], 255); base[b] = rowptr[b * rpb], bit 31 set when a row of block b is
+// longer than 255 (base is initialised by the first kernel, flagged by the second).
+__global__ __launch_bounds__(256) void row_digest_base_kernel(const int *__restrict__ rp, int m, int rpb, int nblocks,
+                                                              int *__restrict__ base) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b > nblocks) return;
+  const long long r = static_cast<long long>(b) * rpb;
+  base[b] = rp[r < m ? r : m];
+}
+__global__ __launch_bounds__(256) void row_digest_lens_kernel(const int *__restrict__ rp, int m, int rpb,
+                                                              unsigned char *__restrict__ lens, int *__restrict__ base) {
+  const long long r = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (r >= m) return;
+  const int len = rp[r + 1] - rp[r];
+  lens[r] = static_cast<unsigned char>(len < 255 ? (len > 0 ? len : 0) : 255);
+  if (len > 255 || len < 0) atomicOr(base + r / rpb, static_cast<int>(0x80000000u));
+}
+
 template <int VEC>
-void launch_vec(hipStream_t stream, const CsrDev &A, int rpb, int xcd, double alpha, double beta, const double *x,
-                double *y) {
+void launch_vec(hipStream_t stream, const CsrDev &A, const RowDigest *D, int rpb, int xcd, double alpha, double beta,
+                const double *x, double *y) {
   if (rpb < 1 || rpb > kThreads / VEC) rpb = kThreads / VEC;
+  if (D && D->rpb != rpb) D = nullptr; // a digest built for another block size does not apply
   const int nblocks = static_cast<int>((static_cast<long long>(A.m) + rpb - 1) / rpb);
   if (nblocks == 0) return;
   const int remap = ((xcd & 1) && nblocks >= 64 ? 1 : 0) | (xcd & ~1);
   // bits 4-5 of the flags: cache policy of the stream loads (0 nt/nt, 1 plain/plain, 2 colindex plain + values nt,
   // 3 colindex nt + values plain)
 #define SPMV_ACC_LAUNCH_RB(NC, NV)                                                                                  \
-  hipLaunchKernelGGL((rowblock_stream_kernel<VEC, NC, NV>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz,  \
-                     nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y)
+  do {                                                                                                             \
+    if (D && D->lens)                                                                                              \
+      hipLaunchKernelGGL((rowblock_stream_kernel<VEC, NC, NV, true>), dim3(nblocks), dim3(kThreads), 0, stream,     \
+                         A.m, A.nnz, nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y, A.guard, A.stale,    \
+                         D->lens, D->base);                                                                        \
+    else                                                                                                           \
+      hipLaunchKernelGGL((rowblock_stream_kernel<VEC, NC, NV, false>), dim3(nblocks), dim3(kThreads), 0, stream,    \
+                         A.m, A.nnz, nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y, A.guard, A.stale,    \
+                         static_cast<const unsigned char *>(nullptr), static_cast<const int *>(nullptr));          \
+  } while (0)
   // one set of kernels for every base-pointer alignment: their 16-B loads go through under-aligned vector types
   // (device_utils.hpp), the same instruction with the same cache policy whether or not the caller's arrays are 16-B aligned
   switch ((xcd >> 4) & 3) {
@@ -143,16 +219,25 @@ void launch_max_block_nnz(hipStream_t stream, const int *rp, int m, int rows_per
                      nblocks, avg_block, d_out);
 }
 
+void launch_row_digest(hipStream_t stream, const int *rp, int m, int rows_per_block, unsigned char *lens, int *base) {
+  if (m <= 0 || rows_per_block <= 0) return;
+  const int nblocks = static_cast<int>((static_cast<long long>(m) + rows_per_block - 1) / rows_per_block);
+  hipLaunchKernelGGL(row_digest_base_kernel, dim3((nblocks + 1 + 255) / 256), dim3(256), 0, stream, rp, m, rows_per_block, nblocks,
+                     base);
+  hipLaunchKernelGGL(row_digest_lens_kernel, dim3(static_cast<unsigned>((static_cast<long long>(m) + 255) / 256)), dim3(256), 0,
+                     stream, rp, m, rows_per_block, lens, base);
+}
+
 void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, int rows_per_block, int xcd_remap,
-                            double alpha, double beta, const double *x, double *y) {
+                            double alpha, double beta, const double *x, double *y, const RowDigest *digest) {
   switch (vec) {
-  case 1: launch_vec<1>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
-  case 2: launch_vec<2>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
-  case 4: launch_vec<4>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
-  case 8: launch_vec<8>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
-  case 16: launch_vec<16>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
-  case 32: launch_vec<32>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
-  default: launch_vec<64>(stream, A, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  case 1: launch_vec<1>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  case 2: launch_vec<2>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  case 4: launch_vec<4>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  case 8: launch_vec<8>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  case 16: launch_vec<16>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  case 32: launch_vec<32>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  default: launch_vec<64>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
   }
 }
 

@@ -31,7 +31,9 @@ __global__ __launch_bounds__(kThreads) void vector_row_kernel(int m, int row_spl
                                                               double alpha, double beta,
                                                               const int *__restrict__ rp, const int *__restrict__ ci,
                                                               const double *__restrict__ v,
-                                                              const double *__restrict__ x, double *__restrict__ y) {
+                                                              const double *__restrict__ x, double *__restrict__ y,
+                                                              const int *__restrict__ guard, int *__restrict__ stale) {
+  check_plan_guard(rp, m, guard, stale);
   const bool second = static_cast<int>(blockIdx.x) >= nb0;
   const int w = second ? w1 : w0;
   const int groups = kThreads / w;
@@ -113,7 +115,9 @@ __global__ __launch_bounds__(kThreads) void vector_row_kernel(int m, int row_spl
 __global__ __launch_bounds__(kThreads) void wave_row_kernel(int m, int nnz, double alpha, double beta,
                                                             const int *__restrict__ rp, const int *__restrict__ ci,
                                                             const double *__restrict__ v,
-                                                            const double *__restrict__ x, double *__restrict__ y) {
+                                                            const double *__restrict__ x, double *__restrict__ y,
+                                                            const int *__restrict__ guard, int *__restrict__ stale) {
+  check_plan_guard(rp, m, guard, stale);
   const int lane = threadIdx.x & (kWave - 1);
   const long long row_ll = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave;
   const bool live = row_ll < m; // wave-uniform
@@ -164,6 +168,11 @@ __global__ __launch_bounds__(kThreads) void wave_row_kernel(int m, int nnz, doub
   }
   s = group_sum<64>(s);
   if (live && lane == 0) store_y(y, row, alpha, beta, s);
+}
+
+// the stale-plan guard's samples: rowptr[k * m / 63], k = 0 .. 63 (same indices as device_utils.hpp::check_plan_guard)
+__global__ __launch_bounds__(kWave) void guard_fill_kernel(const int *__restrict__ rp, int m, int *__restrict__ guard) {
+  guard[threadIdx.x] = rp[static_cast<int>(static_cast<long long>(threadIdx.x) * m / (kWave - 1))];
 }
 
 __global__ __launch_bounds__(kThreads) void scale_y_kernel(int m, double beta, double *__restrict__ y) {
@@ -230,17 +239,17 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
   if (nb0 + nb1 == 0) return;
   if (rows == 1)
     hipLaunchKernelGGL(vector_row_kernel<1>, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1, alpha, beta,
-                       A.rp, A.ci, A.v, x, y);
+                       A.rp, A.ci, A.v, x, y, A.guard, A.stale);
   else
     hipLaunchKernelGGL(vector_row_kernel<4>, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1, alpha, beta,
-                       A.rp, A.ci, A.v, x, y);
+                       A.rp, A.ci, A.v, x, y, A.guard, A.stale);
 }
 
 void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y) {
   if (A.m <= 0) return;
   const int grid = ceil_div_ll(A.m, kThreads / kWave);
   hipLaunchKernelGGL(wave_row_kernel, dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci, A.v,
-                     x, y);
+                     x, y, A.guard, A.stale);
 }
 
 void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes, bool non_temporal) {
@@ -263,6 +272,11 @@ void launch_validate_csr(hipStream_t stream, const CsrDev &A, int *d_flags) {
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(validate_csr_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, A.n,
                      A.nnz, d_flags);
+}
+
+void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard) {
+  static_assert(kGuardSamples == kWave, "one lane per sample");
+  hipLaunchKernelGGL(guard_fill_kernel, dim3(1), dim3(kWave), 0, stream, rp, m, d_guard);
 }
 
 void launch_scale_y(hipStream_t stream, int m, double beta, double *y) {

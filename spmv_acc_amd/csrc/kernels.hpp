@@ -16,7 +16,14 @@ struct CsrDev {
   const int *ci = nullptr;
   const double *v = nullptr;
   bool aligned16 = false; // ci and v are 16-byte aligned and nnz >= 8: wide-load kernels allowed
+  // Stale-plan guard (engine.cpp): kGuardSamples rowptr entries recorded when the plan was built (device array) and a
+  // sticky flag in pinned host memory.  The first wave of block 0 of every SpMV kernel re-reads the samples and raises
+  // the flag when the matrix behind these pointers is no longer the one the plan was built for.  Null: no check.
+  const int *guard = nullptr;
+  int *stale = nullptr;
 };
+constexpr int kGuardSamples = 64; // rowptr[k * m / 63], k = 0 .. 63 (includes rowptr[0] and rowptr[m] = nnz)
+void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard);
 
 // Cache policy of the 16-B colindex / value stream loads of the tile kernels.  Which one is fastest depends on the
 // matrix (A/B on MI355X: default-policy loads win by 7-27 % on FEM-like matrices -- part of the matrix then stays
@@ -50,8 +57,15 @@ void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double b
 // old y at kernel start instead of at the end, bit 2 XCD-chunked block order with chunk = flags >> 8,
 // bit 3 per-lane predicated staging (A/B), bits 4-5 cache policy of the stream loads (0 nt, 1 default, 2 colindex default +
 // values nt, 3 colindex nt + values default).
+// digest (may be null): plan-resident row lengths + per-block bases for THIS rows_per_block, read instead of rowptr.
+struct RowDigest {
+  int rpb = 0;                          // rows per block the bases were built for
+  unsigned char *lens = nullptr;        // m bytes: min(row length, 255)
+  int *base = nullptr;                  // nblocks + 1 ints: rowptr[b * rpb]; bit 31 = a row of the block is longer than 255
+};
 void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, int rows_per_block, int flags,
-                            double alpha, double beta, const double *x, double *y);
+                            double alpha, double beta, const double *x, double *y, const RowDigest *digest = nullptr);
+void launch_row_digest(hipStream_t stream, const int *rp, int m, int rows_per_block, unsigned char *lens, int *base);
 void pick_rowblock_shape(int m, int nnz, int target_products, int *vec, int *rows_per_block);
 
 // plan-time imbalance probe for the row-block family: *d_out (pre-zeroed) = max non-zeros owned by any
@@ -81,6 +95,7 @@ struct FlatPlan {
   bool needs_fixup = true;  // true: every cut row is folded from carries by the fix-up kernel; false (only when
                             // can_finish): tiles finish their cut rows themselves.  Chosen by timing, engine.cpp.
   int max_tile_rows = 0;    // most rows any one tile (= workgroup) owns (plan-time probe)
+  bool early_stream = false; // issue the tile's stream loads before the break point -> rowptr chain (small grids, timed)
   bool mode_tuned = false;  // tuned_fixup holds the timed choice
   bool tuned_fixup = true;
 };

@@ -126,6 +126,67 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
   }
 }
 
+// ---- split staging -----------------------------------------------------------------------------------------------------------
+// The same step in two halves, for kernels that want the tile's stream loads in flight BEFORE their own dependent scalar /
+// rowptr loads (flat on small grids: a tile kernel is a chain of round trips -- break point -> rowptr -> stream -> gather ->
+// LDS -> y -- and on a grid of one or two workgroups per CU nothing else hides them).  stage_issue starts the 16-B stream
+// loads of the branch-free form into registers; stage_finish gathers x, multiplies and writes the tile.  The price is
+// NPT/4 * 12 VGPRs held across whatever the caller does in between, which costs occupancy that only small grids can spare.
+// Only the branch-free form is split: callers test stage_fast_ok() and use stage_products() otherwise.
+__device__ __forceinline__ bool stage_fast_ok(int hi, int nnz) { return ((hi + 3) & ~3) <= nnz; }
+
+template <int NPT> struct StreamRegs {
+  int4v c[NPT / 4];
+  double2v va[NPT / 4], vb[NPT / 4];
+  bool has[NPT / 4]; // wave-uniform
+};
+
+template <int THREADS, int NPT, bool NTC, bool NTV>
+__device__ __forceinline__ void stage_issue(StreamRegs<NPT> &R, int a0, int hi, const int *__restrict__ ci,
+                                            const double *__restrict__ v) {
+#pragma unroll
+  for (int k = 0; k < NPT / 4; ++k) {
+    const int wave_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + k * THREADS));
+    R.has[k] = wave_j < hi;
+    if (R.has[k]) {
+      const int j = a0 + 4 * (threadIdx.x + k * THREADS);
+      const int jc = (j < hi) ? j : a0;
+      R.c[k] = load_stream_i4<NTC>(ci + jc);
+      R.va[k] = load_stream_d2<NTV>(v + jc);
+      R.vb[k] = load_stream_d2<NTV>(v + jc + 2);
+    }
+  }
+}
+
+template <int THREADS, int NPT>
+__device__ __forceinline__ void stage_finish(double *__restrict__ lds, const StreamRegs<NPT> &R, const double *__restrict__ x) {
+  constexpr int K = NPT / 4;
+  double xg[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (R.has[k]) {
+      xg[k][0] = x[R.c[k].x];
+      xg[k][1] = x[R.c[k].y];
+      xg[k][2] = x[R.c[k].z];
+      xg[k][3] = x[R.c[k].w];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (R.has[k]) {
+      const int g = threadIdx.x + k * THREADS;
+      double2v p0, p1;
+      p0.x = R.va[k].x * xg[k][0];
+      p0.y = R.va[k].y * xg[k][1];
+      p1.x = R.vb[k].x * xg[k][2];
+      p1.y = R.vb[k].y * xg[k][3];
+      double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
+      dst[0] = p0;
+      dst[1] = p1;
+    }
+  }
+}
+
 // ---- per-row sums over a staged tile ---------------------------------------------------------------------------------------
 // Every lane group (w lanes, w wave-uniform or compile-time) sums its row's span [lo, hi) of the tile.  A span of more than
 // max(63, 16 w) products would keep w lanes busy for dozens of dependent LDS reads while the rest of the workgroup idles (a

@@ -84,6 +84,14 @@ class RowShardedSpmv:
         self.y_full = torch.zeros(world * self.pad, dtype=torch.float64, device=device)
         self._pending = None
         self._k = 0
+        # On the GPU the local SpMV runs on its OWN (non-NULL) stream and is ordered against the exchange with events, both
+        # ways: the exchange of step k is issued after an event recorded behind SpMV k, and SpMV k+2 -- the next writer of
+        # the buffer that exchange reads -- is issued after the stream has waited for that exchange.  Nothing relies on the
+        # library's stream and torch's current stream being the same stream.
+        self._gpu = torch.device(device).type == "cuda"
+        self.compute_stream = torch.cuda.Stream(device=device) if self._gpu else None
+        self.spmv_done = None  # event behind the latest local SpMV (GPU only)
+        self.exchange_issued_after_spmv = None  # for tests: did the latest exchange wait for that event?
 
     def _hip_spmv(self, alpha, beta, x, y):
         spmv_acc_amd.csr_spmv(alpha, beta, self.m_local, self.n, self.nnz_local, self.rowptr, self.cols, self.vals, x, y,
@@ -91,18 +99,43 @@ class RowShardedSpmv:
 
     def step(self, alpha: float, beta: float, x, y_prev=None, group=None, overlap: bool = True):
         """One sharded SpMV.  ``y_prev`` (m_local values) is this rank's slice of the old y when beta != 0
-        (None: iterate in place on the step's y buffer, see ``set_y``).
+        (None: iterate in place -- step k reads the y step k-1 produced, starting from the slice given to ``set_y``).
         With ``overlap`` the allgather is left in flight; call ``wait()`` (or the next ``step``) to retire it."""
         import torch.distributed as dist
 
         buf = self.y_local[self._k & 1]
+        prev = self.y_local[(self._k & 1) ^ 1]
+        first = self._k == 0
         self._k += 1
-        if beta != 0.0 and y_prev is not None:
-            buf[: self.m_local].copy_(y_prev[: self.m_local])
-        # beta != 0 with y_prev None: the buffer's current content is the old y slice (in-place iteration)
-        if self.m_local > 0:
-            self.local_spmv(alpha, beta, x, buf)
-        self.wait()  # at most one allgather in flight: y_full is written by it
+
+        def local():
+            if beta != 0.0:
+                if y_prev is not None:
+                    buf[: self.m_local].copy_(y_prev[: self.m_local])
+                elif not first:
+                    # in-place iteration: the old y of step k is the RESULT of step k-1, which lives in the other buffer
+                    # (the two buffers alternate so that the exchange of k-1 can still be reading it: a read, like this copy)
+                    buf[: self.m_local].copy_(prev[: self.m_local])
+                # (first step: both buffers hold the slice set_y seeded)
+            if self.m_local > 0:
+                self.local_spmv(alpha, beta, x, buf)
+
+        if self._gpu:
+            torch = self.torch
+            cur = torch.cuda.current_stream(self.device)
+            cs = self.compute_stream
+            # x / y_prev were produced on the caller's stream; `buf` was last read by the exchange of step k-2, which the
+            # caller's stream has waited for (self.wait() of step k-1)
+            cs.wait_stream(cur)
+            with torch.cuda.stream(cs):  # the library follows torch's current stream (spmv_acc_amd._require)
+                local()
+                self.spmv_done = cs.record_event()
+            self.wait()  # at most one exchange in flight: y_full is written by it
+            cur.wait_event(self.spmv_done)  # the exchange (issued against the current stream) starts behind SpMV k
+            self.exchange_issued_after_spmv = True
+        else:
+            local()
+            self.wait()
         if self.world == 1 and not self.always_collective:
             self.y_full[: self.pad].copy_(buf)
             return None

@@ -188,6 +188,21 @@ def large_set_like_torch(name, device="cuda", seed=0xC300, scale=1.0):
     return (m, n, nnz) + structured_csr_torch(m, n, nnz, seed, device=device, far_fraction=0.02, spread=spread)
 
 
+SWEEP_NAMES = tuple(LARGE_SET) + tuple(LARGE_SET_EXTRA)  # BASELINE configs[2]: the 12 stand-ins, in sweep order
+
+
+def sweep_standin_torch(name, device="cuda"):
+    """The stand-in of BASELINE configs[2] called `name`, with the seed every consumer (tests, bench.py's `sweep` leg,
+    tools/sweep.py) uses: Hardesty3 is configs[1]'s matrix (10 % far columns), the others FEM-like with 2 %."""
+    i = SWEEP_NAMES.index(name)
+    if name == "Hardesty3":
+        return hardesty3_like_torch(device=device)
+    if name in LARGE_SET_EXTRA:
+        m, n, nnz = LARGE_SET_EXTRA[name]
+        return (m, n, nnz) + structured_csr_torch(m, n, nnz, 0xC30A + i, device=device, far_fraction=0.02, spread=[1, 1, 1, 2])
+    return large_set_like_torch(name, device=device, seed=0xC300 + i)
+
+
 def banded_torch(m, first_row=0, total_rows=None, device="cuda", offsets=(-4, -3, -2, -1, 0, 1, 2, 3)):
     """Shard rows [first_row, first_row+m) of the C5 banded matrix, built on the GPU."""
     import torch

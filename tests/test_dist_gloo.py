@@ -88,6 +88,57 @@ def test_row_sharded_spmv_world2(tmp_path, oracle, mode, m, world, exchange):
         assert np.array_equal(g[f"y{i}"], ref), (mode, alpha, beta)  # same arithmetic per row: bit-exact
 
 
+def _inplace_worker(rank, world, port, m, steps, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib
+    from spmv_acc_amd import synth
+    from spmv_acc_amd.dist import RowShardedSpmv, local_csr_slice, shard_bounds
+
+    rowptr, cols, vals = synth.random_csr(m, m, 6, seed=77, kind="uniform")
+    rng = np.random.default_rng(9)
+    x, y0 = rng.standard_normal(m), rng.standard_normal(m)
+    bounds = shard_bounds(m, world, mode=0)
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    rp, ci, v = (np.ascontiguousarray(a) for a in local_csr_slice(rowptr, cols, vals, r0, r1))
+
+    def local_spmv(alpha, beta, xt, yt):
+        oracle_lib.host_spmv_inplace(alpha, beta, rp, ci, v, xt.numpy(), yt.numpy()[: r1 - r0])
+
+    eng = RowShardedSpmv(rank, world, bounds, rp, ci, v, m, torch.device("cpu"), local_spmv=local_spmv)
+    eng.set_y(torch.from_numpy(y0[r0:r1].copy()))
+    xt = torch.from_numpy(x)
+    ys = []
+    for _ in range(steps):  # y <- 0.25 * A x + 0.5 * y, no y_prev: every step must read the y of the step before it
+        eng.step(0.25, 0.5, xt, overlap=True)
+        ys.append(eng.gathered().numpy().copy())
+    if rank == 0:
+        np.savez(out_path, **{f"y{i}": y for i, y in enumerate(ys)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_in_place_iteration_follows_the_serial_recurrence(tmp_path, oracle, world):
+    """beta != 0 without y_prev iterates in place: step k reads the y step k-1 wrote although the two y buffers alternate
+    (an earlier form read the y of step k-2)."""
+    from spmv_acc_amd import synth
+
+    m, steps = 3001, 4
+    out = str(tmp_path / "y.npz")
+    mp.spawn(_inplace_worker, args=(world, _free_port(), m, steps, out), nprocs=world, join=True)
+    g = np.load(out)
+    rowptr, cols, vals = synth.random_csr(m, m, 6, seed=77, kind="uniform")
+    rng = np.random.default_rng(9)
+    x, y = rng.standard_normal(m), rng.standard_normal(m)
+    for i in range(steps):
+        y = oracle.host_spmv(0.25, 0.5, rowptr, cols, vals, x, y)
+        assert np.array_equal(g[f"y{i}"], y), i
+
+
 def test_shard_helpers():
     from spmv_acc_amd import synth
     from spmv_acc_amd.dist import local_csr_slice, padded_shard_rows, shard_bounds

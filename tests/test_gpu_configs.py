@@ -1,0 +1,199 @@
+"""GPU suite (-m gpu), BASELINE.json configs[2..4] at FULL size through the C ABI.
+
+configs[2]  the 12 stand-ins of the large-data-set sweep (examples/large-data-set-batch.sh:24-52 dims + scircuit / af_shell10),
+            strategies flat (the one BASELINE names) and adaptive
+configs[3]  R-MAT scale 25, edge factor 16 (~0.53 B non-zeros), line_enhance
+configs[4]  one 32 M-row shard of the 256 M-row banded matrix (global column ids), adaptive / flat / line_enhance
+
+The CPU oracle cannot walk these sizes in seconds, so each matrix is checked three ways (the pattern of
+tests/test_gpu_parity.py::test_full_size_*):
+  * against the oracle (oracle_host_spmv = cli/verification.cpp:56-66) on a row PREFIX of the full-size run,
+  * against an independent fp64 evaluation on the device (products scattered with index_add, another summation order),
+    with the scaled-error gate and the reference's own verify_y rule (cli/verification.cpp:15-38),
+  * through size-independent properties: row sums for x = 1, linearity in x, y = alpha*(A x) + beta*y0.
+Tolerances as in test_gpu_parity.py: scaled error <= 1e-12, reference verdict rel 1e-7 / abs 1e-14.
+"""
+import numpy as np
+import pytest
+
+import spmv_acc_amd
+from spmv_acc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SCALED_TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def torch_dev(hiplib):
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _vectors(torch, m, n, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    x = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    y0 = torch.rand(m, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    return x, y0
+
+
+def _spmv(torch, A, strat, alpha, beta, x, y0):
+    m, n, nnz, rp, ci, v = A
+    y = y0.clone()
+    spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, rp, ci, v, x, y, strategy=strat)
+    torch.cuda.synchronize()
+    return y
+
+
+def _device_reference(torch, A, x):
+    """(A x, |A| |x|) in fp64 on the device, independent of the library: products scattered with index_add, chunked so the
+    int64 row ids of a 0.5 B-non-zero matrix never exist all at once."""
+    m, n, nnz, rp, ci, v = A
+    ax = torch.zeros(m, dtype=torch.float64, device="cuda")
+    mag = torch.zeros(m, dtype=torch.float64, device="cuda")
+    lens = (rp[1:] - rp[:-1]).long()
+    rp64 = rp.long()
+    step = 4_000_000  # rows per chunk
+    for r0 in range(0, m, step):
+        r1 = min(m, r0 + step)
+        s, e = int(rp64[r0].item()), int(rp64[r1].item())
+        if e == s:
+            continue
+        rows = torch.repeat_interleave(torch.arange(r0, r1, device="cuda"), lens[r0:r1], output_size=e - s)
+        prod = v[s:e] * x[ci[s:e].long()]
+        ax.index_add_(0, rows, prod)
+        mag.index_add_(0, rows, prod.abs())
+        del rows, prod
+    return ax, mag
+
+
+def _verify_y_failures(torch, got, ref):
+    """rows breaking the reference benchmark's rule (cli/verification.cpp:15-38), evaluated on the device"""
+    d = (got - ref).abs()
+    bad = torch.where(ref.abs() <= 1e-12, d >= 1e-14, d / ref.abs() >= 1e-7)
+    return int(bad.sum().item())
+
+
+def _prefix_vs_oracle(torch, oracle, A, strats, x, y0, max_rows=150_000, max_nnz=30_000_000):
+    m, n, nnz, rp, ci, v = A
+    k = min(max_rows, m)
+    if int(rp[k].item()) > max_nnz:  # power-law prefixes: cut by non-zeros instead
+        k = max(int(torch.searchsorted(rp, torch.tensor([max_nnz], dtype=rp.dtype, device="cuda")).item()) - 1, 1)
+    hrp = rp[: k + 1].cpu().numpy()
+    e = int(hrp[-1])
+    hci, hv = ci[:e].cpu().numpy(), v[:e].cpu().numpy()
+    hx, hy0 = x.cpu().numpy(), y0[:k].cpu().numpy()
+    ref = oracle.host_spmv(1.0, 1.0, hrp, hci, hv, hx, hy0)
+    for strat in strats:
+        y = _spmv(torch, A, strat, 1.0, 1.0, x, y0)[:k].cpu().numpy()
+        err = oracle.scaled_error(y, ref, 1.0, 1.0, hrp, hci, hv, hx, hy0)
+        assert err <= SCALED_TOL, (strat, "prefix vs oracle", k, err)
+        assert oracle.verify_y(y, ref)[2] == 0, (strat, "reference verdict on the prefix")
+    return k
+
+
+def _full_size_checks(torch, oracle, A, strats, seed):
+    m, n, nnz, rp, ci, v = A
+    x, y0 = _vectors(torch, m, n, seed)
+    # 1. the reference's protocol (alpha = beta = 1) against the independent device evaluation, all rows
+    ax, mag = _device_reference(torch, A, x)
+    ref = ax + y0
+    scale = (mag + y0.abs()).clamp_min(1e-300)
+    got = {}
+    for strat in strats:
+        y = _spmv(torch, A, strat, 1.0, 1.0, x, y0)
+        err = ((y - ref).abs() / scale).max().item()
+        assert err <= SCALED_TOL, (strat, "scaled error vs device reference", err)
+        assert _verify_y_failures(torch, y, ref) == 0, (strat, "verify_y rule")
+        got[strat] = y
+    # 2. general alpha / beta decomposes as alpha * (A x) + beta * y0; beta = 0 ignores y
+    zeros = torch.zeros(m, dtype=torch.float64, device="cuda")
+    for strat in strats:
+        full = _spmv(torch, A, strat, 0.5, -2.0, x, y0)
+        want = 0.5 * ax - 2.0 * y0
+        sc = (0.5 * mag + 2.0 * y0.abs()).clamp_min(1e-300)
+        assert ((full - want).abs() / sc).max().item() <= SCALED_TOL, (strat, "alpha/beta")
+        nan_y = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+        y = _spmv(torch, A, strat, 1.0, 0.0, x, nan_y)
+        assert ((y - ax).abs() / mag.clamp_min(1e-300)).max().item() <= SCALED_TOL, (strat, "beta = 0 must not read y")
+    # 3. row sums (x = 1) and linearity in x
+    ones = torch.ones(n, dtype=torch.float64, device="cuda")
+    sums, sums_mag = _device_reference(torch, A, ones)
+    x2, _ = _vectors(torch, 1, n, seed + 1)
+    for strat in strats:
+        y = _spmv(torch, A, strat, 1.0, 0.0, ones, zeros)
+        assert ((y - sums).abs() / sums_mag.clamp_min(1e-300)).max().item() <= SCALED_TOL, (strat, "row sums")
+        a1 = _spmv(torch, A, strat, 1.0, 0.0, x, zeros)
+        a2 = _spmv(torch, A, strat, 1.0, 0.0, x2, zeros)
+        both = _spmv(torch, A, strat, 1.0, 0.0, 3.0 * x + x2, zeros)
+        sc = (3.0 * mag + _device_reference(torch, A, x2)[1]).clamp_min(1e-300)
+        assert ((both - (3.0 * a1 + a2)).abs() / sc).max().item() <= 1e-11, (strat, "linearity")
+    # 4. a row prefix against the CPU oracle
+    _prefix_vs_oracle(torch, oracle, A, strats, x, y0)
+    return got
+
+
+@pytest.mark.parametrize("name", synth.SWEEP_NAMES)
+def test_configs2_sweep_standin_full_size(torch_dev, oracle, name):
+    """BASELINE configs[2]: every stand-in of the large-set sweep at full size, flat (named by BASELINE) and adaptive."""
+    torch = torch_dev
+    A = synth.sweep_standin_torch(name, device="cuda")
+    want = synth.LARGE_SET.get(name) or synth.LARGE_SET_EXTRA[name]
+    assert A[:3] == want
+    try:
+        got = _full_size_checks(torch, oracle, A, ("flat", "adaptive"), seed=0x5EED + synth.SWEEP_NAMES.index(name))
+        info = spmv_acc_amd.query_plan(A[3], A[0])
+        assert info is not None and info["nnz"] == A[2] and info["flat_tiles"] > 0
+        # the two strategies sum in different orders but agree to rounding
+        assert (got["flat"] - got["adaptive"]).abs().max().item() <= 1e-10
+    finally:
+        spmv_acc_amd.release_plans(A[3])
+        torch.cuda.empty_cache()
+
+
+def test_configs3_rmat25_line_enhance_full_size(torch_dev, oracle):
+    """BASELINE configs[3]: R-MAT scale 25 (33.5 M rows, ~0.53 B non-zeros, hub rows of millions) under line_enhance --
+    the balance probe must hand it to the row-block-plus kernel -- plus flat as the second opinion."""
+    torch = torch_dev
+    A = synth.rmat_torch(25, device="cuda", seed=0xC4)
+    m, n, nnz, rp = A[0], A[1], A[2], A[3]
+    assert m == n == 1 << 25 and 480_000_000 < nnz < 537_000_000
+    lens = rp[1:] - rp[:-1]
+    assert int(lens.max().item()) > 100_000 and int(lens.min().item()) == 0  # power law: hub rows and empty rows
+    del lens
+    try:
+        _full_size_checks(torch, oracle, A, ("line_enhance", "flat"), seed=0xC4C4)
+        info = spmv_acc_amd.query_plan(rp, m)
+        assert info["plus_blocks"] > 0  # line_enhance was rescued by the row-block preprocessing pass
+    finally:
+        spmv_acc_amd.release_plans(rp)
+        del A
+        torch.cuda.empty_cache()
+
+
+def test_configs4_banded_shard_full_size(torch_dev, oracle):
+    """BASELINE configs[4]: rank 3's shard (32 M rows, 256 M non-zeros, global column ids into a 256 M-entry x) of the
+    256 M-row banded matrix.  Closed form for x = 1, the generic full-size checks, and the first rows against the oracle."""
+    torch = torch_dev
+    rows, total, first = 32_000_000, 256_000_000, 96_000_000
+    rp, ci, v = synth.banded_torch(rows, first_row=first, total_rows=total, device="cuda")
+    nnz = int(rp[-1].item())
+    assert nnz == 8 * rows
+    A = (rows, total, nnz, rp, ci, v)
+    offs = np.arange(-4, 4)
+    want2 = [float(np.sum(np.where((r + offs) % 2 == 0, 1.0, -1.0) / (1.0 + np.abs(offs)))) for r in (first, first + 1)]
+    strats = ("adaptive", "flat", "line_enhance")
+    try:
+        ones = torch.ones(total, dtype=torch.float64, device="cuda")
+        zeros = torch.zeros(rows, dtype=torch.float64, device="cuda")
+        for strat in strats:
+            y = _spmv(torch, A, strat, 1.0, 0.0, ones, zeros)
+            assert (y[0::2] - want2[0]).abs().max().item() <= 1e-14 and (y[1::2] - want2[1]).abs().max().item() <= 1e-14, strat
+        del ones, zeros
+        _full_size_checks(torch, oracle, A, strats, seed=0xC5)
+    finally:
+        spmv_acc_amd.release_plans(rp)
+        torch.cuda.empty_cache()

@@ -1,0 +1,254 @@
+"""GPU suite (-m gpu), round-2 additions: the stale-plan guard, the argument checks of the Python plumbing, and the
+stream / event ordering of the row-sharded path on a one-rank RCCL communicator."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import spmv_acc_amd
+from spmv_acc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SCALED_TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def torch_dev(hiplib):
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _two_matrices_same_shape_and_nnz(m, n, seed):
+    """A and B: same m, n and nnz (B's row lengths are A's in reverse order), different structure and values."""
+    rng = np.random.default_rng(seed)
+    lens = np.minimum((rng.pareto(1.3, size=m) * 6).astype(np.int64), 3000) + rng.integers(0, 4, size=m)
+    lens[: m // 3] += 9  # make the reversal change every rowptr entry by a lot
+    A = synth.csr_from_row_lengths(lens, n, rng)
+    B = synth.csr_from_row_lengths(lens[::-1].copy(), n, rng)
+    assert A[0][-1] == B[0][-1] and not np.array_equal(A[0], B[0])
+    return A, B
+
+
+@pytest.mark.parametrize("strat", ["flat", "adaptive_plus", "adaptive", "line_enhance", "vector_row"])
+def test_stale_plan_is_detected_and_rebuilt(torch_dev, oracle, hiplib, strat):
+    """A caller rebuilds a DIFFERENT matrix with equal m, n, nnz in the SAME buffers and does not call
+    spmv_acc_release_plans (the reference recomputes its preprocessing per call, flat.cpp:39-44, so its callers never
+    announce a change).  The first SpMV on the new matrix runs with the old plan and raises the plan's sticky flag;
+    spmv_acc_last_error() / the next call report SPMV_ACC_ERR_BAD_ARGUMENT, the plan is rebuilt, and from then on results
+    match the oracle again.  Editing VALUES in place (same structure) must not trip the guard."""
+    torch = torch_dev
+    m = n = 30000
+    (rpA, ciA, vA), (rpB, ciB, vB) = _two_matrices_same_shape_and_nnz(m, n, seed=11)
+    nnz = int(rpA[-1])
+    rng = np.random.default_rng(12)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx = dev(torch, rpA), dev(torch, ciA), dev(torch, vA), dev(torch, x)
+
+    def spmv():
+        dy = dev(torch, y0)
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat)
+        torch.cuda.synchronize()
+        return dy.cpu().numpy()
+
+    try:
+        hiplib.spmv_acc_clear_error()
+        got = spmv()
+        assert oracle.scaled_error(got, oracle.host_spmv(1.0, 1.0, rpA, ciA, vA, x, y0), 1.0, 1.0, rpA, ciA, vA, x, y0) <= SCALED_TOL
+        plans = hiplib.spmv_acc_cached_plans()
+        # values edited in place: same plan, no complaint, new result
+        vA2 = vA * 1.5
+        dv.copy_(dev(torch, vA2))
+        got = spmv()
+        assert hiplib.spmv_acc_last_error() == 0 and hiplib.spmv_acc_cached_plans() == plans
+        assert oracle.scaled_error(got, oracle.host_spmv(1.0, 1.0, rpA, ciA, vA2, x, y0), 1.0, 1.0, rpA, ciA, vA2, x, y0) <= SCALED_TOL
+        # the other matrix, same buffers, no release
+        drp.copy_(dev(torch, rpB))
+        dci.copy_(dev(torch, ciB))
+        dv.copy_(dev(torch, vB))
+        torch.cuda.synchronize()
+        reported = False
+        try:
+            spmv()  # stale plan: this y is not to be trusted (the kernel may already have raised the flag when the
+        except spmv_acc_amd.SpmvAccError as ex:  # wrapper looks at the error slot)
+            reported = "changed" in str(ex)
+        if not reported:
+            assert hiplib.spmv_acc_last_error() == 2  # SPMV_ACC_ERR_BAD_ARGUMENT, raised by the kernel's guard
+            assert b"changed" in hiplib.spmv_acc_last_error_string()
+        hiplib.spmv_acc_clear_error()
+        refB = oracle.host_spmv(1.0, 1.0, rpB, ciB, vB, x, y0)
+        for _ in range(2):  # fresh plan: correct, and no further complaint
+            got = spmv()
+            assert hiplib.spmv_acc_last_error() == 0
+            assert oracle.scaled_error(got, refB, 1.0, 1.0, rpB, ciB, vB, x, y0) <= SCALED_TOL, strat
+        # second scenario: nobody asks for the error -- the next call on the matrix reports it and still computes correctly
+        drp.copy_(dev(torch, rpA))
+        dci.copy_(dev(torch, ciA))
+        dv.copy_(dev(torch, vA))
+        torch.cuda.synchronize()
+        dy = dev(torch, y0)
+        hiplib.spmv_acc_csr_spmv_strategy(spmv_acc_amd.strategy_id(strat), 0, 1.0, 1.0, m, n, nnz, None, drp.data_ptr(),
+                                          dci.data_ptr(), dv.data_ptr(), dx.data_ptr(), dy.data_ptr())
+        torch.cuda.synchronize()  # (raw C call: nothing looked at the error slot)
+        dy = dev(torch, y0)
+        with pytest.raises(spmv_acc_amd.SpmvAccError, match="changed"):
+            spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat)
+        torch.cuda.synchronize()
+        refA = oracle.host_spmv(1.0, 1.0, rpA, ciA, vA, x, y0)
+        assert oracle.scaled_error(dy.cpu().numpy(), refA, 1.0, 1.0, rpA, ciA, vA, x, y0) <= SCALED_TOL  # rebuilt before it ran
+    finally:
+        hiplib.spmv_acc_clear_error()
+        spmv_acc_amd.release_plans(drp)
+
+
+def test_sparse_spmv_ten_args_with_changed_nnz(torch_dev, oracle, hiplib):
+    """The ten-argument entry never receives nnz: a matrix with ANOTHER nnz behind the same pointers (same m, n) is caught
+    by the guard as well (rowptr[m] is one of the samples)."""
+    torch = torch_dev
+    m = n = 20000
+    rpA, ciA, vA = synth.random_csr(m, n, 8, seed=3, kind="uniform")
+    rpB, ciB, vB = synth.random_csr(m, n, 5, seed=4, kind="uniform")
+    assert rpA[-1] > rpB[-1]
+    rng = np.random.default_rng(5)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    cap = int(rpA[-1])
+    drp, dx = dev(torch, rpA), dev(torch, x)
+    dci = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    dv = torch.zeros(cap, dtype=torch.float64, device="cuda")
+    dci.copy_(dev(torch, ciA))
+    dv.copy_(dev(torch, vA))
+    try:
+        hiplib.spmv_acc_clear_error()
+        dy = dev(torch, y0)
+        spmv_acc_amd.sparse_spmv(0, 1.0, 1.0, m, n, drp, dci, dv, dx, dy)
+        torch.cuda.synchronize()
+        assert oracle.verify(dy.cpu().numpy(), oracle.host_spmv(1.0, 1.0, rpA, ciA, vA, x, y0)) == -1
+        drp.copy_(dev(torch, rpB))
+        dci[: ciB.size].copy_(dev(torch, ciB))
+        dv[: vB.size].copy_(dev(torch, vB))
+        torch.cuda.synchronize()
+        try:
+            spmv_acc_amd.sparse_spmv(0, 1.0, 1.0, m, n, drp, dci, dv, dx, dev(torch, y0))
+        except spmv_acc_amd.SpmvAccError:
+            pass
+        torch.cuda.synchronize()
+        hiplib.spmv_acc_last_error()  # drops the stale plan if the wrapper had not seen the flag yet
+        hiplib.spmv_acc_clear_error()
+        dy = dev(torch, y0)
+        spmv_acc_amd.sparse_spmv(0, 1.0, 1.0, m, n, drp, dci, dv, dx, dy)
+        torch.cuda.synchronize()
+        assert oracle.verify(dy.cpu().numpy(), oracle.host_spmv(1.0, 1.0, rpB, ciB, vB, x, y0)) == -1
+        assert spmv_acc_amd.query_plan(drp, m)["nnz"] == int(rpB[-1])
+    finally:
+        hiplib.spmv_acc_clear_error()
+        spmv_acc_amd.release_plans(drp)
+
+
+def test_wrapper_refuses_what_the_kernels_would_misread(torch_dev):
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(500, 500, 5, seed=1)
+    m = n = 500
+    nnz = int(rowptr[-1])
+    drp, dci, dv = dev(torch, rowptr), dev(torch, cols), dev(torch, vals)
+    dx = torch.ones(n, dtype=torch.float64, device="cuda")
+    dy = torch.zeros(m, dtype=torch.float64, device="cuda")
+    bad = [
+        dict(rowptr=drp.long()),                                   # torch's default integer type
+        dict(value=dv.float()),                                    # fp32 values
+        dict(x=torch.ones(2 * n, dtype=torch.float64, device="cuda")[::2]),  # strided view
+        dict(y=torch.zeros(m - 1, dtype=torch.float64, device="cuda")),      # too short
+        dict(colindex=dci[: nnz - 1]),
+        dict(x=torch.ones(n, dtype=torch.float64)),                # host tensor
+    ]
+    for override in bad:
+        args = dict(rowptr=drp, colindex=dci, value=dv, x=dx, y=dy)
+        args.update(override)
+        with pytest.raises(spmv_acc_amd.SpmvAccError):
+            spmv_acc_amd.csr_spmv(1.0, 0.0, m, n, nnz, args["rowptr"], args["colindex"], args["value"], args["x"], args["y"])
+    spmv_acc_amd.csr_spmv(1.0, 0.0, m, n, nnz, drp, dci, dv, dx, dy)  # and the good call goes through
+    torch.cuda.synchronize()
+    spmv_acc_amd.release_plans(drp)
+
+
+def test_library_follows_torch_current_stream(torch_dev, oracle):
+    """The wrappers point the library stream at torch's current stream: work queued on a side stream before the call
+    (here: a long sleep, then the write of x) is seen by the SpMV without any host synchronisation."""
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(20000, 20000, 7, seed=9)
+    m = n = 20000
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(3)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx_src, dy = dev(torch, rowptr), dev(torch, cols), dev(torch, vals), dev(torch, x), dev(torch, y0)
+    spmv_acc_amd.prepare(m, n, nnz, drp, dci, dv, dx_src, strategy="adaptive")
+    dx = torch.zeros(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(100_000_000)  # tens of milliseconds
+        dx.copy_(dx_src)
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, dy, strategy="adaptive")
+    side.synchronize()
+    ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+    assert oracle.scaled_error(dy.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL
+    spmv_acc_amd.load_library().spmv_acc_set_stream(None)
+    spmv_acc_amd.release_plans(drp)
+
+
+def test_row_sharded_event_ordering_on_one_rank_rccl(torch_dev, oracle):
+    """RowShardedSpmv on a ONE-rank RCCL communicator (all this box allows): the local SpMV runs on the engine's own
+    non-NULL stream, the allgather is issued behind the event recorded after it, and the in-place iteration
+    (beta != 0, no y_prev) follows the serial recurrence.  The compute stream is held back by a long sleep before a
+    step: an exchange that did not wait for the SpMV's event would gather the old buffer."""
+    torch = torch_dev
+    import torch.distributed as dist
+
+    from spmv_acc_amd.dist import RowShardedSpmv
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        m = n = 200_000
+        rowptr, cols, vals = synth.random_csr(m, n, 6, seed=17)
+        nnz = int(rowptr[-1])
+        rng = np.random.default_rng(4)
+        x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+        drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+        bounds = np.array([0, m], dtype=np.int64)
+        for exchange in ("allgather", "p2p"):
+            eng = RowShardedSpmv(0, 1, bounds, drp, dci, dv, n, torch.device("cuda", 0), strategy="adaptive",
+                                 always_collective=True, exchange=exchange)
+            assert eng.compute_stream is not None and eng.compute_stream.cuda_stream != 0  # explicit non-NULL stream
+            assert eng.compute_stream.cuda_stream != torch.cuda.current_stream().cuda_stream
+            eng.set_y(dy0)
+            eng.step(0.25, 0.5, dx)  # builds the plan
+            eng.wait()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(eng.compute_stream):
+                torch.cuda._sleep(200_000_000)  # the next SpMV sits behind this
+            eng.step(0.25, 0.5, dx, overlap=True)
+            assert eng.exchange_issued_after_spmv and not eng.spmv_done.query()  # SpMV still pending: the exchange must wait for it
+            eng.step(0.25, 0.5, dx, overlap=True)
+            got = eng.gathered().cpu().numpy()
+            assert eng.spmv_done.query()
+            y = y0
+            for _ in range(3):
+                y = oracle.host_spmv(0.25, 0.5, rowptr, cols, vals, x, y)
+            scale_ok = oracle.scaled_error(got, y, 0.25, 0.5, rowptr, cols, vals, x, y0)
+            assert scale_ok <= 1e-11, (exchange, scale_ok)
+        spmv_acc_amd.release_plans(drp)
+    finally:
+        dist.destroy_process_group()
+        spmv_acc_amd.load_library().spmv_acc_set_stream(None)

@@ -223,3 +223,27 @@ def test_cmake_build_exports_the_same_symbols(tmp_path):
     exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
     missing = [s for s in spmv_acc_amd.C_ABI_SYMBOLS if s not in exported]
     assert not missing, missing
+
+
+def test_cmake_accepts_the_reference_cache_variables(tmp_path):
+    """A configure line written for the reference (config.cmake:2-51) configures this tree: every option is accepted,
+    KERNEL_STRATEGY is matched by case-insensitive substring in the reference's order (src/configure.cmake:17-40: any string
+    containing a name selects it, `line_enhance` before `line`), and an unknown strategy is the same fatal error."""
+    import shutil
+
+    if not shutil.which("cmake") or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("cmake / hipcc not available")
+    common = ["-DCMAKE_CXX_COMPILER=/opt/rocm/bin/hipcc", "-DHIP_ENABLE_FLAG=ON", "-DSPMV_BUILD_TOOLS=OFF", "-DSPMV_BUILD_BENCHMARK=ON",
+              "-DSPMV_OMP_ENABLED_FLAG=ON", "-DDEVICE_SIDE_VERIFY_FLAG=ON", "-DBENCHMARK_CUDA_ENABLE_FLAG=OFF",
+              "-DBENCHMARK_FORCE_SYNC_KERNELS=ON", "-DAVAILABLE_CU=256", "-DWAVEFRONT_SIZE=64", "-DWF_REDUCE=LDS",
+              "-DFLAT_SEGMENT_SUM_REDUCE=ON"]
+    for given, macro in (("Flat", "KERNEL_STRATEGY_FLAT"), ("my_line_enhance_build", "KERNEL_STRATEGY_LINE_ENHANCE"),
+                         ("LINE", "KERNEL_STRATEGY_LINE"), ("wf_row", "KERNEL_STRATEGY_WAVEFRONT_ROW")):
+        b = tmp_path / given
+        out = subprocess.run(["cmake", "-S", ROOT, "-B", str(b), f"-DKERNEL_STRATEGY={given}"] + common, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-600:]
+        assert f"({macro})" in out.stdout, out.stdout[-400:]
+    out = subprocess.run(["cmake", "-S", ROOT, "-B", str(tmp_path / "bad"), "-DKERNEL_STRATEGY=csr5"] + common, capture_output=True, text=True)
+    assert out.returncode != 0 and "unsupported kernel strategy" in out.stderr
+    out = subprocess.run(["cmake", "-S", ROOT, "-B", str(tmp_path / "bad2"), "-DWF_REDUCE=tree"] + common[:-2], capture_output=True, text=True)
+    assert out.returncode != 0 and "unsupported wavefront reduction strategy" in out.stderr
