@@ -133,7 +133,7 @@ def pmc_traffic(workload, strategy, key="corrected_bytes"):
         return None
 
 
-def timed_leg(torch, strat, A, x, y0, iters, warm=10, beta=1.0):
+def timed_leg(torch, strat, A, x, y0, iters, warm=10, beta=1.0, cols_touched=None):
     """One extra leg: `warm` untimed launches (the first builds the plan), then `iters` back-to-back launches between one
     hipEvent pair on the library stream.  us = mean launch duration; frac = algorithmic bytes / us / 8 TB/s."""
     import spmv_acc_amd
@@ -146,7 +146,8 @@ def timed_leg(torch, strat, A, x, y0, iters, warm=10, beta=1.0):
     torch.cuda.synchronize()
     y.copy_(y0)
     ms = spmv_acc_amd.time_spmv_total(strat, iters, 1.0, beta, m, n, nnz, rp, ci, v, x, y) / iters
-    b = synth.algorithmic_bytes(m, n, nnz, beta_nonzero=beta != 0.0)
+    # (a row shard with global column ids reads only the columns its rows reference, not all n entries of x)
+    b = synth.algorithmic_bytes(m, n if cols_touched is None else cols_touched, nnz, beta_nonzero=beta != 0.0)
     info = spmv_acc_amd.query_plan(rp, m) or {}
     return {"us": round(ms * 1e3, 2), "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "gflops": round(2.0 * nnz / (ms * 1e-3) / 1e9, 1),
@@ -178,8 +179,18 @@ def extra_legs(torch, device, headline):
         sweep[name] = {"rows": A[0], "nnz": A[2]}
         for strat in ("flat", "adaptive"):
             sweep[name][strat] = timed_leg(torch, strat, A, x, y0, iters)
+        # opt-in leg, never the headline: flat over the plan's 16-bit column encoding (tunable col16; the plan then holds a copy
+        # derived from colindex).  frac stays algorithmic bytes of the CSR format (12 B per non-zero) over time.
+        lib = spmv_acc_amd.load_library()
+        spmv_acc_amd.release_plans(A[3])
+        lib.spmv_acc_set_tunable(b"col16", 1)
+        try:
+            sweep[name]["flat_col16_opt_in"] = timed_leg(torch, "flat", A, x, y0, iters)
+        finally:
+            lib.spmv_acc_set_tunable(b"col16", 0)
         progress(f"sweep {name}: flat {sweep[name]['flat']['us']} us ({sweep[name]['flat']['frac']}), "
-                 f"adaptive {sweep[name]['adaptive']['us']} us ({sweep[name]['adaptive']['frac']})")
+                 f"adaptive {sweep[name]['adaptive']['us']} us ({sweep[name]['adaptive']['frac']}), "
+                 f"flat+col16 {sweep[name]['flat_col16_opt_in']['us']} us ({sweep[name]['flat_col16_opt_in']['frac']})")
         spmv_acc_amd.release_plans(A[3])
         del A, x, y0
         torch.cuda.empty_cache()
@@ -187,7 +198,7 @@ def extra_legs(torch, device, headline):
     out["sweep_summary"] = {
         s: {"ge_0.70": sum(1 for r in sweep.values() if r[s]["frac"] >= 0.70),
             "min_frac": min(r[s]["frac"] for r in sweep.values()),
-            "median_frac": float(np.median([r[s]["frac"] for r in sweep.values()]))} for s in ("flat", "adaptive")}
+            "median_frac": float(np.median([r[s]["frac"] for r in sweep.values()]))} for s in ("flat", "adaptive", "flat_col16_opt_in")}
     A = synth.rmat_torch(25, device=device, seed=0xC4)
     x, y0 = vectors(A[0], A[1])
     out["rmat25"] = {"workload": "R-MAT scale 25, edge factor 16 (BASELINE configs[3])", "rows": A[0], "nnz": A[2],
@@ -201,7 +212,8 @@ def extra_legs(torch, device, headline):
     A = (rows, total, int(rp[-1].item()), rp, ci, v)
     x, y0 = vectors(rows, total)
     out["banded_shard"] = {"workload": "rank 3's 32 M-row shard of the 256 M-row banded matrix (BASELINE configs[4]), beta = 0",
-                           "rows": rows, "nnz": A[2], "adaptive": timed_leg(torch, "adaptive", A, x, y0, iters=30, warm=5, beta=0.0)}
+                           "rows": rows, "nnz": A[2], "adaptive": timed_leg(torch, "adaptive", A, x, y0, iters=30, warm=5, beta=0.0, cols_touched=rows + 7),
+                           "algorithmic_bytes_note": "x counted over the rows + 7 columns the shard references, not over all 256 M"}
     progress(f"banded shard: {out['banded_shard']['adaptive']}")
     spmv_acc_amd.release_plans(rp)
     return out
@@ -422,7 +434,7 @@ def main():
             bsteps = min(args.steps, 50)
             bwall, bev, bextra = sharded_leg(torch, dist, args, BW, bx, by0, 1.0, 0.0, rank, world, device, backend, force_dist,
                                              bsteps, min(args.warmup, 5))
-            b_alg_b = _synth.algorithmic_bytes(rows, world * rows, BW["nnz"], beta_nonzero=False)
+            b_alg_b = _synth.algorithmic_bytes(rows, rows + 7, BW["nnz"], beta_nonzero=False)  # x: the columns the shard references
             bextra.update({
                 "workload": f"banded offsets -4..+3, {world} x 32 M rows (BASELINE configs[4]; 8 ranks = the 256 M-row matrix), "
                             "row-range shards, x replicated, beta = 0, allgather(y) per step",

@@ -101,7 +101,11 @@ void adaptive_vec_row_sparse_spmv(const int nnz_block_0, const int nnz_block_1, 
   const int w0 = vec_for(half > 0 ? nnz_block_0 / half : 0);
   const int w1 = vec_for(nnz_block_1 / (m - half));
   (void)trans;
-  launch_vector_row(get_stream(), A, half, w0, w1, alpha, beta, x, y);
+  // the two-width split on the tile machinery (k_vector_row.hip::vector_tile_kernel); no plan is involved: the caller passed
+  // the only structural facts the split needs
+  const double a0 = half > 0 ? static_cast<double>(nnz_block_0) / half : 0.0;
+  const double a1 = static_cast<double>(nnz_block_1) / (m - half);
+  launch_vector_tile(get_stream(), A, half, w0, w1, a0, a1, 1900, 16, kStreamPolicyNt, alpha, beta, x, y);
 }
 
 // legacy baselines kept resolvable

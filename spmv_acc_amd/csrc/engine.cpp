@@ -81,7 +81,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kTunableCount
 };
 Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
@@ -111,6 +111,12 @@ Tunable g_tunables[] = {
                                // rowptr: -1 where rows average <= 16 non-zeros (rowptr is then >= 2 % of the traffic), 0 never, 1 always
     {"flat_early", -1, -1},    // flat: issue a tile's stream loads before its break point -> rowptr chain: -1 timed per matrix
                                // below kFlatSmallNnz non-zeros (else off), 0 off, 1 on
+    {"vector_tile", 1, 1},     // vector_row / light / the two-width split: 1 = w lanes per row over LDS-staged tiles (16-B stream
+                               // loads), 0 = w lanes per row straight from global memory (4-/8-byte loads; also the form very
+                               // uneven matrices keep)
+    {"col16", 0, 0},           // OPT-IN, flat only: 1 = the plan holds a 16-bit encoding of colindex (per-256-non-zero base + escape list,
+                               // k_col16.hip) and the tile kernel streams 2 B instead of 4 B per column.  The plan then holds a copy
+                               // derived from colindex: after editing colindex in place call spmv_acc_release_plans.
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -396,7 +402,7 @@ void guard_release(int device, int slot) {
   g_guard_pools[device].free_slots.push_back(slot);
 }
 
-enum Family { kFamRowblock = 0, kFamPlus = 1, kFamFlat = 2, kFamilyCount = 3 };
+enum Family { kFamRowblock = 0, kFamPlus = 1, kFamFlat = 2, kFamVector = 3, kFamilyCount = 4 };
 
 struct Plan {
   int device = 0;
@@ -408,7 +414,7 @@ struct Plan {
   bool have_samples = false;
   RowptrSamples samples;
   // cache policy of the stream loads (kStreamPolicy*), timed once per matrix AND kernel family; -1 = not tuned yet
-  int stream_policy[kFamilyCount] = {-1, -1, -1};
+  int stream_policy[kFamilyCount] = {-1, -1, -1, -1};
   // opt-in structural check (tunable `validate`): -1 not run, 0 arrays are consistent, else the failure bits
   int invalid = -1;
   // row-block family: -1 unknown, 1 balanced, 0 some workgroup would need too many LDS rounds
@@ -421,6 +427,7 @@ struct Plan {
   // flat
   int flat_tiles = -1;
   FlatPlan flat;
+  Col16 col16;                  // opt-in 16-bit column encoding (tunable col16), built on first use
   int flat_npt_choice = 0;      // timed tile size (non-zeros per lane), 0 = not timed
   bool flat_geometry_tuned = false;
   // row-block-plus
@@ -439,6 +446,13 @@ struct Plan {
     guard_release(device, guard_slot);
   }
   bool is_stale() const { return A.stale && __atomic_load_n(A.stale, __ATOMIC_RELAXED) != 0; }
+  void free_col16() {
+    if (col16.d16) (void)hipFree(col16.d16);
+    if (col16.base) (void)hipFree(col16.base);
+    if (col16.esc_start) (void)hipFree(col16.esc_start);
+    if (col16.esc_cols) (void)hipFree(col16.esc_cols);
+    col16 = Col16();
+  }
   void free_digest() {
     if (digest.lens) (void)hipFree(digest.lens);
     if (digest.base) (void)hipFree(digest.base);
@@ -447,6 +461,7 @@ struct Plan {
   void free_device() {
     free_flat();
     free_digest();
+    free_col16();
     if (d_pbp) (void)hipFree(d_pbp);
     if (d_pfbr) (void)hipFree(d_pfbr);
     if (d_ppartial) (void)hipFree(d_ppartial);
@@ -635,6 +650,7 @@ bool build_flat_plan(const CsrDev &A, int stride, hipStream_t stream, FlatPlan &
 constexpr int kFlatSmallNnz = 24 << 20;
 
 int flat_stride_for(const Plan &p) {
+  if (tun(kT_col16) > 0) return kThreads * kNnzPerThread; // the 16-bit encoding is read by the 2048-non-zero tile
   int npt = tun(kT_flat_npt);
   if (npt < 0) npt = p.flat_npt_choice > 0 ? p.flat_npt_choice : kNnzPerThread;
   return kThreads * ((npt == 4 || npt == 16) ? npt : kNnzPerThread);
@@ -849,6 +865,48 @@ template <typename Launch> bool autotune_policy(Plan &p, int fam, hipStream_t st
   return ok;
 }
 
+// Opt-in 16-bit column encoding of the whole matrix (k_col16.hip): base + escape count per 256-non-zero chunk, exclusive scan
+// of the counts, then the offsets and the escape list.  One synchronisation (the escape total sizes the last allocation).
+bool ensure_col16(Plan &p, hipStream_t st) {
+  if (p.col16.d16) return true;
+  ++t_plan_work;
+  Col16 &C = p.col16;
+  const int nchunks = (p.A.nnz + kCol16Chunk - 1) / kCol16Chunk;
+  int *esc_count = nullptr;
+  void *tmp = nullptr;
+  const size_t tmp_bytes = col16_scan_bytes(nchunks);
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&C.d16), sizeof(unsigned short) * static_cast<size_t>(nchunks) * kCol16Chunk),
+                   "hipMalloc col16 offsets") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&C.base), sizeof(int) * static_cast<size_t>(nchunks)), "hipMalloc col16 bases") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&C.esc_start), sizeof(int) * (static_cast<size_t>(nchunks) + 1)),
+                   "hipMalloc col16 escape offsets") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&esc_count), sizeof(int) * (static_cast<size_t>(nchunks) + 1)),
+                   "hipMalloc col16 escape counts") &&
+            hip_ok(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16), "hipMalloc col16 scan workspace") &&
+            hip_ok(hipMemsetAsync(esc_count + nchunks, 0, sizeof(int), st), "memset col16");
+  int total = 0;
+  if (ok) {
+    launch_col16_base(st, p.A.ci, p.A.nnz, nchunks, C.base, esc_count);
+    ok = launch_col16_scan(st, nchunks, esc_count, C.esc_start, tmp, tmp_bytes) &&
+         hip_ok(hipMemcpyAsync(&total, C.esc_start + nchunks, sizeof(int), hipMemcpyDeviceToHost, st), "read col16 escape total") &&
+         hip_ok(hipStreamSynchronize(st), "sync col16") &&
+         hip_ok(hipMalloc(reinterpret_cast<void **>(&C.esc_cols), sizeof(int) * (static_cast<size_t>(total) + 1)), "hipMalloc col16 escapes");
+  }
+  if (ok) {
+    launch_col16_encode(st, p.A.ci, p.A.nnz, nchunks, C.base, C.esc_start, C.d16, C.esc_cols);
+    ok = hip_ok(hipStreamSynchronize(st), "sync col16 encode");
+  }
+  if (esc_count) (void)hipFree(esc_count);
+  if (tmp) (void)hipFree(tmp);
+  if (!ok) {
+    p.free_col16();
+    return false;
+  }
+  C.nchunks = nchunks;
+  C.escapes = total;
+  return true;
+}
+
 void launch_flat_plan(hipStream_t st, const CsrDev &A, FlatPlan &F, int policy, double alpha, double beta, const double *x,
                       double *y) {
   F.xcd_chunk = tun(kT_stage_fast) ? tun(kT_xcd_chunk_tiles) : -1; // -1: per-lane predicated staging (A/B)
@@ -904,7 +962,7 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
 // per matrix and keep the fastest.  The other tile size gets its own break points / carries; its cut rows are finished in
 // the tile whenever that is legal (no second launch: what wins on short kernels).
 bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
-  if (p.flat_geometry_tuned) return true;
+  if (p.flat_geometry_tuned || tun(kT_col16) > 0) return true;
   if (p.A.nnz >= kFlatSmallNnz || p.flat.ntiles <= 1) {
     p.flat_geometry_tuned = true;
     return true;
@@ -975,6 +1033,11 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
     // (guard against mutual recursion: the row-block rescue goes to row-block-plus unless rescue_flat is set, and a matrix with
     // such tiles has no row-block imbalance of the hub-row kind)
     if (!(tun(kT_rescue_flat) && p.rowblock_ok == 0)) return run_rowblock(st, p, nullptr, alpha, beta, x, y, false);
+  }
+  p.flat.col16 = nullptr;
+  if (tun(kT_col16) > 0) {
+    if (!ensure_col16(p, st)) return false;
+    p.flat.col16 = &p.col16; // (used by the 2048-non-zero tile only; other tile sizes read colindex)
   }
   if (!autotune_policy(p, kFamFlat, st, [&](int pol, double *ys) { launch_flat_with(st, p, pol, 1.0, 0.0, x, ys); })) return false;
   if (!autotune_flat_mode(p, st, x)) return false;
@@ -1265,7 +1328,17 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   {
     const int w = classic_vec(avg);
     if (tun(kT_rowblock_guard) && !probe_rowblock(*p, kThreads / w, st)) return;
-    launch_vector_row(st, p->A, m, w, 1, alpha, beta, dx, dy, p->rowblock_ok == 0);
+    if (tun(kT_vector_tile) && p->rowblock_ok != 0) {
+      // the reference's lane width per row (vector_row.cpp:15-27) on the tile machinery
+      const double a = static_cast<double>(p->A.nnz) / m;
+      auto launch = [&](int pol, double al, double be, double *yy) {
+        launch_vector_tile(st, p->A, m, w, w, a, a, tun(kT_rowblock_target), tun(kT_xcd_chunk), pol, al, be, dx, yy);
+      };
+      if (!autotune_policy(*p, kFamVector, st, [&](int pol, double *ys) { launch(pol, 1.0, 0.0, ys); })) return;
+      launch(policy_for(*p, kFamVector), alpha, beta, dy);
+    } else {
+      launch_vector_row(st, p->A, m, w, 1, alpha, beta, dx, dy, p->rowblock_ok == 0);
+    }
     break;
   }
   case kWfRow:
@@ -1301,7 +1374,14 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
         const int half_rows = m / 2;
         const long long a0 = half_rows > 0 ? p->samples.half / half_rows : 0;
         const long long a1 = (static_cast<long long>(p->samples.last) - p->samples.half) / (m - half_rows);
-        launch_vector_row(st, p->A, half_rows, classic_vec(a0), classic_vec(a1), alpha, beta, dx, dy);
+        if (tun(kT_vector_tile)) {
+          const double f0 = half_rows > 0 ? static_cast<double>(p->samples.half) / half_rows : 0.0;
+          const double f1 = (static_cast<double>(p->samples.last) - p->samples.half) / (m - half_rows);
+          launch_vector_tile(st, p->A, half_rows, classic_vec(a0), classic_vec(a1), f0, f1, tun(kT_rowblock_target),
+                             tun(kT_xcd_chunk), policy_for(*p, kFamVector), alpha, beta, dx, dy);
+        } else {
+          launch_vector_row(st, p->A, half_rows, classic_vec(a0), classic_vec(a1), alpha, beta, dx, dy);
+        }
       } else {
         run_plus(st, *p, h_rowptr, alpha, beta, dx, dy);
       }

@@ -57,7 +57,13 @@ __device__ __forceinline__ int tile_end_excl(const int *__restrict__ rp, const i
   return (e < m && rp[e] < t1) ? e + 1 : e;
 }
 
-template <int NPT, bool NTC, bool NTV, bool EARLY>
+// device-side view of the plan's 16-bit column encoding (kernels.hpp Col16), passed by value
+struct Col16Dev {
+  const unsigned short *d16;
+  const int *base, *esc_start, *esc_cols;
+};
+
+template <int NPT, bool NTC, bool NTV, bool EARLY, bool C16 = false>
 __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int ntiles, double alpha, double beta,
                                                              const int *__restrict__ rp, const int *__restrict__ bp,
                                                              const int *__restrict__ ci,
@@ -66,7 +72,8 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
                                                              double *__restrict__ head, double *__restrict__ tail,
                                                              int *__restrict__ tail_row, int *__restrict__ tail_end,
                                                              int xcd_chunk, int reach,
-                                                             const int *__restrict__ guard, int *__restrict__ stale) {
+                                                             const int *__restrict__ guard, int *__restrict__ stale,
+                                                             Col16Dev c16) {
   check_plan_guard(rp, m, guard, stale);
   // reach: a tile finishes its last row itself when it ends at most `reach` (0 or kFlatFinish) non-zeros past the tile
   constexpr int STRIDE = kThreads * NPT;
@@ -115,7 +122,9 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
   double y_old0 = 0.0;
   if (early_y && live0 && lane == 0) y_old0 = y[first + vec_id]; // read for cut rows too (<= 2 per tile): harmless
 
-  if (EARLY && early) stage_finish<kThreads, EARLY ? NPT : 4>(lds, early_regs, x);
+  if (C16 && stage_fast_ok(t1, nnz)) // (the one tile that holds the ragged end of the arrays reads colindex as usual)
+    stage_products_col16<kThreads, NPT, NTV>(lds, t0, t1, c16.d16, c16.base, c16.esc_start, c16.esc_cols, v, x);
+  else if (EARLY && early) stage_finish<kThreads, EARLY ? NPT : 4>(lds, early_regs, x);
   else stage_products<kThreads, NPT, NTC, NTV>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
 
   __syncthreads();
@@ -250,14 +259,24 @@ namespace {
 template <int NPT, bool NTC, bool NTV>
 void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                          double *y) {
+  const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
   if (P.early_stream)
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale);
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none);
   else
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale);
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none);
+}
+// opt-in 16-bit columns: NPT 8 tiles (a multiple of the 256-non-zero chunk), values under the plan's cache policy
+template <bool NTV>
+void launch_flat_col16(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
+                       double *y) {
+  const Col16Dev c = {P.col16->d16, P.col16->base, P.col16->esc_start, P.col16->esc_cols};
+  hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, true, NTV, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
+                     A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, c);
 }
 template <int NPT>
 void launch_flat_policy(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
@@ -281,7 +300,11 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
                  double *y) {
   if (P.ntiles <= 0) return;
   const int npt = P.stride / kThreads;
-  if (npt == 4) launch_flat_policy<4>(stream, A, P, alpha, beta, x, y);
+  if (P.col16 && npt == kNnzPerThread) {
+    // values default for policies 1 (both default) and 3 (values default), non-temporal otherwise
+    if ((P.stream_policy & 3) == 1 || (P.stream_policy & 3) == 3) launch_flat_col16<false>(stream, A, P, alpha, beta, x, y);
+    else launch_flat_col16<true>(stream, A, P, alpha, beta, x, y);
+  } else if (npt == 4) launch_flat_policy<4>(stream, A, P, alpha, beta, x, y);
   else if (npt == 16) launch_flat_policy<16>(stream, A, P, alpha, beta, x, y);
   else launch_flat_policy<8>(stream, A, P, alpha, beta, x, y);
   if (P.ntiles > 1 && P.needs_fixup) {

@@ -12,6 +12,7 @@
 //     "which width does this workgroup use".
 #include "device_utils.hpp"
 #include "kernels.hpp"
+#include "tile_stage.hpp"
 
 namespace spmv_acc {
 namespace {
@@ -104,6 +105,72 @@ __global__ __launch_bounds__(kThreads) void vector_row_kernel(int m, int row_spl
   for (int k = 0; k < kVecRows; ++k) {
     const double sum = group_sum_dyn(s[k], w); // every lane takes part (DPP needs a full exec mask)
     if (live[k] && lane == 0) store_y(y, static_cast<int>(first + static_cast<long long>(k) * groups), alpha, beta, sum);
+  }
+}
+
+// CSR-Vector on the tile machinery (the form KERNEL_STRATEGY=VECTOR_ROW / LIGHT and the two-width split run by default): a
+// workgroup owns `rpb` consecutive rows, their non-zeros are staged into the LDS tile with the 16-B stream loads shared by
+// the other tile kernels, and every row is summed by the reference's w lanes (vector_row.cpp:15-27: w from the average row
+// length; one w per matrix half for the split, vector_row_adaptive.hpp:72-142).  A lane group owns up to kVecTileRows rows
+// (vecs apart), so that w lanes per row and a full 2048-product tile go together: 256/w groups x 4 rows x avg >= 1900 products
+// for every average row length the width rule maps to w.  Against the direct-from-global kernel above (4-/8-byte loads per
+// lane, 245 us on the Hardesty3-sized matrix) this is the row-block kernel's memory behaviour with the vector-row lane layout.
+constexpr int kVecTileRows = 4;
+template <bool NTC, bool NTV>
+__global__ __launch_bounds__(kThreads) void vector_tile_kernel(int m, int nnz, int row_split, int nb0, int w0, int w1, int rpb0,
+                                                               int rpb1, int xcd_chunk, double alpha, double beta,
+                                                               const int *__restrict__ rp, const int *__restrict__ ci,
+                                                               const double *__restrict__ v, const double *__restrict__ x,
+                                                               double *__restrict__ y, const int *__restrict__ guard,
+                                                               int *__restrict__ stale) {
+  check_plan_guard(rp, m, guard, stale);
+  __shared__ __attribute__((aligned(16))) double lds[kTile];
+  __shared__ TileSpans spans;
+  if (threadIdx.x == 0) spans.n = 0; // published by the barrier that follows the first staging
+  const int nblocks = gridDim.x;
+  const int blk = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, nblocks, xcd_chunk) : static_cast<int>(blockIdx.x);
+  const bool second = blk >= nb0; // block-uniform: which matrix half (one width when row_split == m)
+  const int w = second ? w1 : w0;
+  const int rpb = second ? rpb1 : rpb0;
+  const int half_lo = second ? row_split : 0;
+  const int half_hi = second ? m : row_split;
+  const long long base_ll = static_cast<long long>(half_lo) + static_cast<long long>(second ? blk - nb0 : blk) * rpb;
+  const int row_base = static_cast<int>(base_ll);
+  const int row_end = base_ll + rpb < half_hi ? row_base + rpb : half_hi;
+  const int s0 = rp[row_base];
+  const int s1 = rp[row_end];
+  const int lane = threadIdx.x & (w - 1);
+  const int vecs = kThreads / w;
+  const int vec_id = threadIdx.x / w;
+  int r0[kVecTileRows], r1[kVecTileRows];
+#pragma unroll
+  for (int k = 0; k < kVecTileRows; ++k) {
+    const int row = row_base + vec_id + k * vecs;
+    r0[k] = r1[k] = 0;
+    if (row < row_end) {
+      r0[k] = rp[row];
+      r1[k] = rp[row + 1];
+    }
+  }
+  double acc[kVecTileRows] = {0.0, 0.0, 0.0, 0.0};
+  for (int off = s0 & ~3; off < s1; off += kTile) {
+    stage_products<kThreads, kNnzPerThread, NTC, NTV>(lds, off, s1, nnz, ci, v, x);
+    __syncthreads();
+    int lo[kVecTileRows], hi[kVecTileRows];
+#pragma unroll
+    for (int k = 0; k < kVecTileRows; ++k) {
+      lo[k] = (r0[k] > off ? r0[k] : off) - off;
+      const int h = (r1[k] < off + kTile ? r1[k] : off + kTile) - off;
+      hi[k] = h > lo[k] ? h : lo[k];
+    }
+    tile_rows_sum<kThreads, kVecTileRows>(lds, spans, lo, hi, lane, w, acc);
+    if (off + kTile < s1) __syncthreads(); // the next round overwrites the tile
+  }
+#pragma unroll
+  for (int k = 0; k < kVecTileRows; ++k) {
+    const double s = group_sum_dyn(acc[k], w); // every lane takes part
+    const int row = row_base + vec_id + k * vecs;
+    if (row < row_end && lane == 0) store_y(y, row, alpha, beta, s);
   }
 }
 
@@ -243,6 +310,35 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
   else
     hipLaunchKernelGGL(vector_row_kernel<4>, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1, alpha, beta,
                        A.rp, A.ci, A.v, x, y, A.guard, A.stale);
+}
+
+void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int w0, int w1, double avg0, double avg1,
+                        int target_products, int xcd_chunk, int stream_policy, double alpha, double beta, const double *x,
+                        double *y) {
+  if (A.m <= 0) return;
+  if (row_split < 0) row_split = 0;
+  if (row_split > A.m) row_split = A.m;
+  // rows per workgroup of a half: enough to fill the tile, at most kVecTileRows per lane group
+  auto rows_for = [&](double avg, int w) {
+    const long long cap = static_cast<long long>(kVecTileRows) * (kThreads / w);
+    long long r = avg > 0.0 ? static_cast<long long>(target_products / avg) : cap;
+    if (r > cap) r = cap;
+    return static_cast<int>(r < 1 ? 1 : r);
+  };
+  const int rpb0 = rows_for(avg0, w0), rpb1 = rows_for(avg1, w1);
+  const int nb0 = ceil_div_ll(row_split, rpb0);
+  const int nb1 = ceil_div_ll(A.m - row_split, rpb1);
+  if (nb0 + nb1 == 0) return;
+#define SPMV_ACC_LAUNCH_VT(NC, NV)                                                                                    \
+  hipLaunchKernelGGL((vector_tile_kernel<NC, NV>), dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, A.nnz, row_split, nb0, \
+                     w0, w1, rpb0, rpb1, xcd_chunk, alpha, beta, A.rp, A.ci, A.v, x, y, A.guard, A.stale)
+  switch (stream_policy & 3) {
+  case 1: SPMV_ACC_LAUNCH_VT(false, false); break;
+  case 2: SPMV_ACC_LAUNCH_VT(false, true); break;
+  case 3: SPMV_ACC_LAUNCH_VT(true, false); break;
+  default: SPMV_ACC_LAUNCH_VT(true, true); break;
+  }
+#undef SPMV_ACC_LAUNCH_VT
 }
 
 void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y) {

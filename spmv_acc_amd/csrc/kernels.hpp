@@ -48,6 +48,12 @@ constexpr int kPlusLongChunk = 2 * kPlusMinNnz;        // NN_EI * MIN_NNZ_PER_BL
 void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w0, int w1, double alpha, double beta,
                        const double *x, double *y, bool single_row_groups = false);
 
+// The same lane layout on the tile machinery (LDS-staged 16-B stream loads; up to four rows per lane group so the tile fills).
+// avg0 / avg1: average row length of rows [0, row_split) / [row_split, m) (sizes the rows per workgroup of each half).
+void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int w0, int w1, double avg0, double avg1,
+                        int target_products, int xcd_chunk, int stream_policy, double alpha, double beta, const double *x,
+                        double *y);
+
 // wavefront-per-row for long rows: 4 consecutive non-zeros per lane per step (16-B loads), two steps in flight.
 void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y);
 
@@ -78,6 +84,22 @@ constexpr int kRowblockMaxRounds = 8;
 // (hip-flat/flat_imp.inl:108-131) computed by one binary search per entry; no memset needed.
 void launch_break_points(hipStream_t stream, const int *rp, int m, int nnz, int stride, int *bp, int bp_len);
 
+// ---- opt-in 16-bit column encoding (k_col16.hip; flat family only) ---------------------------------------------------------
+constexpr int kCol16Chunk = 256; // non-zeros per base column: one wavefront's step of the tile kernels (64 lanes x 4)
+struct Col16 {
+  int nchunks = 0;
+  unsigned short *d16 = nullptr; // nchunks * 256 offsets from base[chunk]; 0xFFFF = escape
+  int *base = nullptr;           // nchunks
+  int *esc_start = nullptr;      // nchunks + 1: first escape of the chunk in esc_cols
+  int *esc_cols = nullptr;       // the escaped columns in non-zero order
+  int escapes = 0;
+};
+size_t col16_scan_bytes(int nchunks);
+void launch_col16_base(hipStream_t stream, const int *ci, int nnz, int nchunks, int *base, int *esc_count);
+bool launch_col16_scan(hipStream_t stream, int nchunks, const int *esc_count, int *esc_start, void *tmp, size_t tmp_bytes);
+void launch_col16_encode(hipStream_t stream, const int *ci, int nnz, int nchunks, const int *base, const int *esc_start,
+                         unsigned short *d16, int *esc_cols);
+
 // flat family: one workgroup per `stride` non-zeros (stride = kThreads * {4, 8, 16}); complete rows are
 // stored directly, the two possible partial rows per tile go to head/tail carries that a small second
 // kernel folds into y in tile order.
@@ -96,6 +118,7 @@ struct FlatPlan {
                             // can_finish): tiles finish their cut rows themselves.  Chosen by timing, engine.cpp.
   int max_tile_rows = 0;    // most rows any one tile (= workgroup) owns (plan-time probe)
   bool early_stream = false; // issue the tile's stream loads before the break point -> rowptr chain (small grids, timed)
+  const Col16 *col16 = nullptr; // opt-in: columns from the plan's 16-bit encoding instead of colindex (NPT 8 tiles only)
   bool mode_tuned = false;  // tuned_fixup holds the timed choice
   bool tuned_fixup = true;
 };

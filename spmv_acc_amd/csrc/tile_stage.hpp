@@ -187,6 +187,83 @@ __device__ __forceinline__ void stage_finish(double *__restrict__ lds, const Str
   }
 }
 
+// ---- staging from the 16-bit column encoding (k_col16.hip) ---------------------------------------------------------------------
+// Same step as the branch-free form of stage_products with the colindex stream replaced by the plan's encoding: one 8-B load
+// of four 16-bit offsets per lane per step (instead of 16 B), the chunk's base from a wave-uniform load (a0 is a multiple of
+// 256, so a wavefront's step is exactly one chunk), and -- only in wavefronts that hold an escape, a wave-uniform test -- the
+// escaped columns from the chunk's slice of esc_cols, found by a prefix count of the lanes' escapes.
+// Precondition (checked by the caller): every 4-group below `hi` lies inside the arrays (stage_fast_ok).
+typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
+typedef ushort4v ushort4v_a2 __attribute__((aligned(2)));
+
+template <int THREADS, int NPT, bool NTV>
+__device__ __forceinline__ void stage_products_col16(double *__restrict__ lds, int a0, int hi, const unsigned short *__restrict__ d16,
+                                                     const int *__restrict__ base, const int *__restrict__ esc_start,
+                                                     const int *__restrict__ esc_cols, const double *__restrict__ v,
+                                                     const double *__restrict__ x) {
+  constexpr int K = NPT / 4;
+  ushort4v d[K];
+  double2v va[K], vb[K];
+  int bs[K], es[K];
+  bool has[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int wave_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + k * THREADS));
+    has[k] = wave_j < hi;
+    if (has[k]) {
+      const int j = a0 + 4 * (threadIdx.x + k * THREADS);
+      const int chunk = wave_j >> 8;
+      bs[k] = base[chunk];
+      es[k] = esc_start[chunk];
+      d[k] = __builtin_nontemporal_load(reinterpret_cast<const ushort4v_a2 *>(d16 + j)); // (d16 is padded to whole chunks)
+      const int jv = (j < hi) ? j : a0; // lanes past hi re-read the tile's first group of values (as stage_products does)
+      va[k] = load_stream_d2<NTV>(v + jv);
+      vb[k] = load_stream_d2<NTV>(v + jv + 2);
+    }
+  }
+  double xg[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (has[k]) {
+      int c[4] = {bs[k] + d[k].x, bs[k] + d[k].y, bs[k] + d[k].z, bs[k] + d[k].w};
+      const bool e0 = d[k].x == 0xFFFF, e1 = d[k].y == 0xFFFF, e2 = d[k].z == 0xFFFF, e3 = d[k].w == 0xFFFF;
+      const int mine = (e0 ? 1 : 0) + (e1 ? 1 : 0) + (e2 ? 1 : 0) + (e3 ? 1 : 0);
+      if (__ballot(mine > 0)) { // wave-uniform; every lane of the wave takes part in the prefix count
+        int incl = mine;
+        const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+          const int up = __shfl_up(incl, o, kWave);
+          if (lane >= o) incl += up;
+        }
+        int pos = es[k] + incl - mine;
+        if (e0) c[0] = esc_cols[pos++];
+        if (e1) c[1] = esc_cols[pos++];
+        if (e2) c[2] = esc_cols[pos++];
+        if (e3) c[3] = esc_cols[pos++];
+      }
+      xg[k][0] = x[c[0]];
+      xg[k][1] = x[c[1]];
+      xg[k][2] = x[c[2]];
+      xg[k][3] = x[c[3]];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (has[k]) {
+      const int g = threadIdx.x + k * THREADS;
+      double2v p0, p1;
+      p0.x = va[k].x * xg[k][0];
+      p0.y = va[k].y * xg[k][1];
+      p1.x = vb[k].x * xg[k][2];
+      p1.y = vb[k].y * xg[k][3];
+      double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
+      dst[0] = p0;
+      dst[1] = p1;
+    }
+  }
+}
+
 // ---- per-row sums over a staged tile ---------------------------------------------------------------------------------------
 // Every lane group (w lanes, w wave-uniform or compile-time) sums its row's span [lo, hi) of the tile.  A span of more than
 // max(63, 16 w) products would keep w lanes busy for dozens of dependent LDS reads while the rest of the workgroup idles (a
@@ -240,6 +317,49 @@ __device__ __forceinline__ double tile_row_sum(const double *__restrict__ lds, T
     __syncthreads(); // ... and the counter is back at 0 before anyone can post in a later call
   }
   return s;
+}
+
+// The same for lane groups that own R rows each (vector-row tile kernel): all R spans are summed or posted first, ONE barrier
+// counts the posting lanes, and only then -- every thread being on the slow path -- is the shared post counter read.
+template <int THREADS, int R>
+__device__ __forceinline__ void tile_rows_sum(const double *__restrict__ lds, TileSpans &sh, const int (&lo)[R], const int (&hi)[R],
+                                              int lane, int w, double (&acc)[R]) {
+  int slot[R];
+  bool posted_any = false;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int span = hi[k] - lo[k];
+    const bool posted = w < kWave && span >= 64 && span > 16 * w;
+    slot[k] = -1;
+    if (posted) {
+      if (lane == 0) {
+        slot[k] = atomicAdd(&sh.n, 1);
+        sh.lo[slot[k]] = lo[k];
+        sh.hi[slot[k]] = hi[k];
+        posted_any = true;
+      }
+    } else {
+      for (int j = lo[k] + lane; j < hi[k]; j += w) acc[k] += lds[j];
+    }
+  }
+  if (__syncthreads_count(posted_any) > 0) {
+    const int n = sh.n; // all posts precede the barrier; nobody posts again before the last barrier below
+    const int wave = threadIdx.x / kWave, l = threadIdx.x & (kWave - 1);
+    for (int e = wave; e < n; e += THREADS / kWave) {
+      double t = 0.0;
+      const int b = sh.hi[e];
+      for (int j = sh.lo[e] + l; j < b; j += kWave) t += lds[j];
+      t = group_sum<64>(t);
+      if (l == 0) sh.sum[e] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+      if (slot[k] >= 0) acc[k] += sh.sum[slot[k]];
+    __syncthreads();
+    if (threadIdx.x == 0) sh.n = 0;
+    __syncthreads();
+  }
 }
 
 } // namespace dev

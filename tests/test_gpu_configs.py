@@ -8,11 +8,13 @@ configs[4]  one 32 M-row shard of the 256 M-row banded matrix (global column ids
 The CPU oracle cannot walk these sizes in seconds, so each matrix is checked three ways (the pattern of
 tests/test_gpu_parity.py::test_full_size_*):
   * against the oracle (oracle_host_spmv = cli/verification.cpp:56-66) on a row PREFIX of the full-size run,
-  * against an independent fp64 evaluation on the device (products scattered with index_add, another summation order),
+  * against an independent fp64 evaluation on the device (torch's segmented sum over the products, another summation order),
     with the scaled-error gate and the reference's own verify_y rule (cli/verification.cpp:15-38),
   * through size-independent properties: row sums for x = 1, linearity in x, y = alpha*(A x) + beta*y0.
 Tolerances as in test_gpu_parity.py: scaled error <= 1e-12, reference verdict rel 1e-7 / abs 1e-14.
 """
+import time
+
 import numpy as np
 import pytest
 
@@ -48,9 +50,17 @@ def _spmv(torch, A, strat, alpha, beta, x, y0):
     return y
 
 
+_T0 = time.time()
+
+
+def _say(msg):
+    print(f"[configs +{time.time() - _T0:6.1f}s] {msg}", flush=True)  # (run with -s on the GPU box: a long test is then seen to be alive)
+
+
 def _device_reference(torch, A, x):
-    """(A x, |A| |x|) in fp64 on the device, independent of the library: products scattered with index_add, chunked so the
-    int64 row ids of a 0.5 B-non-zero matrix never exist all at once."""
+    """(A x, |A| |x|) in fp64 on the device, independent of the library: torch's segmented sum over the products (one
+    sequential sum per row: no atomics, so a hub row of millions of non-zeros is not a contention hot spot), in chunks of
+    rows so the temporaries of a 0.5 B-non-zero matrix stay small."""
     m, n, nnz, rp, ci, v = A
     ax = torch.zeros(m, dtype=torch.float64, device="cuda")
     mag = torch.zeros(m, dtype=torch.float64, device="cuda")
@@ -62,11 +72,10 @@ def _device_reference(torch, A, x):
         s, e = int(rp64[r0].item()), int(rp64[r1].item())
         if e == s:
             continue
-        rows = torch.repeat_interleave(torch.arange(r0, r1, device="cuda"), lens[r0:r1], output_size=e - s)
         prod = v[s:e] * x[ci[s:e].long()]
-        ax.index_add_(0, rows, prod)
-        mag.index_add_(0, rows, prod.abs())
-        del rows, prod
+        ax[r0:r1] = torch.segment_reduce(prod, "sum", lengths=lens[r0:r1], unsafe=True)
+        mag[r0:r1] = torch.segment_reduce(prod.abs(), "sum", lengths=lens[r0:r1], unsafe=True)
+        del prod
     return ax, mag
 
 
@@ -98,17 +107,20 @@ def _prefix_vs_oracle(torch, oracle, A, strats, x, y0, max_rows=150_000, max_nnz
 def _full_size_checks(torch, oracle, A, strats, seed):
     m, n, nnz, rp, ci, v = A
     x, y0 = _vectors(torch, m, n, seed)
+    _say(f"{m} rows, {nnz} nnz: device reference")
     # 1. the reference's protocol (alpha = beta = 1) against the independent device evaluation, all rows
     ax, mag = _device_reference(torch, A, x)
     ref = ax + y0
     scale = (mag + y0.abs()).clamp_min(1e-300)
     got = {}
     for strat in strats:
+        _say(f"  {strat}: alpha = beta = 1 against the device reference")
         y = _spmv(torch, A, strat, 1.0, 1.0, x, y0)
         err = ((y - ref).abs() / scale).max().item()
         assert err <= SCALED_TOL, (strat, "scaled error vs device reference", err)
         assert _verify_y_failures(torch, y, ref) == 0, (strat, "verify_y rule")
         got[strat] = y
+    _say("  alpha / beta decomposition, beta = 0")
     # 2. general alpha / beta decomposes as alpha * (A x) + beta * y0; beta = 0 ignores y
     zeros = torch.zeros(m, dtype=torch.float64, device="cuda")
     for strat in strats:
@@ -119,6 +131,7 @@ def _full_size_checks(torch, oracle, A, strats, seed):
         nan_y = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
         y = _spmv(torch, A, strat, 1.0, 0.0, x, nan_y)
         assert ((y - ax).abs() / mag.clamp_min(1e-300)).max().item() <= SCALED_TOL, (strat, "beta = 0 must not read y")
+    _say("  row sums, linearity")
     # 3. row sums (x = 1) and linearity in x
     ones = torch.ones(n, dtype=torch.float64, device="cuda")
     sums, sums_mag = _device_reference(torch, A, ones)
@@ -132,7 +145,9 @@ def _full_size_checks(torch, oracle, A, strats, seed):
         sc = (3.0 * mag + _device_reference(torch, A, x2)[1]).clamp_min(1e-300)
         assert ((both - (3.0 * a1 + a2)).abs() / sc).max().item() <= 1e-11, (strat, "linearity")
     # 4. a row prefix against the CPU oracle
-    _prefix_vs_oracle(torch, oracle, A, strats, x, y0)
+    _say("  row prefix against the CPU oracle")
+    k = _prefix_vs_oracle(torch, oracle, A, strats, x, y0)
+    _say(f"  done ({k} prefix rows)")
     return got
 
 
@@ -158,8 +173,10 @@ def test_configs3_rmat25_line_enhance_full_size(torch_dev, oracle):
     """BASELINE configs[3]: R-MAT scale 25 (33.5 M rows, ~0.53 B non-zeros, hub rows of millions) under line_enhance --
     the balance probe must hand it to the row-block-plus kernel -- plus flat as the second opinion."""
     torch = torch_dev
+    _say("R-MAT scale 25: generating")
     A = synth.rmat_torch(25, device="cuda", seed=0xC4)
     m, n, nnz, rp = A[0], A[1], A[2], A[3]
+    _say(f"R-MAT scale 25: {nnz} nnz")
     assert m == n == 1 << 25 and 480_000_000 < nnz < 537_000_000
     lens = rp[1:] - rp[:-1]
     assert int(lens.max().item()) > 100_000 and int(lens.min().item()) == 0  # power law: hub rows and empty rows

@@ -252,3 +252,57 @@ def test_row_sharded_event_ordering_on_one_rank_rccl(torch_dev, oracle):
     finally:
         dist.destroy_process_group()
         spmv_acc_amd.load_library().spmv_acc_set_stream(None)
+
+
+def test_opt_in_col16_encoding_matches_plain_flat(torch_dev, oracle, hiplib):
+    """Tunable col16 (off by default): flat reads the plan's 16-bit column encoding (per-256-non-zero base + escape list)
+    instead of colindex.  Same products in the same order -> bit-identical to flat without it (same tile size and cut-row
+    form), on local columns (few escapes), on far columns (10 %), on random columns (almost every entry escapes), on every
+    residue of nnz mod 4 (the ragged last group reads colindex as usual) and on a row shard that is not rebased."""
+    torch = torch_dev
+    cases = []
+    rng = np.random.default_rng(21)
+    cases.append(("fem-like", synth.csr_from_row_lengths(rng.integers(20, 40, size=20000), 20000, rng, locality=300, far_fraction=0.02)))
+    cases.append(("far 10 %", synth.csr_from_row_lengths(rng.integers(3, 8, size=60000), 55000, rng, locality=64, far_fraction=0.10)))
+    cases.append(("random columns", synth.csr_from_row_lengths(rng.integers(0, 30, size=8000), 3_000_000, rng, locality=1_400_000, far_fraction=0.5)))
+    cases.append(("long rows", synth.csr_from_row_lengths(rng.integers(900, 5000, size=300), 200000, rng, locality=90000, far_fraction=0.0)))
+    for r in range(4):
+        lens = rng.integers(1, 9, size=3000)
+        lens[-1] += (r - int(lens.sum())) % 4  # nnz mod 4 == r
+        cases.append((f"nnz mod 4 = {r}", synth.csr_from_row_lengths(lens, 3000, rng)))
+    try:
+        for tag, (rowptr, cols, vals) in cases:
+            m, n, nnz = rowptr.size - 1, int(cols.max()) + 1 if cols.size else 1, int(rowptr[-1])
+            x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+            drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+            ref = oracle.host_spmv(0.5, -2.0, rowptr, cols, vals, x, y0)
+            out = {}
+            for mode in (0, 1):
+                for finish in (0, 1):
+                    hiplib.spmv_acc_reset_tunables()
+                    for k, val in (("col16", mode), ("flat_npt", 8), ("flat_finish", finish), ("flat_early", 0), ("stream_plain", 1)):
+                        assert hiplib.spmv_acc_set_tunable(k.encode(), val) == 0
+                    dy = dev(torch, y0)
+                    spmv_acc_amd.csr_spmv(0.5, -2.0, m, n, nnz, drp, dci, dv, dx, dy, strategy="flat")
+                    torch.cuda.synchronize()
+                    out[(mode, finish)] = dy.cpu().numpy()
+                    assert oracle.scaled_error(out[(mode, finish)], ref, 0.5, -2.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, (tag, mode, finish)
+                    spmv_acc_amd.release_plans(drp)
+            for finish in (0, 1):
+                assert np.array_equal(out[(0, finish)], out[(1, finish)]), (tag, finish)
+        # a row shard handed over without rebasing (rowptr[0] > 0, offsets into the whole colindex / value arrays)
+        rowptr, cols, vals = synth.csr_from_row_lengths(rng.integers(10, 30, size=9000), 9000, rng, locality=200, far_fraction=0.05)
+        x, y0 = rng.standard_normal(9000), rng.standard_normal(9000)
+        r0, r1 = 3001, 7777
+        drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+        hiplib.spmv_acc_reset_tunables()
+        assert hiplib.spmv_acc_set_tunable(b"col16", 1) == 0
+        dy = dev(torch, y0[r0:r1])
+        spmv_acc_amd.csr_spmv(1.0, 1.0, r1 - r0, 9000, int(rowptr[r1]), drp[r0: r1 + 1], dci, dv, dx, dy, strategy="flat")
+        torch.cuda.synchronize()
+        ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)[r0:r1]
+        assert np.max(np.abs(dy.cpu().numpy() - ref)) <= 1e-11
+        spmv_acc_amd.release_plans(drp[r0: r1 + 1])
+    finally:
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans()

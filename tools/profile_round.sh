@@ -3,18 +3,22 @@
 #   1. --kernel-trace --stats   (per-kernel durations of the same command bench.py times)
 #   2. --pmc FETCH_SIZE         (own pass)
 #   3. --pmc WRITE_SIZE         (own pass; FETCH_SIZE needs 3 of the 4 TCC slots)
-# usage: tools/profile_round.sh <tag> [bench.py args...]
+#   4. pmc_entry.json           (the profiles/pmc_traffic.json entry, computed from the two PMC summaries of THIS run and the
+#                                algorithmic bytes bench.py printed under the trace -- tools/collect_profile.py merges it)
+# usage: tools/profile_round.sh <tag> [bench.py args...]        e.g.  tools/profile_round.sh r02 --no-legs
 set -o pipefail
-TAG=${1:-r01}; shift
+TAG=${1:-r02}; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+echo "[profile_round] kernel trace"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py "$@" --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.log || exit 1
 S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 { head -1 $S; grep -E "spmv_acc" $S; } > $OUT/kernel_stats_spmv.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 500 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py "$@" --no-cpu-baseline --steps 20 --warmup 5 > $OUT/bench_under_$c.json 2> $OUT/pmc_$c.log || exit 1
+  echo "[profile_round] pmc $c"
+  timeout -k 10 500 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py "$@" --no-cpu-baseline --no-legs --no-sensitivity --steps 20 --warmup 5 > $OUT/bench_under_$c.json 2> $OUT/pmc_$c.log || exit 1
   F=$(find $OUT/pmc_$c -name "*counter_collection.csv" | head -1)
   python3 - "$F" "$c" > $OUT/pmc_$c.summary.txt <<'PY'
 import csv, sys, collections
@@ -29,4 +33,27 @@ for k, v in acc.items():
 PY
 done
 rm -rf $OUT/trace/*/*_kernel_trace.csv $OUT/pmc_*/  # keep summaries only (small)
-cat $OUT/kernel_stats_spmv.csv $OUT/pmc_*.summary.txt
+python3 - "$OUT" "$TAG" > $OUT/pmc_entry.json <<'PY'
+import json, re, sys
+out, tag = sys.argv[1], sys.argv[2]
+def dominant(path):
+    best = None
+    for line in open(path):
+        m = re.match(r"(\w+) kernel=(\S+) dispatches=(\d+) mean_KB=([\d.]+)", line)
+        # the SpMV kernel of the timed loop: most dispatches among the tile kernels
+        if m and any(k in m.group(2) for k in ("rowblock_stream", "flat_tile", "plus_kernel", "vector_row", "wave_row")):
+            if best is None or int(m.group(3)) > best[1]:
+                best = (m.group(2), int(m.group(3)), float(m.group(4)))
+    return best
+f, w = dominant(f"{out}/pmc_FETCH_SIZE.summary.txt"), dominant(f"{out}/pmc_WRITE_SIZE.summary.txt")
+bench = json.loads(open(f"{out}/bench_under_trace.json").read().strip().splitlines()[-1])
+balg = bench["roofline"]["algorithmic_bytes_per_launch"]
+fetch_b, write_b = f[2] * 1024.0, w[2] * 1024.0
+corrected = 2.0 * fetch_b + write_b                      # MI355X_MICROARCH.md: gfx950 tallies wide coalesced reads at half
+reads_alg = balg - write_b                               # algorithmic read bytes
+lower = reads_alg + max(2.0 * fetch_b - reads_alg, 0.0) / 2.0 + write_b  # over-fetch counted at its raw (64-B sector) size
+print(json.dumps({"kernel": f[0], "FETCH_SIZE_KB": f[2], "WRITE_SIZE_KB": w[2], "corrected_bytes": int(round(corrected)),
+                  "lower_bound_bytes": int(round(lower)), "algorithmic_bytes": balg, "round": tag,
+                  "workload": bench["config"]["workload"], "strategy": bench["config"]["strategy"]}))
+PY
+cat $OUT/kernel_stats_spmv.csv $OUT/pmc_*.summary.txt $OUT/pmc_entry.json
