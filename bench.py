@@ -279,19 +279,21 @@ def rccl_debug_summary(rank):
     import re
 
     path = os.environ.get("NCCL_DEBUG_FILE", "").replace("%h", os.uname().nodename).replace("%p", str(os.getpid()))
-    out = {"nranks_seen": None, "lines": []}
+    out = {"nranks_seen": None, "debug_file": path, "debug_file_bytes": None, "lines": []}
     try:
         text = open(path, errors="replace").read()
-    except OSError:
+    except OSError as ex:
+        out["debug_file_error"] = repr(ex)[:120]
         return out
+    out["debug_file_bytes"] = len(text)
     m = re.findall(r"nranks (\d+)", text)
     if m:
         out["nranks_seen"] = int(m[-1])
-    for line in text.splitlines():
-        if re.search(r"Init COMPLETE|Algo|algorithm|Connected all|Channel 00[ /:]|via P2P|via SHM|via NET", line):
-            out["lines"].append(re.sub(r"^.*NCCL INFO ", "", line)[:160])
-            if len(out["lines"]) >= 8:
-                break
+    picked = [ln for ln in text.splitlines()
+              if re.search(r"Init COMPLETE|Algo|algorithm|Connected all|Channel 00[ /:]|via P2P|via SHM|via NET|nranks", ln)]
+    if not picked:
+        picked = [ln for ln in text.splitlines() if "NCCL" in ln]
+    out["lines"] = [re.sub(r"^.*NCCL INFO ", "", ln)[:160] for ln in picked[:8]]
     return out
 
 
@@ -313,6 +315,19 @@ def copy_ceiling_gbs(torch, device):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner with NCCL_DEBUG set, loader
+    # notices): from here on file descriptor 1 is stderr, and the JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("SPMV_ACC_BENCH_FORCE_DIST", "0") == "1":
+        # RCCL's own account of the communicator goes to a per-rank file and is quoted in the JSON line (rccl_debug_summary).
+        # Set BEFORE torch (and with it librccl) is loaded: measured on this image, the same variables set after `import torch`
+        # turn the version banner on but never create the file.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("SPMV_ACC_BENCH_BACKEND", "nccl") == "nccl":
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/spmv_acc_bench_rccl_{os.getpid()}_rank{os.environ.get('RANK', '0')}.log")
     import torch
     import torch.distributed as dist
 
@@ -340,11 +355,6 @@ def main():
     if dist_leg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":  # RCCL's own account of the communicator, quoted in the JSON line (rccl_debug_summary)
-            os.environ.setdefault("NCCL_DEBUG", "INFO")
-            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING")
-            os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/spmv_acc_bench_rccl_{os.getpid()}_rank{rank}.log")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -493,7 +503,9 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
     if dist_leg:
         dist.destroy_process_group()
 

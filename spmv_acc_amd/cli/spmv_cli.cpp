@@ -189,7 +189,10 @@ void unstage(DeviceData &d) {
 // The expected y from rocSPARSE's CSR SpMV on the staged arrays.  The library is opened at run time and only when
 // --device-verify asks for it, so neither spmv-cli nor libspmv_acc.so carries a link-time dependency on it.
 bool rocsparse_expected_y(const DeviceData &d, double alpha, double beta, const std::vector<double> &y0, std::vector<double> &out) {
-  void *lib = dlopen("librocsparse.so.1", RTLD_NOW | RTLD_LOCAL);
+  // SPMV_CLI_ROCSPARSE=<path> picks a particular build (e.g. the one bundled with a PyTorch wheel)
+  void *lib = nullptr;
+  if (const char *env = std::getenv("SPMV_CLI_ROCSPARSE")) lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("librocsparse.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!lib) lib = dlopen("librocsparse.so", RTLD_NOW | RTLD_LOCAL);
   if (!lib) lib = dlopen("/opt/rocm/lib/librocsparse.so", RTLD_NOW | RTLD_LOCAL);
   if (!lib) {

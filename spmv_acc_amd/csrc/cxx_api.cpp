@@ -96,7 +96,13 @@ void adaptive_vec_row_sparse_spmv(const int nnz_block_0, const int nnz_block_1, 
   A.rp = d_csr_desc.row_ptr;
   A.ci = d_csr_desc.col_index;
   A.v = d_csr_desc.values;
-  auto vec_for = [](long long avg) { return avg <= 4 ? 2 : avg <= 8 ? 4 : avg <= 16 ? 8 : avg <= 32 ? 16 : avg <= 64 ? 32 : 64; };
+  // lanes per row for lanes that read an LDS tile: pow2 >= avg / 8, at least 2 (k_vector_row.hip; the reference's rule, which
+  // sizes lanes that stream from global memory, is vector_row.cpp:15-27)
+  auto vec_for = [](long long avg) {
+    int w = 2;
+    while (w < 64 && 8LL * w < avg) w <<= 1;
+    return w;
+  };
   const int half = m / 2;
   const int w0 = vec_for(half > 0 ? nnz_block_0 / half : 0);
   const int w1 = vec_for(nnz_block_1 / (m - half));

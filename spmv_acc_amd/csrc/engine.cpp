@@ -81,7 +81,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kTunableCount
 };
 Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
@@ -108,7 +108,7 @@ Tunable g_tunables[] = {
                                // kFlatSmallNnz non-zeros 4 and 8 are both timed on the matrix (small grids: more, shorter workgroups)
     {"validate", 0, 0},        // 1: check rowptr / colindex of every new matrix on the device before the first launch
     {"rowlen", -1, -1},        // row-block family: row extents from the plan's 1-byte row lengths + per-block bases instead of
-                               // rowptr: -1 where rows average <= 16 non-zeros (rowptr is then >= 2 % of the traffic), 0 never, 1 always
+                               // rowptr: -1 where rows average <= 8 non-zeros (rowptr is then >= 3.5 % of the traffic), 0 never, 1 always
     {"flat_early", -1, -1},    // flat: issue a tile's stream loads before its break point -> rowptr chain: -1 timed per matrix
                                // below kFlatSmallNnz non-zeros (else off), 0 off, 1 on
     {"vector_tile", 1, 1},     // vector_row / light / the two-width split: 1 = w lanes per row over LDS-staged tiles (16-B stream
@@ -117,6 +117,7 @@ Tunable g_tunables[] = {
     {"col16", 0, 0},           // OPT-IN, flat only: 1 = the plan holds a 16-bit encoding of colindex (per-256-non-zero base + escape list,
                                // k_col16.hip) and the tile kernel streams 2 B instead of 4 B per column.  The plan then holds a copy
                                // derived from colindex: after editing colindex in place call spmv_acc_release_plans.
+    {"vector_width", 0, 0},    // vector_row / light: lanes per row; 0 = the reference's rule (vector_row.cpp:15-27: pow2 >= avg row length / 2)
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -286,6 +287,16 @@ int classic_vec(long long avg) {
   if (avg <= 32) return 16;
   if (avg <= 64) return 32;
   return 64;
+}
+} // namespace
+
+namespace {
+// lanes per row of the vector-row TILE kernel: same shape as classic_vec, 8 products per lane instead of 2 (the products are
+// in LDS already; see k_vector_row.hip)
+int tile_vec(long long avg) {
+  int w = 2;
+  while (w < 64 && 8LL * w < avg) w <<= 1;
+  return w;
 }
 } // namespace
 
@@ -868,6 +879,7 @@ template <typename Launch> bool autotune_policy(Plan &p, int fam, hipStream_t st
 // Opt-in 16-bit column encoding of the whole matrix (k_col16.hip): base + escape count per 256-non-zero chunk, exclusive scan
 // of the counts, then the offsets and the escape list.  One synchronisation (the escape total sizes the last allocation).
 bool ensure_col16(Plan &p, hipStream_t st) {
+  constexpr size_t kWarpPad = 64;
   if (p.col16.d16) return true;
   ++t_plan_work;
   Col16 &C = p.col16;
@@ -890,7 +902,9 @@ bool ensure_col16(Plan &p, hipStream_t st) {
     ok = launch_col16_scan(st, nchunks, esc_count, C.esc_start, tmp, tmp_bytes) &&
          hip_ok(hipMemcpyAsync(&total, C.esc_start + nchunks, sizeof(int), hipMemcpyDeviceToHost, st), "read col16 escape total") &&
          hip_ok(hipStreamSynchronize(st), "sync col16") &&
-         hip_ok(hipMalloc(reinterpret_cast<void **>(&C.esc_cols), sizeof(int) * (static_cast<size_t>(total) + 1)), "hipMalloc col16 escapes");
+         // (+ 64: every wavefront preloads 64 entries from its chunk's first escape on, also at the very end of the list)
+         hip_ok(hipMalloc(reinterpret_cast<void **>(&C.esc_cols), sizeof(int) * (static_cast<size_t>(total) + kWarpPad)), "hipMalloc col16 escapes") &&
+         hip_ok(hipMemsetAsync(C.esc_cols, 0, sizeof(int) * (static_cast<size_t>(total) + kWarpPad), st), "memset col16 escapes");
   }
   if (ok) {
     launch_col16_encode(st, p.A.ci, p.A.nnz, nchunks, C.base, C.esc_start, C.d16, C.esc_cols);
@@ -1157,7 +1171,9 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
   }
   const RowDigest *dg = nullptr;
   const int want_lens = tun(kT_rowlen);
-  if (want_lens > 0 || (want_lens < 0 && static_cast<long long>(p.A.nnz) <= 16LL * p.A.m)) {
+  // (auto: rows of <= 8 non-zeros on average, where rowptr is >= 3.5 % of the traffic; measured at 12.6 per row the scan costs
+  // more than the bytes save -- largebasis-sized 17.8 vs 17.4 us)
+  if (want_lens > 0 || (want_lens < 0 && static_cast<long long>(p.A.nnz) <= 8LL * p.A.m)) {
     if (!ensure_digest(p, rpb, st)) return false;
     dg = &p.digest;
   }
@@ -1326,9 +1342,16 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   case kLight:
   case kVectorRow:
   {
-    const int w = classic_vec(avg);
+    const int forced_w = tun(kT_vector_width);
+    const bool tile_form = tun(kT_vector_tile) != 0;
+    const int w = (forced_w >= 1 && forced_w <= 64 && (forced_w & (forced_w - 1)) == 0) ? forced_w
+                  : tile_form ? tile_vec(avg) : classic_vec(avg);
     if (tun(kT_rowblock_guard) && !probe_rowblock(*p, kThreads / w, st)) return;
-    if (tun(kT_vector_tile) && p->rowblock_ok != 0) {
+    if (tile_form && p->rowblock_ok == 0 && !tun(kT_rescue_flat)) {
+      // very uneven rows (hub rows of a power-law matrix): w lanes walking a row of 10^5 non-zeros serialise the kernel (5.8 ms
+      // on a 60 000-row power-law matrix that the other families run in 30 us); same rescue as the row-block family
+      run_plus(st, *p, h_rowptr, alpha, beta, dx, dy);
+    } else if (tile_form && p->rowblock_ok != 0) {
       // the reference's lane width per row (vector_row.cpp:15-27) on the tile machinery
       const double a = static_cast<double>(p->A.nnz) / m;
       auto launch = [&](int pol, double al, double be, double *yy) {
@@ -1377,7 +1400,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
         if (tun(kT_vector_tile)) {
           const double f0 = half_rows > 0 ? static_cast<double>(p->samples.half) / half_rows : 0.0;
           const double f1 = (static_cast<double>(p->samples.last) - p->samples.half) / (m - half_rows);
-          launch_vector_tile(st, p->A, half_rows, classic_vec(a0), classic_vec(a1), f0, f1, tun(kT_rowblock_target),
+          launch_vector_tile(st, p->A, half_rows, tile_vec(a0), tile_vec(a1), f0, f1, tun(kT_rowblock_target),
                              tun(kT_xcd_chunk), policy_for(*p, kFamVector), alpha, beta, dx, dy);
         } else {
           launch_vector_row(st, p->A, half_rows, classic_vec(a0), classic_vec(a1), alpha, beta, dx, dy);

@@ -63,8 +63,10 @@ struct Col16Dev {
   const int *base, *esc_start, *esc_cols;
 };
 
+// (amdgpu_waves_per_eu(7): the register allocator is asked to stay within 72 VGPRs -- 7 workgroups per CU -- where the
+// plain kernel with the finishing prefetch would take 78; the stream-first variants need more registers by design)
 template <int NPT, bool NTC, bool NTV, bool EARLY, bool C16 = false>
-__global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int ntiles, double alpha, double beta,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY || NPT > 8 ? 1 : 7, 8))) void flat_tile_kernel(int m, int nnz, int ntiles, double alpha, double beta,
                                                              const int *__restrict__ rp, const int *__restrict__ bp,
                                                              const int *__restrict__ ci,
                                                              const double *__restrict__ v,
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
   static_assert(STRIDE / 64 <= kTileSpans, "TileSpans must hold every >= 64-product span of one tile");
   __shared__ __attribute__((aligned(16))) double lds[STRIDE]; // written 16 B at a time
   __shared__ double sh_tail_sum, sh_tail_yold;                 // partial (and old y) of the row this tile will finish itself
-  __shared__ int sh_tail_row, sh_tail_end;
+  __shared__ int sh_tail_row;
   __shared__ TileSpans spans;
   if (threadIdx.x == 0) {
     sh_tail_row = -1;
@@ -122,10 +124,41 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
   double y_old0 = 0.0;
   if (early_y && live0 && lane == 0) y_old0 = y[first + vec_id]; // read for cut rows too (<= 2 per tile): harmless
 
+  // Finish mode (reach > 0): the tile's last row, when it starts here and runs at most `reach` non-zeros past the tile, is
+  // completed by this tile's first wave.  Its overhang [t1, row end) is requested NOW, next to the stream loads -- the row's
+  // extents are two scalar loads away from end_excl -- so that nothing but a wave reduction is left for the end of the
+  // workgroup.  (Reading the overhang after the row loop made every workgroup end on a chain of dependent loads, which is
+  // why carries + the fix-up launch won on 150 us kernels; with the loads up front finishing is the cheaper form wherever it
+  // is legal.)
+  constexpr int FIN_STEPS = kFlatFinish / kWave;
+  int fin_c[FIN_STEPS];
+  double fin_v[FIN_STEPS];
+  bool fin = false; // wave-uniform
+  if (reach > 0 && nrows > 0 && t < ntiles - 1 && threadIdx.x < kWave) {
+    const int lr = end_excl - 1;
+    const int la = rp[lr], lb = rp[lr + 1];
+    fin = la >= t0 && lb > t1 && lb - t1 <= reach;
+    if (fin) {
+#pragma unroll
+      for (int k = 0; k < FIN_STEPS; ++k) {
+        const int j = t1 + static_cast<int>(threadIdx.x) + k * kWave;
+        fin_c[k] = j < lb ? load_stream(ci + j) : -1;
+        fin_v[k] = j < lb ? load_stream(v + j) : 0.0;
+      }
+    }
+  }
+
   if (C16 && stage_fast_ok(t1, nnz)) // (the one tile that holds the ragged end of the arrays reads colindex as usual)
     stage_products_col16<kThreads, NPT, NTV>(lds, t0, t1, c16.d16, c16.base, c16.esc_start, c16.esc_cols, v, x);
   else if (EARLY && early) stage_finish<kThreads, EARLY ? NPT : 4>(lds, early_regs, x);
   else stage_products<kThreads, NPT, NTC, NTV>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
+
+  double fin_extra = 0.0; // this lane's share of the overhang (first wave, finish mode)
+  if (fin) {
+#pragma unroll
+    for (int k = 0; k < FIN_STEPS; ++k)
+      if (fin_c[k] >= 0) fin_extra += fin_v[k] * x[fin_c[k]];
+  }
 
   __syncthreads();
 
@@ -158,7 +191,6 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
       } else if (b - t1 <= reach) {
         sh_tail_sum = s; // row starts here and ends at most kFlatFinish non-zeros into the next tile(s): finished below
         sh_tail_row = r;
-        sh_tail_end = b;
         sh_tail_yold = (base == 0 && early_y) ? y_old0 : (early_y ? y[r] : 0.0);
       } else {
         tail[t] = s; // long row: carry, folded by the fix-up kernel in tile order
@@ -168,27 +200,12 @@ __global__ __launch_bounds__(kThreads) void flat_tile_kernel(int m, int nnz, int
     }
   }
   if (reach > 0) __syncthreads();
-  // One wave reads the overhang [t1, row end) of the tile's last row straight from global memory (<= kFlatFinish
-  // non-zeros, kFlatFinish / 64 unrolled steps per lane) and completes y[row]: no carry, no second kernel for such rows.
+  // The first wave adds up the overhang it fetched at the start (<= kFlatFinish non-zeros, kFlatFinish / 64 per lane) and
+  // completes y[row]: no carry, no second kernel for such rows.  (sh_tail_row >= 0 exactly when `fin` was set: only the
+  // tile's last row can run past t1.)
   if (reach > 0 && threadIdx.x < kWave) {
     const int r = sh_tail_row;
-    double extra = 0.0;
-    if (r >= 0) {
-      const int b = sh_tail_end;
-      constexpr int STEPS = kFlatFinish / kWave; // all loads of the overhang in flight at once
-      int cc[STEPS];
-      double vv[STEPS];
-#pragma unroll
-      for (int k = 0; k < STEPS; ++k) {
-        const int j = t1 + static_cast<int>(threadIdx.x) + k * kWave;
-        cc[k] = j < b ? load_stream(ci + j) : -1;
-        vv[k] = j < b ? load_stream(v + j) : 0.0;
-      }
-#pragma unroll
-      for (int k = 0; k < STEPS; ++k)
-        if (cc[k] >= 0) extra += vv[k] * x[cc[k]];
-    }
-    extra = group_sum<64>(extra);
+    const double extra = group_sum<64>(fin_extra);
     if (r >= 0 && threadIdx.x == 0) y[r] = (beta == 0.0) ? alpha * (sh_tail_sum + extra) : alpha * (sh_tail_sum + extra) + beta * sh_tail_yold;
   }
   // a tile without a carried row says so (the fix-up reads tail_row only)

@@ -110,14 +110,16 @@ __global__ __launch_bounds__(kThreads) void vector_row_kernel(int m, int row_spl
 
 // CSR-Vector on the tile machinery (the form KERNEL_STRATEGY=VECTOR_ROW / LIGHT and the two-width split run by default): a
 // workgroup owns `rpb` consecutive rows, their non-zeros are staged into the LDS tile with the 16-B stream loads shared by
-// the other tile kernels, and every row is summed by the reference's w lanes (vector_row.cpp:15-27: w from the average row
-// length; one w per matrix half for the split, vector_row_adaptive.hpp:72-142).  A lane group owns up to kVecTileRows rows
-// (vecs apart), so that w lanes per row and a full 2048-product tile go together: 256/w groups x 4 rows x avg >= 1900 products
-// for every average row length the width rule maps to w.  Against the direct-from-global kernel above (4-/8-byte loads per
-// lane, 245 us on the Hardesty3-sized matrix) this is the row-block kernel's memory behaviour with the vector-row lane layout.
-constexpr int kVecTileRows = 4;
+// the other tile kernels, and every row is summed by w lanes -- one w per matrix half for the split
+// (vector_row_adaptive.hpp:72-142).  A lane group owns up to kVecTileRows rows (vecs apart), so that w lanes per row and a full
+// 2048-product tile go together.  The width rule is the reference's shape (a power of two from the average row length,
+// vector_row.cpp:15-27) with another constant: the reference gives a lane ~2 non-zeros because its lanes stream from global
+// memory; here the products already sit in LDS and a lane adds up to 8 of them (w = pow2 >= avg / 8, at least 2) -- with the
+// reference's widths the butterflies of 16- and 32-lane groups dominated the kernel (boneS10-sized 96 us at w = 16 against
+// 77 us at w = 4; Bump_2911-sized 264 against 195 us).
+constexpr int kVecTileRows = 2;
 template <bool NTC, bool NTV>
-__global__ __launch_bounds__(kThreads) void vector_tile_kernel(int m, int nnz, int row_split, int nb0, int w0, int w1, int rpb0,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))) void vector_tile_kernel(int m, int nnz, int row_split, int nb0, int w0, int w1, int rpb0,
                                                                int rpb1, int xcd_chunk, double alpha, double beta,
                                                                const int *__restrict__ rp, const int *__restrict__ ci,
                                                                const double *__restrict__ v, const double *__restrict__ x,
@@ -140,8 +142,9 @@ __global__ __launch_bounds__(kThreads) void vector_tile_kernel(int m, int nnz, i
   const int s0 = rp[row_base];
   const int s1 = rp[row_end];
   const int lane = threadIdx.x & (w - 1);
-  const int vecs = kThreads / w;
-  const int vec_id = threadIdx.x / w;
+  const int log2w = 31 - __builtin_clz(w); // w is a power of two
+  const int vecs = kThreads >> log2w;
+  const int vec_id = threadIdx.x >> log2w;
   int r0[kVecTileRows], r1[kVecTileRows];
 #pragma unroll
   for (int k = 0; k < kVecTileRows; ++k) {
@@ -152,7 +155,9 @@ __global__ __launch_bounds__(kThreads) void vector_tile_kernel(int m, int nnz, i
       r1[k] = rp[row + 1];
     }
   }
-  double acc[kVecTileRows] = {0.0, 0.0, 0.0, 0.0};
+  double acc[kVecTileRows];
+#pragma unroll
+  for (int k = 0; k < kVecTileRows; ++k) acc[k] = 0.0;
   for (int off = s0 & ~3; off < s1; off += kTile) {
     stage_products<kThreads, kNnzPerThread, NTC, NTV>(lds, off, s1, nnz, ci, v, x);
     __syncthreads();

@@ -189,9 +189,13 @@ __device__ __forceinline__ void stage_finish(double *__restrict__ lds, const Str
 
 // ---- staging from the 16-bit column encoding (k_col16.hip) ---------------------------------------------------------------------
 // Same step as the branch-free form of stage_products with the colindex stream replaced by the plan's encoding: one 8-B load
-// of four 16-bit offsets per lane per step (instead of 16 B), the chunk's base from a wave-uniform load (a0 is a multiple of
-// 256, so a wavefront's step is exactly one chunk), and -- only in wavefronts that hold an escape, a wave-uniform test -- the
-// escaped columns from the chunk's slice of esc_cols, found by a prefix count of the lanes' escapes.
+// of four 16-bit offsets per lane per step (instead of 16 B) and the chunk's base from a wave-uniform load (a0 is a multiple of
+// 256, so a wavefront's step is exactly one chunk).  Escapes must not lengthen the load chain (a first form that fetched
+// esc_cols[rank] AFTER decoding ran 12 % SLOWER than the 4-byte columns: at 2 % far columns nearly every wavefront holds an
+// escape and paid a third dependent round trip): each wavefront PRELOADS its chunk's first 64 escapes together with the
+// stream (lane l takes esc_cols[esc_start + l]; the list is padded by 64 entries), and an escaped entry picks its column out
+// of the preloaded registers by rank -- ballots + popcounts for the rank, one ds_bpermute per element slot that holds an escape
+// anywhere in the wavefront.  Only a chunk with more than 64 escapes (random columns) reads esc_cols a second time.
 // Precondition (checked by the caller): every 4-group below `hi` lies inside the arrays (stage_fast_ok).
 typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
 typedef ushort4v ushort4v_a2 __attribute__((aligned(2)));
@@ -204,8 +208,9 @@ __device__ __forceinline__ void stage_products_col16(double *__restrict__ lds, i
   constexpr int K = NPT / 4;
   ushort4v d[K];
   double2v va[K], vb[K];
-  int bs[K], es[K];
+  int bs[K], es[K], pre[K];
   bool has[K];
+  const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int wave_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + k * THREADS));
@@ -221,26 +226,29 @@ __device__ __forceinline__ void stage_products_col16(double *__restrict__ lds, i
       vb[k] = load_stream_d2<NTV>(v + jv + 2);
     }
   }
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if (has[k]) pre[k] = esc_cols[es[k] + lane]; // speculative: the chunk's first 64 escapes, one coalesced 256-B load
   double xg[K][4];
+  const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     if (has[k]) {
       int c[4] = {bs[k] + d[k].x, bs[k] + d[k].y, bs[k] + d[k].z, bs[k] + d[k].w};
-      const bool e0 = d[k].x == 0xFFFF, e1 = d[k].y == 0xFFFF, e2 = d[k].z == 0xFFFF, e3 = d[k].w == 0xFFFF;
-      const int mine = (e0 ? 1 : 0) + (e1 ? 1 : 0) + (e2 ? 1 : 0) + (e3 ? 1 : 0);
-      if (__ballot(mine > 0)) { // wave-uniform; every lane of the wave takes part in the prefix count
-        int incl = mine;
-        const int lane = threadIdx.x & (kWave - 1);
+      const bool e[4] = {d[k].x == 0xFFFF, d[k].y == 0xFFFF, d[k].z == 0xFFFF, d[k].w == 0xFFFF};
+      const unsigned long long b0 = __ballot(e[0]), b1 = __ballot(e[1]), b2 = __ballot(e[2]), b3 = __ballot(e[3]);
+      if (b0 | b1 | b2 | b3) { // wave-uniform
+        // rank of this lane's first escape in the chunk's list: escapes held by lower lanes (the list is in non-zero order)
+        int r = __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
+        const unsigned long long slot[4] = {b0, b1, b2, b3};
 #pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-          const int up = __shfl_up(incl, o, kWave);
-          if (lane >= o) incl += up;
+        for (int q = 0; q < 4; ++q) {
+          if (slot[q]) { // wave-uniform: some lane's q-th entry is an escape
+            const int got = __shfl(pre[k], r & (kWave - 1), kWave);
+            if (e[q]) c[q] = r < kWave ? got : esc_cols[es[k] + r];
+          }
+          r += e[q] ? 1 : 0;
         }
-        int pos = es[k] + incl - mine;
-        if (e0) c[0] = esc_cols[pos++];
-        if (e1) c[1] = esc_cols[pos++];
-        if (e2) c[2] = esc_cols[pos++];
-        if (e3) c[3] = esc_cols[pos++];
       }
       xg[k][0] = x[c[0]];
       xg[k][1] = x[c[1]];

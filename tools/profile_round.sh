@@ -13,7 +13,7 @@ OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "[profile_round] kernel trace"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py "$@" --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.log || exit 1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py "$@" --no-cpu-baseline --no-sensitivity > $OUT/bench_under_trace.json 2> $OUT/trace.log || exit 1
 S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 { head -1 $S; grep -E "spmv_acc" $S; } > $OUT/kernel_stats_spmv.csv
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -39,7 +39,7 @@ out, tag = sys.argv[1], sys.argv[2]
 def dominant(path):
     best = None
     for line in open(path):
-        m = re.match(r"(\w+) kernel=(\S+) dispatches=(\d+) mean_KB=([\d.]+)", line)
+        m = re.match(r"(\w+) kernel=(.+?) dispatches=(\d+) mean_KB=([\d.]+)", line)
         # the SpMV kernel of the timed loop: most dispatches among the tile kernels
         if m and any(k in m.group(2) for k in ("rowblock_stream", "flat_tile", "plus_kernel", "vector_row", "wave_row")):
             if best is None or int(m.group(3)) > best[1]:
