@@ -326,7 +326,8 @@ def main():
         # turn the version banner on but never create the file.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if os.environ.get("SPMV_ACC_BENCH_BACKEND", "nccl") == "nccl":
-            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            # (assigned, not setdefault: the GPU boxes of this pool export NCCL_DEBUG=VERSION, which prints the banner and nothing else)
+            os.environ["NCCL_DEBUG"] = "INFO"
             os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/spmv_acc_bench_rccl_{os.getpid()}_rank{os.environ.get('RANK', '0')}.log")
     import torch
     import torch.distributed as dist

@@ -116,6 +116,22 @@ int spmv_acc_adaptive_branch(int m, int rp_quarter, int rp_half, int rp_three_qu
  * h_rowptr: host rowptr (may be NULL for mode 0).  row_begin: out, parts + 1 entries. */
 int spmv_acc_partition_rows(int m, int parts, int mode, const int *h_rowptr, int *row_begin);
 
+/* ---- one rank's step of the row-sharded SpMV, behind the C boundary (new) ---------------------------------------------------
+ * replaces: nothing in the reference (single GPU: hipSetDevice(0) at cli/main.cpp:89, no collective anywhere); BASELINE's
+ * north_star adds the row-range partition with an RCCL allgather of the y sub-vectors.  spmv_acc_amd/dist.py does this with
+ * torch.distributed; this entry gives C / C++ consumers (one process or one thread per GPU) the same step:
+ *     y_local[0 .. m_local) = alpha * A_local * x + beta * y_local          (this rank's rows, any strategy)
+ *     ncclAllGather(y_local, y_full, m_pad doubles, comm, library stream)   (ONE collective per SpMV, behind the kernels)
+ * nccl_comm: the caller's ncclComm_t.  The library resolves ncclAllGather at run time from the RCCL the process already has
+ * (dlopen RTLD_NOLOAD of librccl.so.1 / librccl.so, else a fresh dlopen; environment variable SPMV_ACC_RCCL_LIB names a
+ * particular file), so libspmv_acc.so keeps linking only the HIP runtime.  y_local holds m_pad >= m_local doubles (every rank
+ * the same m_pad: RCCL has no allgatherv; rows past m_local are padding the caller zeroes once), y_full holds
+ * world * m_pad doubles; rank r's rows land at y_full + r * m_pad.  Returns 0 or an error code (SPMV_ACC_ERR_NO_DEVICE when
+ * no RCCL can be found, SPMV_ACC_ERR_HIP when the collective fails). */
+int spmv_acc_sharded_spmv(void *nccl_comm, int strategy, double alpha, double beta, int m_local, int m_pad, int n, int nnz_local,
+                          const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx,
+                          double *dy_local, double *dy_full);
+
 /* ---- host staging (new; replaces the pageable blocking hipMemcpy of cli/utils.hpp:94-117) ----------------------------
  * Copies host CSR arrays + vectors to freshly hipMalloc'ed device buffers: the caller's arrays are pinned in place
  * (hipHostRegister) and sent with hipMemcpyAsync on a private copy stream, all transfers in flight together; an

@@ -36,7 +36,7 @@ C_ABI_SYMBOLS = (
     "spmv_acc_set_stream", "spmv_acc_get_stream", "spmv_acc_last_error", "spmv_acc_last_error_string",
     "spmv_acc_clear_error", "spmv_acc_time_spmv", "spmv_acc_version", "spmv_acc_set_tunable",
     "spmv_acc_get_tunable", "spmv_acc_reset_tunables", "spmv_acc_time_spmv_total", "spmv_acc_copy_ceiling_gbs", "spmv_acc_adaptive_plus_analyze_device", "spmv_acc_prepare",
-    "spmv_acc_last_prepare_us",
+    "spmv_acc_last_prepare_us", "spmv_acc_sharded_spmv",
 )
 
 _lib = None
@@ -105,6 +105,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_copy_ceiling_gbs.argtypes = [vp, vp, ctypes.c_longlong, ci]
     lib.spmv_acc_copy_ceiling_gbs.restype = cd
     lib.spmv_acc_last_prepare_us.restype = cd
+    lib.spmv_acc_sharded_spmv.argtypes = [vp, ci, cd, cd, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
     if path is None:
         _lib = lib
     return lib

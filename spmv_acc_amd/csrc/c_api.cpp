@@ -3,8 +3,12 @@
 // cannot be declared with both linkages in one translation unit.)
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/spmv_acc.h"
@@ -71,6 +75,27 @@ template <typename T> bool stage_one(Stager &st, const T *h, size_t count, T **d
   if (hipMalloc(reinterpret_cast<void **>(d), sizeof(T) * count) != hipSuccess) return false;
   return st.upload(*d, h, sizeof(T) * count);
 }
+} // namespace
+
+// ---- RCCL, resolved at run time (the library links only the HIP runtime) ------------------------------------------------------
+namespace {
+typedef int (*nccl_all_gather_t)(const void *, void *, size_t, int, void *, hipStream_t);
+nccl_all_gather_t resolve_all_gather() {
+  static std::once_flag once;
+  static nccl_all_gather_t fn = nullptr;
+  std::call_once(once, [] {
+    void *lib = nullptr;
+    if (const char *env = std::getenv("SPMV_ACC_RCCL_LIB")) lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    // the copy the process already uses (the caller made its communicator with it) before any other
+    for (const char *name : {"librccl.so.1", "librccl.so"})
+      if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"})
+      if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (lib) fn = reinterpret_cast<nccl_all_gather_t>(dlsym(lib, "ncclAllGather"));
+  });
+  return fn;
+}
+constexpr int kNcclFloat64 = 8; // ncclDataType_t ncclFloat64 / ncclDouble (rccl.h)
 } // namespace
 
 extern "C" {
@@ -188,6 +213,30 @@ int spmv_acc_partition_rows(int m, int parts, int mode, const int *h_rowptr, int
       r = std::max(r, row_begin[p - 1]);
       row_begin[p] = std::min(r, m);
     }
+  }
+  return kOk;
+}
+
+int spmv_acc_sharded_spmv(void *nccl_comm, int strategy, double alpha, double beta, int m_local, int m_pad, int n, int nnz_local,
+                          const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx,
+                          double *dy_local, double *dy_full) {
+  if (!nccl_comm || m_local < 0 || m_pad < m_local || m_pad <= 0 || !dy_local || !dy_full) {
+    set_error(kErrBadArgument, "spmv_acc_sharded_spmv: bad argument");
+    return kErrBadArgument;
+  }
+  const nccl_all_gather_t all_gather = resolve_all_gather();
+  if (!all_gather) {
+    set_error(kErrNoDevice, "spmv_acc_sharded_spmv: no RCCL found in the process (librccl.so.1 / librccl.so / SPMV_ACC_RCCL_LIB)");
+    return kErrNoDevice;
+  }
+  clear_error();
+  if (m_local > 0) run_spmv(strategy, 0, alpha, beta, m_local, n, nnz_local, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy_local);
+  if (last_error() != kOk) return last_error();
+  // same stream: the collective reads y_local behind the kernels that wrote it
+  const int rc = all_gather(dy_local, dy_full, static_cast<size_t>(m_pad), kNcclFloat64, nccl_comm, get_stream());
+  if (rc != 0) {
+    set_error(kErrHip, "spmv_acc_sharded_spmv: ncclAllGather failed (ncclResult " + std::to_string(rc) + ")");
+    return kErrHip;
   }
   return kOk;
 }

@@ -306,3 +306,56 @@ def test_opt_in_col16_encoding_matches_plain_flat(torch_dev, oracle, hiplib):
     finally:
         hiplib.spmv_acc_reset_tunables()
         spmv_acc_amd.release_plans()
+
+
+def test_c_abi_sharded_spmv_on_a_one_rank_communicator(torch_dev, oracle, hiplib):
+    """spmv_acc_sharded_spmv: one rank's step of the row-sharded SpMV for C consumers -- local SpMV + ONE ncclAllGather of the
+    padded y slices on the caller's communicator, RCCL resolved at run time from the copy the process already uses (here: the
+    one bundled with torch, driven through ctypes exactly as a C caller would drive it).  One rank is all this box allows;
+    the collective still runs through RCCL."""
+    import ctypes
+
+    torch = torch_dev
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")  # the device is initialised before RCCL looks at it
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        m, n, pad = 50_000, 60_000, 50_048
+        rowptr, cols, vals = synth.random_csr(m, n, 9, seed=5, kind="uniform")
+        nnz = int(rowptr[-1])
+        rng = np.random.default_rng(6)
+        x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+        drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+        hiplib.spmv_acc_set_stream(None)
+        for strat, (alpha, beta) in (("adaptive", (1.0, 1.0)), ("flat", (0.5, -2.0)), ("line_enhance", (1.0, 0.0))):
+            y_local = torch.zeros(pad, dtype=torch.float64, device="cuda")
+            y_local[:m] = dev(torch, y0)
+            y_full = torch.full((pad,), float("nan"), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            rc = hiplib.spmv_acc_sharded_spmv(comm, spmv_acc_amd.strategy_id(strat), alpha, beta, m, pad, n, nnz, None,
+                                              drp.data_ptr(), dci.data_ptr(), dv.data_ptr(), dx.data_ptr(), y_local.data_ptr(),
+                                              y_full.data_ptr())
+            assert rc == 0, hiplib.spmv_acc_last_error_string()
+            torch.cuda.synchronize()
+            got = y_full.cpu().numpy()
+            ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+            assert oracle.scaled_error(got[:m], ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL, strat
+            assert np.all(got[m:] == 0.0)  # the padding travelled too
+        # bad arguments are refused before anything is launched
+        assert hiplib.spmv_acc_sharded_spmv(None, 1, 1.0, 0.0, m, pad, n, nnz, None, drp.data_ptr(), dci.data_ptr(), dv.data_ptr(),
+                                            dx.data_ptr(), y_local.data_ptr(), y_full.data_ptr()) == 2
+        assert hiplib.spmv_acc_sharded_spmv(comm, 1, 1.0, 0.0, m, m - 1, n, nnz, None, drp.data_ptr(), dci.data_ptr(), dv.data_ptr(),
+                                            dx.data_ptr(), y_local.data_ptr(), y_full.data_ptr()) == 2
+        hiplib.spmv_acc_clear_error()
+        spmv_acc_amd.release_plans(drp)
+    finally:
+        rccl.ncclCommDestroy(comm)
