@@ -12,6 +12,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 g = torch.Generator(device="cuda"); g.manual_seed(int(rng.integers(1 << 30)))
 worst = 0.0
+reference_glitches = 0
 for case in range(cases):
     m = int(10 ** rng.uniform(3, 6.7))
     mean = float(rng.choice([1.5, 4, 12, 40, 300, 4000]))
@@ -79,19 +80,67 @@ for case in range(cases):
     elif form == "shard" and m >= 4:
         r0 = int(rng.integers(1, m // 2 + 1)); r1 = int(rng.integers(r0 + 1, m + 1))
     line = f"case {case:3d}: m={m} n={n} nnz={nnz} law={law} cols={cols_law} mean={mean} a/b={alpha}/{beta} form={form}"
-    for strat in ("adaptive", "line_enhance", "flat", "adaptive_plus", "default", "vector_row"):
+    lib = spmv_acc_amd.load_library()
+    failures = []
+    # the shipped configuration of every family, then the round-2 variants the per-matrix timings may or may not pick
+    variants = [("adaptive", {}), ("line_enhance", {}), ("flat", {}), ("adaptive_plus", {}), ("default", {}), ("vector_row", {}),
+                ("line_enhance", {"rowlen": 1}), ("line_enhance", {"rowlen": 0}), ("flat", {"flat_early": 1, "flat_npt": 4}),
+                ("flat", {"flat_early": 1, "flat_npt": 8}), ("flat", {"flat_finish": 1, "flat_npt": 4}), ("flat", {"col16": 1}),
+                ("vector_row", {"vector_tile": 0}), ("light", {"vector_width": 16})]
+    for strat, knobs in variants:
+        lib.spmv_acc_reset_tunables()
+        for k_, v_ in knobs.items():
+            assert lib.spmv_acc_set_tunable(k_.encode(), v_) == 0
+        if knobs:
+            spmv_acc_amd.release_plans(rp32[r0:])
         y = y0.clone()
         spmv_acc_amd.csr_spmv(alpha, beta, r1 - r0, n, int(rp32[r1].item()), rp32[r0:], ci, v, x, y[r0:], strategy=strat)
         torch.cuda.synchronize()
+        strat = strat + (" " + str(knobs) if knobs else "")
         if not (torch.equal(y[:r0], y0[:r0]) and torch.equal(y[r1:], y0[r1:])):
             print(line); print("   FAIL", strat, "wrote outside the shard"); sys.exit(1)
         err = float(((y[r0:r1] - ref[r0:r1]).abs() / scale[r0:r1]).max().item()) if r1 > r0 else 0.0
-        spmv_acc_amd.release_plans(rp32[r0:]) if strat == "vector_row" else None
-        worst = max(worst, err)
+        if err <= 1e-12:
+            worst = max(worst, err)
         if not err <= 1e-12:
-            print(line); print("   FAIL", strat, err); sys.exit(1)
+            bad = ((y[r0:r1] - ref[r0:r1]).abs() / scale[r0:r1]) > 1e-12
+            idx = torch.nonzero(bad).flatten()
+            # torch.segment_reduce itself has been caught wrong (25 M mostly empty segments: 1073 rows off by O(1) while every
+            # kernel family agreed with a host evaluation to the last bits): a row only counts when the HOST sum disagrees too
+            confirmed = 0
+            for i in idx[:400].tolist():
+                r = i + r0
+                a, b = int(rp32[r].item()), int(rp32[r + 1].item())
+                pr = v[a:b].cpu().numpy() * x[ci[a:b].long()].cpu().numpy()
+                exact = beta * float(y0[r].item()) + alpha * float(pr.sum())
+                sc = abs(beta * float(y0[r].item())) + abs(alpha) * float(np.abs(pr).sum()) + 1e-300
+                if abs(float(y[r].item()) - exact) / sc > 1e-12:
+                    confirmed += 1
+            if confirmed == 0:
+                reference_glitches += 1
+                continue
+            failures.append((strat, err, int(bad.sum().item()), [int(i) + r0 for i in idx[:5].tolist()],
+                             spmv_acc_amd.query_plan(rp32[r0:], r1 - r0)))
+    if failures:
+        print(line)
+        for f in failures:
+            print("   FAIL", f)
+        print(f"   shard rows [{r0}, {r1}), rowptr[r0] = {int(rp32[r0].item())}, max row = {int(lens.max().item())}")
+        # who is wrong?  the failing rows once more, one by one on the host
+        strat0, _, _, rows_bad, _ = failures[0]
+        y = y0.clone()
+        lib.spmv_acc_reset_tunables()
+        spmv_acc_amd.csr_spmv(alpha, beta, r1 - r0, n, int(rp32[r1].item()), rp32[r0:], ci, v, x, y[r0:], strategy="line_enhance")
+        torch.cuda.synchronize()
+        for r in rows_bad:
+            a, b = int(rp32[r].item()), int(rp32[r + 1].item())
+            exact = beta * float(y0[r].item()) + alpha * float((v[a:b].cpu().numpy() * x[ci[a:b].long()].cpu().numpy()).sum())
+            print(f"   row {r}: nnz {b - a}  host {exact:.17g}  library {float(y[r].item()):.17g}  torch.segment_reduce reference {float(ref[r].item()):.17g}")
+        sys.exit(1)
     print(line, "-> ok", flush=True)
+    lib.spmv_acc_reset_tunables()
     spmv_acc_amd.release_plans()
     del rp, rp32, ci, v, x, y0, ref, scale, lens
     torch.cuda.empty_cache()
-print(f"all {cases} cases within 1e-12 scaled error (worst {worst:.2e})")
+print(f"all {cases} cases within 1e-12 scaled error (worst {worst:.2e}); torch.segment_reduce disagreed with the host "
+      f"(and the library agreed with the host) in {reference_glitches} strategy runs")
