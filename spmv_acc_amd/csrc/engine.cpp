@@ -13,6 +13,8 @@
 
 #include <chrono>
 #include <climits>
+#include <cstdarg>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -425,7 +427,10 @@ struct Plan {
   bool have_samples = false;
   RowptrSamples samples;
   // cache policy of the stream loads (kStreamPolicy*), timed once per matrix AND kernel family; -1 = not tuned yet
-  int stream_policy[kFamilyCount] = {-1, -1, -1, -1};
+  // ... AND per beta class ([0]: beta == 0, y is only written; [1]: y is read as well): the extra 8 B/row change what the
+  // streams should leave in the Infinity Cache -- on the Hardesty3-sized matrix without far columns the three policies tie at
+  // beta = 0 (108 / 107 / 107 us) and differ by 7 % at beta = 1 (112 / 121 / 119 us)
+  int stream_policy[kFamilyCount][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
   // opt-in structural check (tunable `validate`): -1 not run, 0 arrays are consistent, else the failure bits
   int invalid = -1;
   // row-block family: -1 unknown, 1 balanced, 0 some workgroup would need too many LDS rounds
@@ -805,20 +810,45 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) 
   return true;
 }
 
+// beta class of the call being served (set by run_spmv): per-matrix timings run in the caller's class, into a zeroed scratch y
+thread_local int t_beta_class = 1;
+inline double trial_beta() { return t_beta_class ? 1.0 : 0.0; }
+
 int policy_for(const Plan &p, int fam) {
   const int forced = tun(kT_stream_plain);
   if (forced >= 0) return forced & 3;
-  if (p.stream_policy[fam] >= 0) return p.stream_policy[fam];
-  // not timed for this family yet (adaptive's comparison of the families): the policy another family measured on this matrix
-  // is a far better guess than a fixed one -- the policies differ through what the MATRIX leaves in the Infinity Cache
+  const int c = t_beta_class;
+  if (p.stream_policy[fam][c] >= 0) return p.stream_policy[fam][c];
+  // not timed for this family in this class yet (adaptive's comparison of the families): the policy another family measured on
+  // this matrix in the same class is a far better guess than a fixed one, then this family's other class
   for (int f = 0; f < kFamilyCount; ++f)
-    if (p.stream_policy[f] >= 0) return p.stream_policy[f];
+    if (p.stream_policy[f][c] >= 0) return p.stream_policy[f][c];
+  if (p.stream_policy[fam][c ^ 1] >= 0) return p.stream_policy[fam][c ^ 1];
   return kStreamPolicyNt;
 }
 
 // While adaptive compares the families it runs each with its default sub-choices (flat: carries + fix-up unless pinned;
 // row-block-plus: MIN_NNZ 1536); the family that wins refines its own sub-choice on its next call.
 thread_local bool t_coarse_tuning = false;
+
+// SPMV_ACC_TUNE_LOG=1: every per-matrix timing and the choice it led to, one line each on stderr (what was measured, not only
+// what was kept -- for users who want to pin a choice, and for finding out why a plan settled where it did).
+bool tune_log_enabled() {
+  static const bool on = [] {
+    const char *e = std::getenv("SPMV_ACC_TUNE_LOG");
+    return e && *e && *e != '0';
+  }();
+  return on;
+}
+void tune_log(const char *fmt, ...) {
+  if (!tune_log_enabled()) return;
+  va_list ap;
+  va_start(ap, fmt);
+  std::fputs("[spmv_acc tune] ", stderr);
+  std::vfprintf(stderr, fmt, ap);
+  std::fputc('\n', stderr);
+  va_end(ap);
+}
 
 // Shared by the per-matrix timings below: average milliseconds of fn() in the cache state fn itself leaves behind.  The
 // first launch is timed alone and sizes the rest, so tuning a matrix whose SpMV takes milliseconds costs 2 launches per
@@ -857,21 +887,23 @@ struct TuneTimer {
 // no side effects on the caller's y) and keep the fastest.  Up to eight launches per candidate (TuneTimer: 3 to reach
 // that policy's cache steady state + 5 timed; 2 in all when a launch takes milliseconds), once per matrix.
 template <typename Launch> bool autotune_policy(Plan &p, int fam, hipStream_t st, Launch &&launch) {
-  if (p.stream_policy[fam] >= 0) return true;
+  const int cls = t_beta_class;
+  if (p.stream_policy[fam][cls] >= 0) return true;
   if (tun(kT_stream_plain) >= 0) return true; // pinned (A/B runs): policy_for follows the tunable, nothing is recorded
   // While adaptive compares the families only the first one times the three policies; the others run under that result
   // (policy_for) and the family that wins times its own on its next call.  (Timing all three per family made adaptive's
   // first call 21 ms on the Hardesty3-sized matrix, 134 SpMVs' worth; the comparison itself needs 8 launches per family.)
   if (t_coarse_tuning) {
     for (int f = 0; f < kFamilyCount; ++f)
-      if (p.stream_policy[f] >= 0) return true;
+      if (p.stream_policy[f][cls] >= 0) return true;
   }
   ++t_plan_work;
   double *scratch = nullptr;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
     return false;
   TuneTimer timer;
-  bool ok = timer.ok;
+  // (zeroed: in the beta != 0 class the trial launches accumulate into it)
+  bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
   const int candidates[3] = {kStreamPolicyNt, kStreamPolicyDefault, kStreamPolicyValueDefault};
   float best = 1e30f;
   int best_policy = kStreamPolicyNt;
@@ -880,13 +912,15 @@ template <typename Launch> bool autotune_policy(Plan &p, int fam, hipStream_t st
     // runs until the caches hold its own steady state, then is timed over several launches
     float ms = 0.f;
     ok = timer.time(st, [&] { launch(candidates[c], scratch); }, &ms);
+    if (ok) tune_log("m %d nnz %d family %d beta class %d: stream policy %d -> %.2f us", p.A.m, p.A.nnz, fam, cls, candidates[c], ms * 1e3f);
     if (ok && ms < best) {
       best = ms;
       best_policy = candidates[c];
     }
   }
   (void)hipFree(scratch);
-  if (ok) p.stream_policy[fam] = best_policy;
+  if (ok) tune_log("m %d nnz %d family %d: keeps stream policy %d", p.A.m, p.A.nnz, fam, best_policy);
+  if (ok) p.stream_policy[fam][cls] = best_policy;
   return ok;
 }
 
@@ -974,15 +1008,16 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
     return false;
   TuneTimer timer;
-  bool ok = timer.ok;
+  bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
   float ms[2] = {0.f, 0.f};
   for (int mode = 0; ok && mode < 2; ++mode) {
     F.needs_fixup = mode == 0;
-    ok = timer.time(st, [&] { launch_flat_with(st, p, policy_for(p, kFamFlat), 1.0, 0.0, x, scratch); }, &ms[mode]);
+    ok = timer.time(st, [&] { launch_flat_with(st, p, policy_for(p, kFamFlat), 1.0, trial_beta(), x, scratch); }, &ms[mode]);
   }
   (void)hipFree(scratch);
   F.tuned_fixup = F.needs_fixup = !(ok && ms[1] < ms[0]);
   F.mode_tuned = ok;
+  if (ok) tune_log("m %d nnz %d flat cut rows: carries + fix-up %.2f us, finished in the tile %.2f us", p.A.m, p.A.nnz, ms[0] * 1e3f, ms[1] * 1e3f);
   return ok;
 }
 
@@ -1002,7 +1037,7 @@ bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
     return false;
   TuneTimer timer;
-  bool ok = timer.ok;
+  bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
   const int pol = policy_for(p, kFamFlat);
   FlatPlan alt;
   FlatPlan *plans[2] = {&p.flat, nullptr};
@@ -1023,7 +1058,9 @@ bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
     for (int e = 0; ok && e < (time_early ? 2 : 1); ++e) {
       plans[k]->early_stream = time_early ? e != 0 : plans[k]->early_stream;
       float ms = 0.f;
-      ok = timer.time(st, [&] { launch_flat_plan(st, p.A, *plans[k], pol, 1.0, 0.0, x, scratch); }, &ms);
+      ok = timer.time(st, [&] { launch_flat_plan(st, p.A, *plans[k], pol, 1.0, trial_beta(), x, scratch); }, &ms);
+      if (ok) tune_log("m %d nnz %d flat geometry: %d non-zeros per tile, stream-first %d -> %.2f us", p.A.m, p.A.nnz, plans[k]->stride,
+                       plans[k]->early_stream ? 1 : 0, ms * 1e3f);
       if (ok && ms < best) {
         best = ms;
         best_plan = k;
@@ -1067,7 +1104,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
     if (!ensure_col16(p, st)) return false;
     p.flat.col16 = &p.col16; // (used by the 2048-non-zero tile only; other tile sizes read colindex)
   }
-  if (!autotune_policy(p, kFamFlat, st, [&](int pol, double *ys) { launch_flat_with(st, p, pol, 1.0, 0.0, x, ys); })) return false;
+  if (!autotune_policy(p, kFamFlat, st, [&](int pol, double *ys) { launch_flat_with(st, p, pol, 1.0, trial_beta(), x, ys); })) return false;
   if (!autotune_flat_mode(p, st, x)) return false;
   if (!autotune_flat_geometry(p, st, x)) return false;
   launch_flat_with(st, p, policy_for(p, kFamFlat), alpha, beta, x, y);
@@ -1195,7 +1232,7 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
   const int base_flags = (tun(kT_xcd_remap) ? 1 : 0) | (tun(kT_early_y) ? 2 : 0) |
                          (chunk > 0 ? (4 | (chunk << 8)) : 0) | (tun(kT_stage_fast) ? 0 : 8);
   if (!autotune_policy(p, kFamRowblock, st, [&](int pol, double *ys) {
-        launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (pol << 4), 1.0, 0.0, x, ys, dg);
+        launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (pol << 4), 1.0, trial_beta(), x, ys, dg);
       }))
     return false;
   launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p, kFamRowblock) << 4), alpha, beta, x, y, dg);
@@ -1209,7 +1246,7 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
 bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double *x) {
   auto launch = [&](int pol, double *ys) {
     launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk_tiles), pol,
-                p.d_ppartial, 1.0, 0.0, x, ys);
+                p.d_ppartial, 1.0, trial_beta(), x, ys);
   };
   const int forced = tun(kT_plus_min_nnz);
   if (forced > 0 || tun(kT_plus_ref_vec)) {
@@ -1225,7 +1262,7 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
     return false;
   TuneTimer timer;
-  bool ok = timer.ok;
+  bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
   const int candidates[3] = {1536, 1920, kPlusMinNnz};
   float best = 1e30f;
   int best_min = kPlusMinNnz;
@@ -1234,6 +1271,7 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
     if (!ok) break;
     float ms = 0.f;
     ok = timer.time(st, [&] { launch(policy_for(p, kFamPlus), scratch); }, &ms);
+    if (ok) tune_log("m %d nnz %d row-block-plus: MIN_NNZ_PER_BLOCK %d -> %.2f us", p.A.m, p.A.nnz, candidates[c], ms * 1e3f);
     if (ok && ms < best) {
       best = ms;
       best_min = candidates[c];
@@ -1277,7 +1315,7 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
     // The families are compared in the caller's beta class: with beta != 0 every row also reads its old y, which is a large
     // share of the traffic where rows hold one or two non-zeros and ranks the families differently (15 M rows of ~1 nnz:
     // flat looked 3 % faster than the row blocks at beta = 0 and is 9 % slower at beta = 1).
-    const double beta_trial = beta != 0.0 ? 1.0 : 0.0;
+    const double beta_trial = trial_beta();
     t_coarse_tuning = true;
     for (int f = 0; ok && f < 3; ++f) {
       ok = run_family(f, 1.0, beta_trial, scratch); // builds this family's plan (sub-choices at their defaults)
@@ -1301,6 +1339,8 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
     int best_family = ms[0] < 1e29f ? 0 : 1;
     for (int f = 1; f < 3; ++f)
       if (ms[f] < (best_family == 0 ? 0.97f * ms[0] : ms[best_family])) best_family = f;
+    tune_log("m %d nnz %d adaptive (beta %s 0): fixed row blocks %.2f us, row-block-plus %.2f us, flat %.2f us -> family %d", p.A.m, p.A.nnz,
+             beta != 0.0 ? "!=" : "==", ms[0] * 1e3f, ms[1] * 1e3f, ms[2] * 1e3f, best_family);
     (void)hipFree(scratch);
     if (!ok) return false;
     p.adaptive_family = best_family;
@@ -1336,6 +1376,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   // one call at a time per matrix: plan fields, the per-matrix timings and the carry buffers of flat / row-block-plus belong
   // to the plan (two host threads on DIFFERENT matrices do not meet here; this lock is never held together with g_mu)
   std::lock_guard<std::mutex> plan_lock(p->mu);
+  t_beta_class = beta != 0.0 ? 1 : 0;
   // What the reference's harness calls `pre` (its per-call break-point / analysis cost, benchmark_time.cpp:23-43) is paid here
   // by the FIRST call on a matrix: structural passes + per-matrix timings, all of which end in a synchronisation, so the host
   // time from here to the return of that call is the preparation time (the final launch itself is asynchronous).
@@ -1382,7 +1423,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
       auto launch = [&](int pol, double al, double be, double *yy) {
         launch_vector_tile(st, p->A, m, w, w, a, a, tun(kT_rowblock_target), tun(kT_xcd_chunk), pol, al, be, dx, yy);
       };
-      if (!autotune_policy(*p, kFamVector, st, [&](int pol, double *ys) { launch(pol, 1.0, 0.0, ys); })) return;
+      if (!autotune_policy(*p, kFamVector, st, [&](int pol, double *ys) { launch(pol, 1.0, trial_beta(), ys); })) return;
       launch(policy_for(*p, kFamVector), alpha, beta, dy);
     } else {
       launch_vector_row(st, p->A, m, w, 1, alpha, beta, dx, dy, p->rowblock_ok == 0);
@@ -1489,8 +1530,8 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       // the policy of the family that runs this matrix: adaptive's choice if it was timed, else the first family tuned
       int fam = p.adaptive_family >= 0 ? p.adaptive_family : -1;
       for (int f = 0; fam < 0 && f < kFamilyCount; ++f)
-        if (p.stream_policy[f] >= 0) fam = f;
-      out->stream_policy = fam >= 0 ? p.stream_policy[fam] : -1;
+        if (p.stream_policy[f][1] >= 0 || p.stream_policy[f][0] >= 0) fam = f;
+      out->stream_policy = fam < 0 ? -1 : (p.stream_policy[fam][1] >= 0 ? p.stream_policy[fam][1] : p.stream_policy[fam][0]);
       out->flat_fixup = p.flat_tiles > 0 ? (p.flat.needs_fixup ? 1 : 0) : -1;
       out->adaptive_family = p.adaptive_family;
       return true;
