@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   const bool writer = live && lane == 0;
   double y_old = 0.0;
   const bool early_y = (flags & 2) && beta != 0.0;
-  if (early_y && writer) y_old = y[row];
+  if (early_y && writer) y_old = y[row]; // (non-temporal y loads / stores were A/B-tested in round 2: no effect on any stand-in)
 
   double acc = 0.0;
   int incl = 0;
