@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
                                                              int *__restrict__ tail_row, int *__restrict__ tail_end,
                                                              int xcd_chunk, int reach,
                                                              const int *__restrict__ guard, int *__restrict__ stale,
-                                                             Col16Dev c16) {
+                                                             Col16Dev c16, int reverse) {
   check_plan_guard(rp, m, guard, stale);
   // reach: a tile finishes its last row itself when it ends at most `reach` (0 or kFlatFinish) non-zeros past the tile
   constexpr int STRIDE = kThreads * NPT;
@@ -88,7 +88,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
     sh_tail_row = -1;
     spans.n = 0;
   }
-  const int t = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, ntiles, xcd_chunk) : static_cast<int>(blockIdx.x);
+  int t = reverse ? zigzag_block(blockIdx.x, ntiles) : static_cast<int>(blockIdx.x); // every other SpMV walks the tiles backwards
+  if (xcd_chunk > 0) t = xcd_chunked_block(t, ntiles, xcd_chunk);
   const int t0 = t * STRIDE; // host guarantees nnz + stride fits in int
   const int t1 = (nnz - t0 > STRIDE) ? t0 + STRIDE : nnz;
 
@@ -280,11 +281,11 @@ void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P,
   if (P.early_stream)
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none);
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0);
   else
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none);
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0);
 }
 // opt-in 16-bit columns: NPT 8 tiles (a multiple of the 256-non-zero chunk), values under the plan's cache policy
 template <bool NTV>
@@ -293,7 +294,7 @@ void launch_flat_col16(hipStream_t stream, const CsrDev &A, const FlatPlan &P, d
   const Col16Dev c = {P.col16->d16, P.col16->base, P.col16->esc_start, P.col16->esc_cols};
   hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, true, NTV, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, c);
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, c, P.reverse ? 1 : 0);
 }
 template <int NPT>
 void launch_flat_policy(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,

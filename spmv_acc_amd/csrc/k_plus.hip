@@ -74,13 +74,14 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
                                                         const int *__restrict__ ci, const double *__restrict__ v,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         double *__restrict__ partial, int m,
-                                                        const int *__restrict__ guard, int *__restrict__ stale) {
+                                                        const int *__restrict__ guard, int *__restrict__ stale, int reverse) {
   check_plan_guard(rp, m, guard, stale);
   __shared__ __attribute__((aligned(16))) double lds[kPlusTile]; // written 16 B at a time
   __shared__ double row_acc[kPlusMaxRows];
   __shared__ TileSpans spans;
   if (threadIdx.x == 0) spans.n = 0; // published by the barrier that follows the first staging
-  const int g = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, nblocks, xcd_chunk) : static_cast<int>(blockIdx.x);
+  int g = reverse ? zigzag_block(blockIdx.x, nblocks) : static_cast<int>(blockIdx.x); // zigzag (engine.cpp)
+  if (xcd_chunk > 0) g = xcd_chunked_block(g, nblocks, xcd_chunk);
   const int4v rec = blk[g]; // wave-uniform: one scalar 16-B load
   const int row_begin = rec.x;
 
@@ -190,11 +191,11 @@ void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, cons
 
 void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, const void *blk, int nblocks,
                  bool has_long_rows, int xcd_chunk, int stream_policy, double *partial, double alpha, double beta,
-                 const double *x, double *y) {
+                 const double *x, double *y, bool reverse) {
   if (nblocks <= 0) return;
 #define SPMV_ACC_LAUNCH_PLUS(NC, NV)                                                                                \
   hipLaunchKernelGGL((plus_kernel<NC, NV>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk,   \
-                     alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial, A.m, A.guard, A.stale)
+                     alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial, A.m, A.guard, A.stale, reverse ? 1 : 0)
   switch (stream_policy & 3) {
   case 1: SPMV_ACC_LAUNCH_PLUS(false, false); break;
   case 2: SPMV_ACC_LAUNCH_PLUS(false, true); break;

@@ -124,13 +124,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))
                                                                const int *__restrict__ rp, const int *__restrict__ ci,
                                                                const double *__restrict__ v, const double *__restrict__ x,
                                                                double *__restrict__ y, const int *__restrict__ guard,
-                                                               int *__restrict__ stale) {
+                                                               int *__restrict__ stale, int reverse) {
   check_plan_guard(rp, m, guard, stale);
   __shared__ __attribute__((aligned(16))) double lds[kTile];
   __shared__ TileSpans spans;
   if (threadIdx.x == 0) spans.n = 0; // published by the barrier that follows the first staging
   const int nblocks = gridDim.x;
-  const int blk = xcd_chunk > 0 ? xcd_chunked_block(blockIdx.x, nblocks, xcd_chunk) : static_cast<int>(blockIdx.x);
+  int blk = reverse ? zigzag_block(blockIdx.x, nblocks) : static_cast<int>(blockIdx.x); // zigzag (engine.cpp)
+  if (xcd_chunk > 0) blk = xcd_chunked_block(blk, nblocks, xcd_chunk);
   const bool second = blk >= nb0; // block-uniform: which matrix half (one width when row_split == m)
   const int w = second ? w1 : w0;
   const int rpb = second ? rpb1 : rpb0;
@@ -319,7 +320,7 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
 
 void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int w0, int w1, double avg0, double avg1,
                         int target_products, int xcd_chunk, int stream_policy, double alpha, double beta, const double *x,
-                        double *y) {
+                        double *y, bool reverse) {
   if (A.m <= 0) return;
   if (row_split < 0) row_split = 0;
   if (row_split > A.m) row_split = A.m;
@@ -336,7 +337,7 @@ void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int 
   if (nb0 + nb1 == 0) return;
 #define SPMV_ACC_LAUNCH_VT(NC, NV)                                                                                    \
   hipLaunchKernelGGL((vector_tile_kernel<NC, NV>), dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, A.nnz, row_split, nb0, \
-                     w0, w1, rpb0, rpb1, xcd_chunk, alpha, beta, A.rp, A.ci, A.v, x, y, A.guard, A.stale)
+                     w0, w1, rpb0, rpb1, xcd_chunk, alpha, beta, A.rp, A.ci, A.v, x, y, A.guard, A.stale, reverse ? 1 : 0)
   switch (stream_policy & 3) {
   case 1: SPMV_ACC_LAUNCH_VT(false, false); break;
   case 2: SPMV_ACC_LAUNCH_VT(false, true); break;

@@ -52,7 +52,7 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
 // avg0 / avg1: average row length of rows [0, row_split) / [row_split, m) (sizes the rows per workgroup of each half).
 void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int w0, int w1, double avg0, double avg1,
                         int target_products, int xcd_chunk, int stream_policy, double alpha, double beta, const double *x,
-                        double *y);
+                        double *y, bool reverse = false);
 
 // wavefront-per-row for long rows: 4 consecutive non-zeros per lane per step (16-B loads), two steps in flight.
 void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y);
@@ -118,6 +118,7 @@ struct FlatPlan {
                             // can_finish): tiles finish their cut rows themselves.  Chosen by timing, engine.cpp.
   int max_tile_rows = 0;    // most rows any one tile (= workgroup) owns (plan-time probe)
   bool early_stream = false; // issue the tile's stream loads before the break point -> rowptr chain (small grids, timed)
+  bool reverse = false;     // this launch walks the tiles in reverse order (zigzag, set per launch by the engine)
   const Col16 *col16 = nullptr; // opt-in: columns from the plan's 16-bit encoding instead of colindex (NPT 8 tiles only)
   bool mode_tuned = false;  // tuned_fixup holds the timed choice
   bool tuned_fixup = true;
@@ -141,7 +142,7 @@ void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, cons
                         int *d_has_long);
 void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, const void *blk, int nblocks,
                  bool has_long_rows, int xcd_chunk, int stream_policy, double *partial, double alpha, double beta,
-                 const double *x, double *y);
+                 const double *x, double *y, bool reverse = false);
 
 // Device form of the row-block analysis (k_analyze.hip).  count: enqueue steps 1-3, d_total[0] = block count once
 // the stream has run; emit: write break_points (total + 1 entries) and first_block_of_row (m + 1 entries).
