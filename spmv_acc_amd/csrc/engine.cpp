@@ -83,7 +83,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kTunableCount
 };
 Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
@@ -124,6 +124,8 @@ Tunable g_tunables[] = {
                                // previous SpMV touched last is still in the 256 MB Infinity Cache when the next one starts there
                                // (Bump_2911-sized 156.5 -> 149 us, RM07R-sized 77.6 -> 74.2, largebasis-sized 15.5 -> 15.05; nothing where
                                // the plan streams non-temporally)
+    {"cache_ends_mb", 24, 24}, // row blocks / flat under the non-temporal policy: MB of stream at each end of the grid that stay cacheable
+                               // (an L2's worth: the zigzag order starts the next SpMV there); 0 = off
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -984,6 +986,7 @@ void launch_flat_plan(hipStream_t st, const CsrDev &A, FlatPlan &F, int policy, 
   const int early = tun(kT_flat_early);
   if (early >= 0) F.early_stream = early != 0; // pinned (A/B runs); otherwise the plan's timed choice
   F.reverse = reverse;
+  F.cache_ends = tun(kT_cache_ends_mb) > 0 && tun(kT_zigzag) ? static_cast<int>(tun(kT_cache_ends_mb) * 1048576.0 / (12.0 * F.stride)) : 0;
   launch_flat(st, A, F, alpha, beta, x, y);
 }
 void launch_flat_with(hipStream_t st, Plan &p, int policy, double alpha, double beta, const double *x, double *y) {
@@ -1237,16 +1240,23 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
     if (!ensure_digest(p, rpb, st)) return false;
     dg = &p.digest;
   }
+  // blocks at each end of the grid whose streams stay cacheable (tunable cache_ends_mb; 12 B per non-zero of stream)
+  int cache_ends = 0;
+  if (tun(kT_cache_ends_mb) > 0 && tun(kT_zigzag) && p.A.nnz > 0) {
+    const long long nblocks = (static_cast<long long>(p.A.m) + rpb - 1) / rpb;
+    const double bytes_per_block = 12.0 * p.A.nnz / static_cast<double>(nblocks);
+    cache_ends = static_cast<int>(tun(kT_cache_ends_mb) * 1048576.0 / bytes_per_block);
+  }
   const int chunk = tun(kT_xcd_chunk);
   const int base_flags = (tun(kT_xcd_remap) ? 1 : 0) | (tun(kT_early_y) ? 2 : 0) |
                          (chunk > 0 ? (4 | (chunk << 8)) : 0) | (tun(kT_stage_fast) ? 0 : 8);
   if (!autotune_policy(p, kFamRowblock, st, [&](int pol, double *ys) {
         const int zz = next_reverse(p) ? 64 : 0;
-        launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (pol << 4) | zz, 1.0, trial_beta(), x, ys, dg);
+        launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (pol << 4) | zz, 1.0, trial_beta(), x, ys, dg, cache_ends);
       }))
     return false;
   const int zz = next_reverse(p) ? 64 : 0;
-  launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p, kFamRowblock) << 4) | zz, alpha, beta, x, y, dg);
+  launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p, kFamRowblock) << 4) | zz, alpha, beta, x, y, dg, cache_ends);
   return true;
 }
 

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
                                                              int *__restrict__ tail_row, int *__restrict__ tail_end,
                                                              int xcd_chunk, int reach,
                                                              const int *__restrict__ guard, int *__restrict__ stale,
-                                                             Col16Dev c16, int reverse) {
+                                                             Col16Dev c16, int reverse, int cache_ends) {
   check_plan_guard(rp, m, guard, stale);
   // reach: a tile finishes its last row itself when it ends at most `reach` (0 or kFlatFinish) non-zeros past the tile
   constexpr int STRIDE = kThreads * NPT;
@@ -152,6 +152,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
   if (C16 && stage_fast_ok(t1, nnz)) // (the one tile that holds the ragged end of the arrays reads colindex as usual)
     stage_products_col16<kThreads, NPT, NTV>(lds, t0, t1, c16.d16, c16.base, c16.esc_start, c16.esc_cols, v, x);
   else if (EARLY && early) stage_finish<kThreads, EARLY ? NPT : 4>(lds, early_regs, x);
+  else if (NTC && NTV && cache_ends > 0 && (t < cache_ends || t >= ntiles - cache_ends)) // (k_rowblock.hip: cacheable grid ends)
+    stage_products<kThreads, NPT, false, false>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
   else stage_products<kThreads, NPT, NTC, NTV>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
 
   double fin_extra = 0.0; // this lane's share of the overhang (first wave, finish mode)
@@ -281,11 +283,11 @@ void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P,
   if (P.early_stream)
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0);
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends);
   else
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0);
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends);
 }
 // opt-in 16-bit columns: NPT 8 tiles (a multiple of the 256-non-zero chunk), values under the plan's cache policy
 template <bool NTV>
@@ -294,7 +296,7 @@ void launch_flat_col16(hipStream_t stream, const CsrDev &A, const FlatPlan &P, d
   const Col16Dev c = {P.col16->d16, P.col16->base, P.col16->esc_start, P.col16->esc_cols};
   hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, true, NTV, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, c, P.reverse ? 1 : 0);
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, c, P.reverse ? 1 : 0, P.cache_ends);
 }
 template <int NPT>
 void launch_flat_policy(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
                                                                    const int *__restrict__ guard,
                                                                    int *__restrict__ stale,
                                                                    const unsigned char *__restrict__ lens,
-                                                                   const int *__restrict__ base) {
+                                                                   const int *__restrict__ base, int cache_ends) {
   check_plan_guard(rp, m, guard, stale);
   __shared__ int wave_tot[kThreads / kWave];
   // rpb rows per workgroup, rpb <= kThreads / VEC (not necessarily a power of two: it is chosen so that
@@ -109,7 +109,14 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   }
   // tile origin aligned down so 16-B loads stay aligned; the (at most 3) extra leading products are never read
   for (int off = s0 & ~3; off < s1; off += kTile) {
-    stage_products<kThreads, kNnzPerThread, NTC, NTV>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0);
+    // Plans that stream non-temporally (short rows: the vectors are worth more cache than the matrix) still keep the two ENDS
+    // of the grid cacheable -- `cache_ends` blocks each, ~24 MB of stream, an L2's worth: with the zigzag order those are the
+    // blocks the next SpMV starts with (Hardesty3-sized 155.0 -> 152.9 us; 8 / 16 / 24 / 32 / 48 / 100 MB: 153.5 / 152.9 / 152.9 /
+    // 152.9 / 153.3 / 155.1).
+    if (NTC && NTV && cache_ends > 0 && (b < cache_ends || b >= nblocks - cache_ends))
+      stage_products<kThreads, kNnzPerThread, false, false>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0);
+    else
+      stage_products<kThreads, kNnzPerThread, NTC, NTV>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0);
     __syncthreads();
     if (LENS && from_lens && off == (s0 & ~3)) {
       const int w = threadIdx.x / kWave;
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(256) void row_digest_lens_kernel(const int *__restr
 
 template <int VEC>
 void launch_vec(hipStream_t stream, const CsrDev &A, const RowDigest *D, int rpb, int xcd, double alpha, double beta,
-                const double *x, double *y) {
+                const double *x, double *y, int cache_ends) {
   if (rpb < 1 || rpb > kThreads / VEC) rpb = kThreads / VEC;
   if (D && D->rpb != rpb) D = nullptr; // a digest built for another block size does not apply
   const int nblocks = static_cast<int>((static_cast<long long>(A.m) + rpb - 1) / rpb);
@@ -194,11 +201,11 @@ void launch_vec(hipStream_t stream, const CsrDev &A, const RowDigest *D, int rpb
     if (D && D->lens)                                                                                              \
       hipLaunchKernelGGL((rowblock_stream_kernel<VEC, NC, NV, true>), dim3(nblocks), dim3(kThreads), 0, stream,     \
                          A.m, A.nnz, nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y, A.guard, A.stale,    \
-                         D->lens, D->base);                                                                        \
+                         D->lens, D->base, cache_ends);                                                            \
     else                                                                                                           \
       hipLaunchKernelGGL((rowblock_stream_kernel<VEC, NC, NV, false>), dim3(nblocks), dim3(kThreads), 0, stream,    \
                          A.m, A.nnz, nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y, A.guard, A.stale,    \
-                         static_cast<const unsigned char *>(nullptr), static_cast<const int *>(nullptr));          \
+                         static_cast<const unsigned char *>(nullptr), static_cast<const int *>(nullptr), cache_ends); \
   } while (0)
   // one set of kernels for every base-pointer alignment: their 16-B loads go through under-aligned vector types
   // (device_utils.hpp), the same instruction with the same cache policy whether or not the caller's arrays are 16-B aligned
@@ -230,15 +237,15 @@ void launch_row_digest(hipStream_t stream, const int *rp, int m, int rows_per_bl
 }
 
 void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, int rows_per_block, int xcd_remap,
-                            double alpha, double beta, const double *x, double *y, const RowDigest *digest) {
+                            double alpha, double beta, const double *x, double *y, const RowDigest *digest, int cache_ends) {
   switch (vec) {
-  case 1: launch_vec<1>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
-  case 2: launch_vec<2>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
-  case 4: launch_vec<4>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
-  case 8: launch_vec<8>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
-  case 16: launch_vec<16>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
-  case 32: launch_vec<32>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
-  default: launch_vec<64>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y); break;
+  case 1: launch_vec<1>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  case 2: launch_vec<2>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  case 4: launch_vec<4>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  case 8: launch_vec<8>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  case 16: launch_vec<16>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  case 32: launch_vec<32>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  default: launch_vec<64>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
   }
 }
 

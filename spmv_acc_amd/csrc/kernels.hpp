@@ -70,7 +70,8 @@ struct RowDigest {
   int *base = nullptr;                  // nblocks + 1 ints: rowptr[b * rpb]; bit 31 = a row of the block is longer than 255
 };
 void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, int rows_per_block, int flags,
-                            double alpha, double beta, const double *x, double *y, const RowDigest *digest = nullptr);
+                            double alpha, double beta, const double *x, double *y, const RowDigest *digest = nullptr,
+                            int cache_ends = 0);
 void launch_row_digest(hipStream_t stream, const int *rp, int m, int rows_per_block, unsigned char *lens, int *base);
 void pick_rowblock_shape(int m, int nnz, int target_products, int *vec, int *rows_per_block);
 
@@ -119,6 +120,7 @@ struct FlatPlan {
   int max_tile_rows = 0;    // most rows any one tile (= workgroup) owns (plan-time probe)
   bool early_stream = false; // issue the tile's stream loads before the break point -> rowptr chain (small grids, timed)
   bool reverse = false;     // this launch walks the tiles in reverse order (zigzag, set per launch by the engine)
+  int cache_ends = 0;       // tiles at each end of the grid that stay cacheable under the non-temporal policy (set per launch)
   const Col16 *col16 = nullptr; // opt-in: columns from the plan's 16-bit encoding instead of colindex (NPT 8 tiles only)
   bool mode_tuned = false;  // tuned_fixup holds the timed choice
   bool tuned_fixup = true;
