@@ -16,6 +16,11 @@ echo "[profile_round] kernel trace"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py "$@" --no-cpu-baseline --no-sensitivity > $OUT/bench_under_trace.json 2> $OUT/trace.log || exit 1
 S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 { head -1 $S; grep -E "spmv_acc" $S; } > $OUT/kernel_stats_spmv.csv
+# The counter passes serialise and perturb the kernels, which is enough to tip the per-matrix timings between near-equal
+# candidates: they run with the cache policy the (unperturbed) trace pass settled on, so all three passes profile one kernel.
+POL=$(python3 -c "import json,sys; d=json.loads(open('$OUT/bench_under_trace.json').read().strip().splitlines()[-1]); print(d.get('plan',{}).get('stream_policy',-1))")
+if [ "$POL" -ge 0 ] 2>/dev/null; then export SPMV_ACC_TUNABLES="stream_plain=$POL${SPMV_ACC_TUNABLES:+,$SPMV_ACC_TUNABLES}"; fi
+echo "[profile_round] counter passes with SPMV_ACC_TUNABLES=$SPMV_ACC_TUNABLES"
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "[profile_round] pmc $c"
   timeout -k 10 500 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py "$@" --no-cpu-baseline --no-legs --no-sensitivity --steps 20 --warmup 5 > $OUT/bench_under_$c.json 2> $OUT/pmc_$c.log || exit 1
