@@ -687,7 +687,11 @@ def test_measurement_switches_keep_parity(torch_dev, oracle, hiplib):
                 ("vector_row", {"vector_tile": 0}), ("vector_row", {"vector_tile": 1, "rowblock_guard": 0}), ("light", {"vector_tile": 1, "rowblock_guard": 0}),
                 ("adaptive", {"adaptive_timed": 0, "adaptive_split": 1, "vector_tile": 1}), ("adaptive", {"adaptive_timed": 0, "adaptive_split": 1, "vector_tile": 0}),
                 ("flat", {"flat_early": 1, "flat_npt": 8}), ("flat", {"flat_early": 1, "flat_npt": 4}), ("flat", {"flat_early": 0, "flat_npt": 4}),
-                ("flat", {"flat_early": 1, "flat_npt": 16, "flat_finish": 0}), ("flat", {"col16": 1}), ("flat", {"col16": 1, "flat_finish": 0})]
+                ("flat", {"flat_early": 1, "flat_npt": 16, "flat_finish": 0}), ("flat", {"col16": 1}), ("flat", {"col16": 1, "flat_finish": 0}),
+                # walking direction and cacheable grid ends (speed only)
+                ("flat", {"zigzag": 0}), ("line_enhance", {"zigzag": 0}), ("adaptive_plus", {"zigzag": 0}), ("vector_row", {"zigzag": 0}),
+                ("line_enhance", {"cache_ends_mb": 0, "stream_plain": 0}), ("line_enhance", {"cache_ends_mb": 1, "stream_plain": 0}),
+                ("flat", {"cache_ends_mb": 1, "stream_plain": 0}), ("flat", {"cache_ends_mb": 4000, "stream_plain": 0})]
     try:
         for strat, knobs in variants:
             hiplib.spmv_acc_reset_tunables()

@@ -359,3 +359,37 @@ def test_c_abi_sharded_spmv_on_a_one_rank_communicator(torch_dev, oracle, hiplib
         spmv_acc_amd.release_plans(drp)
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+def test_zigzag_direction_never_enters_a_sum(torch_dev, oracle, hiplib):
+    """Consecutive SpMVs on a plan walk the grid in alternating directions (tunable zigzag, on by default): the direction is
+    a matter of cache reuse only.  Four consecutive calls (forward, backward, forward, backward) of every tile-kernel family
+    give bit-identical y, identical to the one-direction form, and match the oracle; block counts that are not a multiple of
+    the eight XCDs and single-block grids included."""
+    torch = torch_dev
+    rng = np.random.default_rng(33)
+    for m, avg in ((50_003, 9), (9, 3), (1, 5), (2051, 40), (70_000, 2)):
+        rowptr, cols, vals = synth.csr_from_row_lengths(rng.integers(0, 2 * avg + 1, size=m), max(m, 64), rng)
+        n, nnz = max(m, 64), int(rowptr[-1])
+        x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+        drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+        ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+        for strat in ("line_enhance", "flat", "adaptive_plus", "vector_row"):
+            outs = []
+            for zz in (1, 0):
+                hiplib.spmv_acc_reset_tunables()
+                assert hiplib.spmv_acc_set_tunable(b"zigzag", zz) == 0
+                for k, val in (("flat_finish", 0), ("stream_plain", 0), ("plus_min_nnz", 1024), ("flat_npt", 8)):  # one summation order
+                    assert hiplib.spmv_acc_set_tunable(k.encode(), val) == 0
+                spmv_acc_amd.release_plans(drp)
+                for _ in range(4):
+                    dy = dev(torch, y0)
+                    spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat)
+                    torch.cuda.synchronize()
+                    outs.append(dy.cpu().numpy())
+            for o in outs[1:]:
+                assert np.array_equal(o, outs[0]), (m, strat)
+            if nnz:
+                assert oracle.scaled_error(outs[0], ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, (m, strat)
+        spmv_acc_amd.release_plans(drp)
+    hiplib.spmv_acc_reset_tunables()
