@@ -499,6 +499,7 @@ struct Plan {
     if (F.tail) (void)hipFree(F.tail);
     if (F.tail_row) (void)hipFree(F.tail_row);
     if (F.tail_end) (void)hipFree(F.tail_end);
+    if (F.digest) (void)hipFree(F.digest);
     F = FlatPlan();
   }
   void free_flat() {
@@ -636,13 +637,15 @@ bool build_flat_plan(const CsrDev &A, int stride, hipStream_t stream, FlatPlan &
       !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.head), sizeof(double) * n1), "hipMalloc head carries") ||
       !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail), sizeof(double) * n1), "hipMalloc tail carries") ||
       !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail_row), sizeof(int) * n1), "hipMalloc tail rows") ||
-      !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail_end), sizeof(int) * n1), "hipMalloc tail ends")) {
+      !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.tail_end), sizeof(int) * n1), "hipMalloc tail ends") ||
+      !hip_ok(hipMalloc(&F.digest, 16 * n1), "hipMalloc tile digest")) {
     Plan::free_flat_plan(F); // nothing half-built stays behind
     return false;
   }
   F.stride = stride;
   F.ntiles = tiles;
   launch_break_points(stream, A.rp, A.m, nnz, stride, F.bp, static_cast<int>(n1));
+  launch_flat_digest(stream, A, F);
   // does this matrix need the carry fix-up kernel at all? (only rows longer than a tile's finishing reach do)
   int *d_flag = nullptr;
   int h_flag[2] = {1, 0};

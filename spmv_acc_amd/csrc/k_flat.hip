@@ -75,7 +75,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
                                                              int *__restrict__ tail_row, int *__restrict__ tail_end,
                                                              int xcd_chunk, int reach,
                                                              const int *__restrict__ guard, int *__restrict__ stale,
-                                                             Col16Dev c16, int reverse, int cache_ends) {
+                                                             Col16Dev c16, int reverse, int cache_ends,
+                                                             const int4v *__restrict__ dig) {
   check_plan_guard(rp, m, guard, stale);
   // reach: a tile finishes its last row itself when it ends at most `reach` (0 or kFlatFinish) non-zeros past the tile
   constexpr int STRIDE = kThreads * NPT;
@@ -103,9 +104,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
   // stream: the reduction after the barrier finds everything in registers (no global latency follows the barrier on the
   // common path).  Issuing the stream loads before this chain instead (split staging) was measured: +46 VGPRs, occupancy
   // 8 -> 5, 2-4 % slower on six of seven stand-ins.
-  int first = bp[t];
-  first = first < m ? first : m;
-  const int end_excl = tile_end_excl(rp, bp, t, ntiles, m, t1);
+  // (round 2: one 16-B record per tile, built once per plan -- {first row, end row, rowptr of the last row, rowptr past it} --
+  // replaces the bp[t] -> bp[t+1] -> rowptr[.] chain and the two scalar loads of the finishing prefetch: one scalar load
+  // instead of up to five dependent ones before the row extents can be requested)
+  const int4v rec = dig[t];
+  const int first = rec.x;
+  const int end_excl = rec.y;
   const int nrows = end_excl - first;
 
   // lanes per row for this tile: as many as the tile's row count leaves room for (wave-uniform)
@@ -136,8 +140,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
   double fin_v[FIN_STEPS];
   bool fin = false; // wave-uniform
   if (reach > 0 && nrows > 0 && t < ntiles - 1 && threadIdx.x < kWave) {
-    const int lr = end_excl - 1;
-    const int la = rp[lr], lb = rp[lr + 1];
+    const int la = rec.z, lb = rec.w;
     fin = la >= t0 && lb > t1 && lb - t1 <= reach;
     if (fin) {
 #pragma unroll
@@ -213,13 +216,28 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
   }
   // a tile without a carried row says so (the fix-up reads tail_row only)
   if (threadIdx.x == 0) {
-    bool has_carry = false;
-    if (nrows > 0) {
-      const int r = end_excl - 1;
-      has_carry = (rp[r] >= t0) && (rp[r + 1] - t1 > reach);
-    }
+    const bool has_carry = nrows > 0 && rec.z >= t0 && rec.w - t1 > reach;
     if (!has_carry) tail_row[t] = -1;
   }
+}
+
+// Plan time, one thread per tile: the tile's digest {first row, end row (exclusive), rowptr[end - 1], rowptr[end]} (zeros for
+// the extents of a tile that owns no rows).
+__global__ __launch_bounds__(256) void flat_digest_kernel(const int *__restrict__ rp, const int *__restrict__ bp, int ntiles, int m,
+                                                          int nnz, int stride, int4v *__restrict__ dig) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntiles) return;
+  const int t0 = t * stride;
+  const int t1 = (nnz - t0 > stride) ? t0 + stride : nnz;
+  int first = bp[t];
+  first = first < m ? first : m;
+  const int end_excl = tile_end_excl(rp, bp, t, ntiles, m, t1);
+  int4v rec;
+  rec.x = first;
+  rec.y = end_excl;
+  rec.z = end_excl > first ? rp[end_excl - 1] : 0;
+  rec.w = end_excl > first ? rp[end_excl] : 0;
+  dig[t] = rec;
 }
 
 // Plan time, one thread per tile:  flag[0] = 1 if any row runs more than kFlatFinish non-zeros past the end of the tile it
@@ -283,11 +301,11 @@ void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P,
   if (P.early_stream)
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends);
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest));
   else
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends);
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest));
 }
 // opt-in 16-bit columns: NPT 8 tiles (a multiple of the 256-non-zero chunk), values under the plan's cache policy
 template <bool NTV>
@@ -296,7 +314,7 @@ void launch_flat_col16(hipStream_t stream, const CsrDev &A, const FlatPlan &P, d
   const Col16Dev c = {P.col16->d16, P.col16->base, P.col16->esc_start, P.col16->esc_cols};
   hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, true, NTV, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, c, P.reverse ? 1 : 0, P.cache_ends);
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, c, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest));
 }
 template <int NPT>
 void launch_flat_policy(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
@@ -309,6 +327,12 @@ void launch_flat_policy(hipStream_t stream, const CsrDev &A, const FlatPlan &P, 
   }
 }
 } // namespace
+
+void launch_flat_digest(hipStream_t stream, const CsrDev &A, const FlatPlan &P) {
+  if (P.ntiles <= 0) return;
+  hipLaunchKernelGGL(flat_digest_kernel, dim3((P.ntiles + 255) / 256), dim3(256), 0, stream, A.rp, P.bp, P.ntiles, A.m, A.nnz, P.stride,
+                     static_cast<int4v *>(P.digest));
+}
 
 void launch_flat_needs_fixup(hipStream_t stream, const CsrDev &A, const FlatPlan &P, int *d_flag) {
   if (P.ntiles <= 0) return;

@@ -112,6 +112,8 @@ struct FlatPlan {
   double *tail = nullptr;   // per tile: partial sum of the row that continues in the next tile
   int *tail_row = nullptr;  // per tile: that row, or -1
   int *tail_end = nullptr;  // per tile: rowptr[row + 1] of that row
+  void *digest = nullptr;   // per tile, 16 B: {first row, end row, rowptr[end - 1], rowptr[end]} -- what the tile kernel reads instead
+                            // of the bp -> rowptr chain (built once per plan from bp and rowptr)
   int xcd_chunk = 0;        // > 0: XCD-chunked tile order (device_utils.hpp::xcd_chunked_block)
   int stream_policy = 0;    // cache policy of the stream loads (kStreamPolicy*)
   bool can_finish = false;  // no row runs more than kFlatFinish non-zeros past the tile it starts in (plan-time probe)
@@ -132,6 +134,7 @@ struct FlatPlan {
 // (by the finishing tile and by the next one), so the reach is kept small: <= 6% of a tile.  Measured with a reach of
 // 2048 the TSOPF-like matrix (424 nnz/row) lost 15%: ~10% extra traffic plus a serial tail per block.
 constexpr int kFlatFinish = 128;
+void launch_flat_digest(hipStream_t stream, const CsrDev &A, const FlatPlan &P); // after launch_break_points
 void launch_flat_needs_fixup(hipStream_t stream, const CsrDev &A, const FlatPlan &P, int *d_flag); // d_flag[2] pre-zeroed
 void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                  double *y);
