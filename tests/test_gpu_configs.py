@@ -236,3 +236,28 @@ def test_configs4_banded_shard_full_size(torch_dev, oracle):
     finally:
         spmv_acc_amd.release_plans(rp)
         torch.cuda.empty_cache()
+
+
+def test_bench_line_carries_every_baseline_config(torch_dev):
+    """The driver's command -- `python bench.py` with its defaults -- prints ONE JSON line on stdout whose headline is
+    configs[1] and which carries configs[2] (`sweep`: 12 stand-ins x {flat, adaptive}), configs[3] (`rmat25`) and configs[4]
+    (`banded_shard`) measured live in the same run, next to `roofline` and `cpu_baseline`."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "50", "--warmup", "5", "--cpu-seconds", "2"],
+                         capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    assert len(out) == 1, out[:3]  # libraries' chatter goes to stderr
+    d = json.loads(out[0])
+    assert d["n_gpus"] == 1 and d["config"]["strategy"] == "adaptive" and "Hardesty3" in d["config"]["workload"]
+    assert set(d["sweep"]) == set(synth.SWEEP_NAMES)
+    for name, row in d["sweep"].items():
+        for strat in ("flat", "adaptive"):
+            assert row[strat]["us"] > 0 and 0.05 < row[strat]["frac"] < 1.2, (name, strat, row[strat])
+    assert d["rmat25"]["nnz"] > 480_000_000 and d["rmat25"]["line_enhance"]["us"] > 1000
+    assert d["banded_shard"]["rows"] == 32_000_000 and 0.3 < d["banded_shard"]["adaptive"]["frac"] < 1.2
+    assert d["roofline"]["traffic"] is not None and d["roofline"]["traffic_lower_bound"] is not None
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
