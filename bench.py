@@ -474,6 +474,9 @@ def main():
                      "traffic": pmc_traffic(args.workload, strat) if args.scale == 1.0 else None,
                      "traffic_lower_bound": pmc_traffic(args.workload, strat, "lower_bound_bytes") if args.scale == 1.0 else None,
                      "algorithmic_bytes_per_launch": b_alg, "launch_ms_mean": round(ev_ms, 6)},
+        "protocol": "K back-to-back SpMVs on one matrix resident in HBM (the reference's benchmark protocol, csr_spmv.hpp:49-74); every SpMV reads "
+                    "all of its inputs and writes all of y; consecutive SpMVs on a plan walk the matrix in alternating directions (library "
+                    "default, tunable zigzag), so each pass starts in what the previous one left in L2 / Infinity Cache",
         "ref_formula_gibps": round(synth.reference_bytes(m, nnz) / 2**30 / (ev_ms * 1e-3), 2),
         "gflops_kernel_only_per_gpu": round(2.0 * nnz / (ev_ms * 1e-3) / 1e9, 3),
     }
