@@ -900,6 +900,12 @@ template <typename Launch> bool autotune_policy(Plan &p, int fam, hipStream_t st
   const int cls = t_beta_class;
   if (p.stream_policy[fam][cls] >= 0) return true;
   if (tun(kT_stream_plain) >= 0) return true; // pinned (A/B runs): policy_for follows the tunable, nothing is recorded
+  // A matrix prepared in one beta class (spmv_acc_prepare: beta = 1) and then CAPTURED into a hipGraph in the other: timing would
+  // synchronise inside the capture.  The call runs under the policy the other class measured (policy_for's fallback) and this
+  // class is timed by the first call made outside a capture.
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &capture) == hipSuccess && capture != hipStreamCaptureStatusNone) return true;
+  (void)hipGetLastError();
   // While adaptive compares the families only the first one times the three policies; the others run under that result
   // (policy_for) and the family that wins times its own on its next call.  (Timing all three per family made adaptive's
   // first call 21 ms on the Hardesty3-sized matrix, 134 SpMVs' worth; the comparison itself needs 8 launches per family.)

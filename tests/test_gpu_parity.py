@@ -942,6 +942,16 @@ def test_prepare_then_first_call_is_capturable(torch_dev, oracle, hiplib):
             torch.cuda.synchronize()
             err = oracle.scaled_error(static_y.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, vals, x, y0)
             assert err <= SCALED_TOL, (strat, err)
+            # the other beta class (y = A x) captured straight after a preparation made at beta = 1: the cache policy of that class
+            # has not been timed -- the captured call must not try to (it would synchronise inside the capture)
+            y_b0 = dev(torch, y0)
+            g0 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g0, stream=side):
+                spmv_acc_amd.csr_spmv(1.0, 0.0, m, n, nnz, drp, dci, dv, dx, y_b0, strategy=strat)
+            g0.replay()
+            torch.cuda.synchronize()
+            ref0 = oracle.host_spmv(1.0, 0.0, rowptr, cols, vals, x, y0)
+            assert oracle.scaled_error(y_b0.cpu().numpy(), ref0, 1.0, 0.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, (strat, "beta = 0 captured")
             spmv_acc_amd.release_plans(drp)
     finally:
         hiplib.spmv_acc_set_stream(None)
