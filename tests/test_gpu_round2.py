@@ -393,3 +393,48 @@ def test_zigzag_direction_never_enters_a_sum(torch_dev, oracle, hiplib):
                 assert oracle.scaled_error(outs[0], ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, (m, strat)
         spmv_acc_amd.release_plans(drp)
     hiplib.spmv_acc_reset_tunables()
+
+
+def test_row_digest_edge_cases(torch_dev, oracle, hiplib):
+    """The row-block kernel's row extents from the plan's digest (1-byte lengths + per-block bases, tunable rowlen forced on):
+    rows of exactly 254 / 255 / 256 / 257 non-zeros (255 is the last length a byte holds; longer rows flag their block, which
+    then reads rowptr), such rows first / last in their block, empty rows and empty blocks, a row count that is not a multiple
+    of the rows per block, every lane width, and a row shard that is not rebased (rowptr[0] > 0)."""
+    torch = torch_dev
+    rng = np.random.default_rng(77)
+    m = 5003
+    lens = rng.integers(0, 7, size=m)
+    lens[0], lens[255], lens[256], lens[511] = 255, 254, 256, 257     # block edges of the 256-row blocks
+    lens[1000:1300] = 0                                               # an empty block and more
+    lens[2047], lens[2048] = 255, 255
+    lens[m - 1] = 256
+    rowptr, cols, vals = synth.csr_from_row_lengths(lens, 6000, rng)
+    nnz = int(rowptr[-1])
+    x, y0 = rng.standard_normal(6000), rng.standard_normal(m)
+    drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+    ref = oracle.host_spmv(0.5, -2.0, rowptr, cols, vals, x, y0)
+    try:
+        for vec in (0, 1, 2, 4, 8, 16, 32, 64):
+            for target in (1900, 300):
+                hiplib.spmv_acc_reset_tunables()
+                for k, val in (("rowlen", 1), ("rowblock_guard", 0), ("rowblock_vec", vec), ("rowblock_target", target)):
+                    assert hiplib.spmv_acc_set_tunable(k.encode(), val) == 0
+                spmv_acc_amd.release_plans(drp)
+                for _ in range(2):  # both walking directions
+                    dy = dev(torch, y0)
+                    spmv_acc_amd.csr_spmv(0.5, -2.0, m, 6000, nnz, drp, dci, dv, dx, dy, strategy="line_enhance")
+                    torch.cuda.synchronize()
+                    err = oracle.scaled_error(dy.cpu().numpy(), ref, 0.5, -2.0, rowptr, cols, vals, x, y0)
+                    assert err <= SCALED_TOL, (vec, target, err)
+        # not rebased shard
+        r0, r1 = 257, 4100
+        hiplib.spmv_acc_reset_tunables()
+        assert hiplib.spmv_acc_set_tunable(b"rowlen", 1) == 0 and hiplib.spmv_acc_set_tunable(b"rowblock_guard", 0) == 0
+        dy = dev(torch, y0[r0:r1])
+        spmv_acc_amd.csr_spmv(0.5, -2.0, r1 - r0, 6000, int(rowptr[r1]), drp[r0: r1 + 1], dci, dv, dx, dy, strategy="line_enhance")
+        torch.cuda.synchronize()
+        assert np.max(np.abs(dy.cpu().numpy() - ref[r0:r1])) <= 1e-11
+        spmv_acc_amd.release_plans(drp[r0: r1 + 1])
+    finally:
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans(drp)
