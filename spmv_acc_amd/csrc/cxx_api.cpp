@@ -51,6 +51,7 @@ void flat_sparse_spmv(int trans, const double alpha, const double beta, const cs
 void segment_sum_flat_sparse_spmv(int trans, const double alpha, const double beta,
                                   const csr_desc<int, double> h_csr_desc, const csr_desc<int, double> d_csr_desc,
                                   const double *x, double *y) {
+  FlatSegmentSumScope scope; // same tiles and cut-row handling, rows reduced by the segmented scan over the tile
   go(kFlat, trans, alpha, beta, &h_csr_desc, d_csr_desc, x, y);
 }
 void adaptive_flat_sparse_spmv(const int, const int, int trans, const double alpha, const double beta,

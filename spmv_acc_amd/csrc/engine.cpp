@@ -83,8 +83,13 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kTunableCount
 };
+#ifdef FLAT_SEGMENT_SUM_REDUCE
+constexpr int kFlatReduceBuilt = 1;
+#else
+constexpr int kFlatReduceBuilt = 0;
+#endif
 Tunable g_tunables[] = {
     {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
     {"xcd_chunk", 16, 16},     // row-block family: each XCD takes this many consecutive blocks per super-chunk (0 = off)
@@ -126,6 +131,11 @@ Tunable g_tunables[] = {
                                // the plan streams non-temporally)
     {"cache_ends_mb", 24, 24}, // row blocks / flat under the non-temporal policy: MB of stream at each end of the grid that stay cacheable
                                // (an L2's worth: the zigzag order starts the next SpMV there); 0 = off
+    {"flat_reduce", kFlatReduceBuilt, kFlatReduceBuilt}, // flat: how a tile's products become row sums: 0 = lane groups per row (w lanes per row from the tile's row
+                               // count, long spans to whole waves), 1 = the segmented scan over the tile (the reference's option
+                               // FLAT_SEGMENT_SUM_REDUCE, which as a build macro makes 1 the default like strategy_picker.cpp:34-39; what
+                               // segment_sum_flat_sparse_spmv runs whatever this is set to); 2048-non-zero tiles.  Measured: +1 % on the
+                               // headline matrix, +30..40 % on the small / medium stand-ins (three more barriers per tile)
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -675,7 +685,11 @@ bool build_flat_plan(const CsrDev &A, int stride, hipStream_t stream, FlatPlan &
 // not hidden by other workgroups: there the tile size and the stream-first staging are timed per matrix as well.
 constexpr int kFlatSmallNnz = 24 << 20;
 
+thread_local bool t_flat_segment_sum = false; // this thread is inside segment_sum_flat_sparse_spmv (FlatSegmentSumScope)
+inline bool flat_segment_sum() { return (t_flat_segment_sum || tun(kT_flat_reduce) == 1) && tun(kT_col16) <= 0; }
+
 int flat_stride_for(const Plan &p) {
+  if (flat_segment_sum()) return kThreads * kNnzPerThread; // the scan is written for the 2048-non-zero tile
   if (tun(kT_col16) > 0) return kThreads * kNnzPerThread; // the 16-bit encoding is read by the 2048-non-zero tile
   int npt = tun(kT_flat_npt);
   if (npt < 0) npt = p.flat_npt_choice > 0 ? p.flat_npt_choice : kNnzPerThread;
@@ -999,6 +1013,7 @@ void launch_flat_plan(hipStream_t st, const CsrDev &A, FlatPlan &F, int policy, 
   launch_flat(st, A, F, alpha, beta, x, y);
 }
 void launch_flat_with(hipStream_t st, Plan &p, int policy, double alpha, double beta, const double *x, double *y) {
+  p.flat.segment_sum = flat_segment_sum();
   launch_flat_plan(st, p.A, p.flat, policy, alpha, beta, x, y, next_reverse(p));
 }
 
@@ -1046,7 +1061,7 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
 // per matrix and keep the fastest.  The other tile size gets its own break points / carries; its cut rows are finished in
 // the tile whenever that is legal (no second launch: what wins on short kernels).
 bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
-  if (p.flat_geometry_tuned || tun(kT_col16) > 0) return true;
+  if (p.flat_geometry_tuned || tun(kT_col16) > 0 || flat_segment_sum()) return true;
   if (p.A.nnz >= kFlatSmallNnz || p.flat.ntiles <= 1) {
     p.flat_geometry_tuned = true;
     return true;
@@ -1379,6 +1394,9 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
 }
 
 } // namespace
+
+FlatSegmentSumScope::FlatSegmentSumScope() : prev(t_flat_segment_sum) { t_flat_segment_sum = true; }
+FlatSegmentSumScope::~FlatSegmentSumScope() { t_flat_segment_sum = prev; }
 
 void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
               const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx, double *dy) {

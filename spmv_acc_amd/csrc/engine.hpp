@@ -66,6 +66,14 @@ hipStream_t get_stream();
 int active_strategy();
 int set_active_strategy(int s);
 
+// While one of these lives, kFlat calls of this thread reduce their tiles by the segmented scan (tunable flat_reduce = 1 for the
+// thread): how segment_sum_flat_sparse_spmv (reference: hip-flat/flat.cpp:59-76) differs from flat_sparse_spmv.
+struct FlatSegmentSumScope {
+  FlatSegmentSumScope();
+  ~FlatSegmentSumScope();
+  bool prev;
+};
+
 // Host samples of rowptr that the reference's pickers read from h_csr_desc (adaptive.cpp:24-27,
 // flat.cpp:51-52).
 struct RowptrSamples {

@@ -65,7 +65,12 @@ struct Col16Dev {
 
 // (amdgpu_waves_per_eu(7): the register allocator is asked to stay within 72 VGPRs -- 7 workgroups per CU -- where the
 // plain kernel with the finishing prefetch would take 78; the stream-first variants need more registers by design)
-template <int NPT, bool NTC, bool NTV, bool EARLY, bool C16 = false>
+// SEGSUM: the reference's other reduction of a flat tile (FLAT_SEGMENT_SUM_REDUCE, hip-flat/flat.cpp:59-76 +
+// common/utils.h:75-94 block_segment_sum: a Hillis-Steele segmented scan over the tile keyed by row index).  Here: row starts
+// are flagged in LDS, every lane scans its NPT consecutive products in place (restarting at a flag), the lanes' open sums cross
+// by a segmented scan over the 256 lanes (shuffles inside a wave, LDS across the four waves), and a row's sum is the scanned
+// value at its last product.  No lane-group width, no dependence on the tile's row-length mix; one lane per row afterwards.
+template <int NPT, bool NTC, bool NTV, bool EARLY, bool C16 = false, bool SEGSUM = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY || NPT > 8 ? 1 : 7, 8))) void flat_tile_kernel(int m, int nnz, int ntiles, double alpha, double beta,
                                                              const int *__restrict__ rp, const int *__restrict__ bp,
                                                              const int *__restrict__ ci,
@@ -112,9 +117,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
   const int end_excl = rec.y;
   const int nrows = end_excl - first;
 
-  // lanes per row for this tile: as many as the tile's row count leaves room for (wave-uniform)
+  // lanes per row for this tile: as many as the tile's row count leaves room for (wave-uniform); one with the segmented scan
   int w = 1;
-  while (w < 64 && nrows * (w * 2) <= kThreads) w <<= 1;
+  while (!SEGSUM && w < 64 && nrows * (w * 2) <= kThreads) w <<= 1;
   const int lane = threadIdx.x & (w - 1);
   const int vec_id = threadIdx.x / w;
   const int vecs = kThreads / w;
@@ -166,7 +171,74 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
       if (fin_c[k] >= 0) fin_extra += fin_v[k] * x[fin_c[k]];
   }
 
+  __shared__ unsigned char seg_head[SEGSUM ? STRIDE : 1];
+  __shared__ double seg_wave_sum[kThreads / kWave];
+  __shared__ int seg_wave_flag[kThreads / kWave];
+  if (SEGSUM) { // flags cleared before the barrier that publishes the tile
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) seg_head[NPT * threadIdx.x + e] = 0;
+  }
+
   __syncthreads();
+
+  if (SEGSUM) {
+    // 1. flag the first product of every row that starts inside the tile (one lane per row; the tile start opens a segment too)
+    if (threadIdx.x == 0) seg_head[0] = 1;
+    for (int base = 0; base < nrows; base += kThreads) {
+      const int i = base + static_cast<int>(threadIdx.x);
+      if (i < nrows) {
+        const int a = (base == 0) ? a0 : rp[first + i];
+        const int b = (base == 0) ? b0 : rp[first + i + 1];
+        if (a >= t0 && a < t1 && b > a) seg_head[a - t0] = 1;
+      }
+    }
+    __syncthreads();
+    // 2. every lane scans its NPT consecutive products in place
+    const int c0 = NPT * static_cast<int>(threadIdx.x);
+    double run = 0.0;
+    int first_head = NPT; // position of the first flag in this lane's chunk (NPT: none)
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) {
+      if (seg_head[c0 + e]) {
+        run = 0.0;
+        first_head = first_head == NPT ? e : first_head;
+      }
+      run += lds[c0 + e];
+      lds[c0 + e] = run;
+    }
+    // 3. segmented inclusive scan of the lanes' open sums: (flag, value) pairs, flag = the chunk holds a row start
+    double sv = run;
+    int sf = first_head < NPT ? 1 : 0;
+    const int wl = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const double pv = __shfl_up(sv, d, kWave);
+      const int pf = __shfl_up(sf, d, kWave);
+      if (wl >= d && !sf) {
+        sv += pv;
+        sf = pf;
+      }
+    }
+    if (wl == kWave - 1) {
+      seg_wave_sum[threadIdx.x / kWave] = sv;
+      seg_wave_flag[threadIdx.x / kWave] = sf;
+    }
+    __syncthreads();
+    double incoming = 0.0; // what flows into this wave from the waves before it
+    for (int k = 0; k < static_cast<int>(threadIdx.x / kWave); ++k) incoming = seg_wave_flag[k] ? seg_wave_sum[k] : incoming + seg_wave_sum[k];
+    double ev = __shfl_up(sv, 1, kWave);
+    int ef = __shfl_up(sf, 1, kWave);
+    if (wl == 0) {
+      ev = 0.0;
+      ef = 0;
+    }
+    const double carry_in = ef ? ev : ev + incoming;
+    // 4. the products before the chunk's first flag belong to the segment that was open on entry
+#pragma unroll
+    for (int e = 0; e < NPT; ++e)
+      if (e < first_head) lds[c0 + e] += carry_in;
+    __syncthreads();
+  }
 
   // all lanes walk the same number of iterations so the DPP reduction sees a full exec mask
   for (int base = 0; base < nrows; base += vecs) {
@@ -182,8 +254,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
     }
     const int lo = (a > t0 ? a : t0) - t0;
     const int hi = (b < t1 ? b : t1) - t0;
-    double s = tile_row_sum<kThreads>(lds, spans, lo, hi > lo ? hi : lo, lane, w); // long spans go to whole waves
-    s = group_sum_dyn(s, w);
+    double s;
+    if (SEGSUM) {
+      s = hi > lo ? lds[hi - 1] : 0.0; // the scanned value at the row's last product in the tile
+    } else {
+      s = tile_row_sum<kThreads>(lds, spans, lo, hi > lo ? hi : lo, lane, w); // long spans go to whole waves
+      s = group_sum_dyn(s, w);
+    }
     if (live && lane == 0) {
       if (a >= t0 && b <= t1) {
         // complete row (possibly empty): final value
@@ -307,6 +384,16 @@ void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
                        P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest));
 }
+// the segmented-scan reduction (reference option FLAT_SEGMENT_SUM_REDUCE): 2048-non-zero tiles, values / colindex under the plan's policy
+template <bool NTC, bool NTV>
+void launch_flat_segsum(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
+                        double *y) {
+  const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
+                     A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
+                     static_cast<const int4v *>(P.digest));
+}
 // opt-in 16-bit columns: NPT 8 tiles (a multiple of the 256-non-zero chunk), values under the plan's cache policy
 template <bool NTV>
 void launch_flat_col16(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
@@ -344,7 +431,14 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
                  double *y) {
   if (P.ntiles <= 0) return;
   const int npt = P.stride / kThreads;
-  if (P.col16 && npt == kNnzPerThread) {
+  if (P.segment_sum && npt == kNnzPerThread) {
+    switch (P.stream_policy & 3) {
+    case 1: launch_flat_segsum<false, false>(stream, A, P, alpha, beta, x, y); break;
+    case 2: launch_flat_segsum<false, true>(stream, A, P, alpha, beta, x, y); break;
+    case 3: launch_flat_segsum<true, false>(stream, A, P, alpha, beta, x, y); break;
+    default: launch_flat_segsum<true, true>(stream, A, P, alpha, beta, x, y); break;
+    }
+  } else if (P.col16 && npt == kNnzPerThread) {
     // values default for policies 1 (both default) and 3 (values default), non-temporal otherwise
     if ((P.stream_policy & 3) == 1 || (P.stream_policy & 3) == 3) launch_flat_col16<false>(stream, A, P, alpha, beta, x, y);
     else launch_flat_col16<true>(stream, A, P, alpha, beta, x, y);

@@ -123,6 +123,7 @@ struct FlatPlan {
   bool early_stream = false; // issue the tile's stream loads before the break point -> rowptr chain (small grids, timed)
   bool reverse = false;     // this launch walks the tiles in reverse order (zigzag, set per launch by the engine)
   int cache_ends = 0;       // tiles at each end of the grid that stay cacheable under the non-temporal policy (set per launch)
+  bool segment_sum = false; // rows reduced by the segmented scan over the tile (reference option FLAT_SEGMENT_SUM_REDUCE), 2048-tile only
   const Col16 *col16 = nullptr; // opt-in: columns from the plan's 16-bit encoding instead of colindex (NPT 8 tiles only)
   bool mode_tuned = false;  // tuned_fixup holds the timed choice
   bool tuned_fixup = true;

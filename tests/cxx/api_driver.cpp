@@ -78,6 +78,7 @@ int main(int argc, char **argv) {
   reset(); default_sparse_spmv(trans, alpha, beta, d_csr.as_const(), dx, dy); dump();
   reset(); adaptive_sparse_spmv(trans, alpha, beta, h_csr.as_const(), d_csr.as_const(), dx, dy); dump();
   reset(); flat_sparse_spmv(trans, alpha, beta, h_csr.as_const(), d_csr.as_const(), dx, dy); dump();
+  reset(); segment_sum_flat_sparse_spmv(trans, alpha, beta, h_csr.as_const(), d_csr.as_const(), dx, dy); dump();
   reset(); line_enhance_sparse_spmv(trans, alpha, beta, d_csr.as_const(), dx, dy); dump();
   reset(); adaptive_enhance_sparse_spmv(trans, alpha, beta, d_csr.as_const(), dx, dy); dump();
   reset(); adaptive_line_sparse_spmv(trans, alpha, beta, d_csr.as_const(), dx, dy); dump();

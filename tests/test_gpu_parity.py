@@ -377,7 +377,7 @@ def test_cxx_api_driver(torch_dev, oracle, tmp_path):
     outp = str(tmp_path / "out.bin")
     subprocess.run([exe, inp, outp], check=True)
     ys = np.fromfile(outp, dtype=np.float64).reshape(-1, 4000)
-    assert ys.shape[0] >= 8
+    assert ys.shape[0] >= 13
     for k, y in enumerate(ys):
         check(oracle, y, 1.0, 1.0, rowptr, cols, vals, x, y0, ("cxx", k))
 
@@ -691,7 +691,10 @@ def test_measurement_switches_keep_parity(torch_dev, oracle, hiplib):
                 # walking direction and cacheable grid ends (speed only)
                 ("flat", {"zigzag": 0}), ("line_enhance", {"zigzag": 0}), ("adaptive_plus", {"zigzag": 0}), ("vector_row", {"zigzag": 0}),
                 ("line_enhance", {"cache_ends_mb": 0, "stream_plain": 0}), ("line_enhance", {"cache_ends_mb": 1, "stream_plain": 0}),
-                ("flat", {"cache_ends_mb": 1, "stream_plain": 0}), ("flat", {"cache_ends_mb": 4000, "stream_plain": 0})]
+                ("flat", {"cache_ends_mb": 1, "stream_plain": 0}), ("flat", {"cache_ends_mb": 4000, "stream_plain": 0}),
+                # the segmented-scan reduction of a flat tile (the reference's FLAT_SEGMENT_SUM_REDUCE)
+                ("flat", {"flat_reduce": 1}), ("flat", {"flat_reduce": 1, "flat_finish": 0}), ("flat", {"flat_reduce": 1, "flat_finish": 1, "stream_plain": 1}),
+                ("flat", {"flat_reduce": 1, "flat_npt": 4}), ("flat", {"flat_reduce": 1, "stage_fast": 0})]
     try:
         for strat, knobs in variants:
             hiplib.spmv_acc_reset_tunables()

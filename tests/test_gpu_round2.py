@@ -438,3 +438,46 @@ def test_row_digest_edge_cases(torch_dev, oracle, hiplib):
     finally:
         hiplib.spmv_acc_reset_tunables()
         spmv_acc_amd.release_plans(drp)
+
+
+def test_flat_segmented_scan_reduction(torch_dev, oracle, hiplib):
+    """flat with its tiles reduced by the segmented scan (tunable flat_reduce = 1; what segment_sum_flat_sparse_spmv runs; reference:
+    hip-flat/flat.cpp:59-76 with block_segment_sum, common/utils.h:75-94): rows that start on a lane's first / last product, rows that span
+    lanes, waves and tiles, runs of empty rows at tile edges, one row over many tiles, hypersparse tails, a single non-zero, both cut-row
+    forms, both walking directions, alpha / beta classes."""
+    torch = torch_dev
+    rng = np.random.default_rng(404)
+    cases = []
+    lens = rng.integers(0, 12, size=9001)
+    lens[17], lens[400], lens[401] = 2048, 5000, 1          # exactly one tile; several tiles; a one-product row right behind
+    lens[1000:1400] = 0                                      # a run of empty rows
+    lens[3000:3008] = 8                                      # rows equal to a lane's chunk
+    lens[5000] = 511
+    cases.append(("mixed", lens, 7000))
+    cases.append(("one_long_row", np.array([0, 0, 30000, 0, 1]), 40000))
+    cases.append(("ones", np.ones(10000, dtype=np.int64), 10000))
+    cases.append(("hypersparse", (rng.random(200000) < 0.01).astype(np.int64), 5000))
+    cases.append(("single", np.array([0, 1, 0]), 3))
+    cases.append(("sevens_and_nines", np.where(np.arange(6000) % 2 == 0, 7, 9), 6000))
+    cases.append(("wave_rows", np.full(700, 64), 4096))
+    try:
+        for name, lens, n in cases:
+            rowptr, cols, vals = synth.csr_from_row_lengths(lens, n, rng)
+            m, nnz = len(lens), int(rowptr[-1])
+            x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+            drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+            for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (-0.75, 2.5)):
+                ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+                for finish in (-1, 0, 1):
+                    hiplib.spmv_acc_reset_tunables()
+                    assert hiplib.spmv_acc_set_tunable(b"flat_reduce", 1) == 0 and hiplib.spmv_acc_set_tunable(b"flat_finish", finish) == 0
+                    spmv_acc_amd.release_plans(drp)
+                    for _ in range(2):
+                        dy = dev(torch, y0)
+                        spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, dy, strategy="flat")
+                        torch.cuda.synchronize()
+                        err = oracle.scaled_error(dy.cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0)
+                        assert err <= SCALED_TOL, (name, alpha, beta, finish, err)
+            spmv_acc_amd.release_plans(drp)
+    finally:
+        hiplib.spmv_acc_reset_tunables()
