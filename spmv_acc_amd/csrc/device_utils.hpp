@@ -82,6 +82,29 @@ template <bool NT> __device__ __forceinline__ double2v load_stream_d2(const doub
   return NT ? __builtin_nontemporal_load(reinterpret_cast<const double2v_a8 *>(p)) : *reinterpret_cast<const double2v_a8 *>(p);
 }
 
+// ---- hinted gathers -------------------------------------------------------------------------------------------------------
+// A gather whose cache policy is chosen per lane.  Written as `cold ? nontemporal_load(p) : *p` the compiler folds the two loads
+// into one plain load of a selected address; buffer loads carry the policy as an immediate operand of the builtin, so the two
+// calls stay two instructions (same destination register, complementary lanes, one wait at the first use).  Byte offsets are
+// 32 bits: the engine uses hints only where x is below 4 GB; out-of-range offsets read 0 instead of faulting.
+struct XGather {
+  __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ __forceinline__ XGather make_xgather(const double *x, bool used) {
+  XGather g;
+  // raw buffer over [x, x + 4 GB): stride 0, DATA_FORMAT 32 (word 3 = 0x00020000, the gfx9 untyped-buffer descriptor)
+  g.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(used ? x : nullptr), 0, used ? 0xffffffff : 0, 0x00020000);
+  return g;
+}
+__device__ __forceinline__ double gather_hinted(const XGather &g, int col, unsigned cold) {
+  typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+  uint2v r;
+  const int off = col << 3;
+  if (cold) r = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, off, 0, 2); // aux 2: nt
+  else r = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, off, 0, 0);
+  return __hiloint2double(static_cast<int>(r.y), static_cast<int>(r.x));
+}
+
 // ---- XCD-aware block remap ------------------------------------------------------------------------
 // Hardware deals block b to XCD (b mod 8).  Neighbouring row blocks share x[] lines, so give each
 // XCD one contiguous chunk of the logical block range (bijective for any nblocks).  Placement is a

@@ -83,7 +83,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kTunableCount
 };
 #ifdef FLAT_SEGMENT_SUM_REDUCE
 constexpr int kFlatReduceBuilt = 1;
@@ -136,6 +136,12 @@ Tunable g_tunables[] = {
                                // FLAT_SEGMENT_SUM_REDUCE, which as a build macro makes 1 the default like strategy_picker.cpp:34-39; what
                                // segment_sum_flat_sparse_spmv runs whatever this is set to); 2048-non-zero tiles.  Measured: +1 % on the
                                // headline matrix, +30..40 % on the small / medium stand-ins (three more barriers per tile)
+    {"gather_hint", -1, -1},   // gather hints (k_hint.hip): the plan's column census marks the non-zeros whose x line is outside the hot set that
+                               // fits an L2, and their gathers go non-temporal so they do not displace it.  -1 = where the census finds such a
+                               // set (power-law columns) the kernel is timed with and without once per matrix; 0 off; 1 = always build and use
+    {"hint_budget_kb", 4608, 4608}, // size of the hot set of x lines the census keeps cacheable.  An XCD's L2 is 4 MB; measured on R-MAT scale 25
+                               // (8.17-8.21 ms without hints): 1 MB 9.43, 2 MB 8.33, 3 MB 7.71, 3.5 MB 7.35, 4 MB 7.06-7.25, 4.5 MB 7.21, 5 MB 7.19,
+                               // 6 MB 7.25, 8 MB 7.70, 16 MB 7.94 ms -- a hot set smaller than what LRU keeps by itself loses, one around the L2 size wins
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -469,6 +475,12 @@ struct Plan {
   int plus_min = 0; // MIN_NNZ_PER_BLOCK the analysis ran with
   int plus_tuned_min = 0; // the timed choice (0 = not timed yet)
   bool plus_has_long = false;
+  // gather hints: census state (-1 not taken, 0 no hot set worth protecting / not applicable, 1 bits built), the bits, the timed
+  // choice per kernel family (-1 not timed, 0 plain gathers, 1 hinted)
+  int hint_state = -1;
+  unsigned char *d_cold = nullptr;
+  double hint_hot_share = 0.0;
+  int hint_use[kFamilyCount] = {-1, -1, -1, -1};
   int *d_pbp = nullptr;
   int *d_pfbr = nullptr;
   double *d_ppartial = nullptr;
@@ -492,6 +504,9 @@ struct Plan {
     digest = RowDigest();
   }
   void free_device() {
+    if (d_cold) (void)hipFree(d_cold);
+    d_cold = nullptr;
+    hint_state = -1;
     free_flat();
     free_digest();
     free_col16();
@@ -1120,6 +1135,118 @@ bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
   return ok;
 }
 
+// Gather hints (k_hint.hip): census of the matrix' columns -> hot set of x lines within the budget -> one cold bit per non-zero.
+// Returns false on a HIP failure only; p.hint_state says whether hints exist.
+bool ensure_hint(Plan &p, hipStream_t st) {
+  if (p.hint_state >= 0) return true;
+  const int mode = tun(kT_gather_hint);
+  p.hint_state = 0;
+  const CsrDev &A = p.A;
+  // hinted gathers address x by 32-bit byte offsets; a matrix whose x fits an L2 several times over has nothing to protect
+  if (mode == 0 || A.nnz < 8 || A.n <= 0 || static_cast<long long>(A.n) * 8 >= (1LL << 32)) return true;
+  if (mode < 0 && static_cast<long long>(A.n) * 8 < (8LL << 20)) return true;
+  ++t_plan_work;
+  const int nlines = (A.n + (1 << kHintLineShift) - 1) >> kHintLineShift;
+  const int stride = (A.nnz + kHintSamples - 1) / kHintSamples;
+  const int samples = (A.nnz + stride - 1) / stride;
+  unsigned *counts = nullptr, *hist_lines = nullptr;
+  unsigned long long *hist_hits = nullptr;
+  std::vector<unsigned> h_lines(kHintBins);
+  std::vector<unsigned long long> h_hits(kHintBins);
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&counts), sizeof(unsigned) * static_cast<size_t>(nlines)), "hipMalloc hint census") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&hist_lines), sizeof(unsigned) * kHintBins), "hipMalloc hint histogram") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&hist_hits), sizeof(unsigned long long) * kHintBins), "hipMalloc hint histogram") &&
+            hip_ok(hipMemsetAsync(counts, 0, sizeof(unsigned) * static_cast<size_t>(nlines), st), "memset hint census") &&
+            hip_ok(hipMemsetAsync(hist_lines, 0, sizeof(unsigned) * kHintBins, st), "memset hint histogram") &&
+            hip_ok(hipMemsetAsync(hist_hits, 0, sizeof(unsigned long long) * kHintBins, st), "memset hint histogram");
+  if (ok) {
+    launch_hint_census(st, A.ci, A.nnz, A.n, stride, samples, counts);
+    launch_hint_hist(st, counts, nlines, hist_lines, hist_hits);
+    ok = hip_ok(hipMemcpyAsync(h_lines.data(), hist_lines, sizeof(unsigned) * kHintBins, hipMemcpyDeviceToHost, st), "read hint histogram") &&
+         hip_ok(hipMemcpyAsync(h_hits.data(), hist_hits, sizeof(unsigned long long) * kHintBins, hipMemcpyDeviceToHost, st), "read hint histogram") &&
+         hip_ok(hipStreamSynchronize(st), "sync hint census");
+  }
+  if (ok) {
+    // hot set = the lines with the highest counts that fit the budget; T = the smallest count still inside it
+    const long long budget_lines = static_cast<long long>(tun(kT_hint_budget_kb) > 0 ? tun(kT_hint_budget_kb) : 1) * 1024 / (8 << kHintLineShift);
+    unsigned long long total = 0, hot = 0;
+    long long lines = 0, touched = 0;
+    for (int b = 1; b < kHintBins; ++b) {
+      total += h_hits[b];
+      touched += h_lines[b];
+    }
+    unsigned threshold = kHintBins; // nothing hot
+    for (int b = kHintBins - 1; b >= 1; --b) {
+      if (lines + h_lines[b] > budget_lines) break;
+      lines += h_lines[b];
+      hot += h_hits[b];
+      threshold = static_cast<unsigned>(b);
+    }
+    p.hint_hot_share = total ? static_cast<double>(hot) / static_cast<double>(total) : 0.0;
+    // worth a timed look: the hot set takes a real share of the gathers, is a small part of the lines the matrix touches (else
+    // everything is hot and nothing needs protecting), and enough cold gathers exist to do the displacing
+    const bool candidate = lines > 0 && p.hint_hot_share >= 0.10 && p.hint_hot_share <= 0.95 && touched >= 4 * lines;
+    tune_log("m %d nnz %d column census: %d samples, %lld of %lld touched x lines hot (count >= %u), %.1f %% of the gathers%s", A.m, A.nnz,
+             samples, lines, touched, threshold, 100.0 * p.hint_hot_share, candidate || mode > 0 ? "" : " -> no hints");
+    if (candidate || mode > 0) {
+      const size_t nbytes = (static_cast<size_t>(A.nnz) + 7) / 8 + 16;
+      ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_cold), nbytes), "hipMalloc hint bits") &&
+           hip_ok(hipMemsetAsync(p.d_cold, 0, nbytes, st), "memset hint bits");
+      if (ok) {
+        launch_hint_bits(st, A.ci, A.nnz, A.n, counts, threshold, p.d_cold);
+        ok = hip_ok(hipStreamSynchronize(st), "sync hint bits");
+      }
+      if (ok) p.hint_state = 1;
+      else if (p.d_cold) {
+        (void)hipFree(p.d_cold);
+        p.d_cold = nullptr;
+      }
+    }
+  }
+  if (counts) (void)hipFree(counts);
+  if (hist_lines) (void)hipFree(hist_lines);
+  if (hist_hits) (void)hipFree(hist_hits);
+  return ok;
+}
+
+// Hints for kernel family `fam`: forced by the tunable, else timed once per matrix (with / without) and kept if they win by > 2 %.
+// `launch(ys)` launches the family's kernel with the plan's current settings writing to ys; p.A.cold selects the hinted variant.
+template <class Launch> bool autotune_hint(Plan &p, int fam, hipStream_t st, Launch launch) {
+  p.A.cold = nullptr;
+  const int mode = tun(kT_gather_hint);
+  if (mode == 0) return true;
+  if (p.hint_state < 0 || (mode < 0 && p.hint_state == 1 && p.hint_use[fam] < 0)) { // census / timing ahead: not inside a capture
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return true;
+  }
+  if (!ensure_hint(p, st)) return false;
+  if (p.hint_state != 1) return true;
+  if (mode > 0) {
+    p.A.cold = p.d_cold;
+    return true;
+  }
+  if (p.hint_use[fam] < 0) {
+    ++t_plan_work;
+    double *scratch = nullptr;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y")) return false;
+    TuneTimer timer;
+    bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
+    float ms[2] = {0.f, 0.f};
+    for (int h = 0; ok && h < 2; ++h) {
+      p.A.cold = h ? p.d_cold : nullptr;
+      ok = timer.time(st, [&] { launch(scratch); }, &ms[h]);
+    }
+    (void)hipFree(scratch);
+    p.A.cold = nullptr;
+    if (!ok) return false;
+    p.hint_use[fam] = ms[1] < 0.98f * ms[0] ? 1 : 0;
+    tune_log("m %d nnz %d family %d gather hints: plain %.2f us, hinted %.2f us -> %s", p.A.m, p.A.nnz, fam, ms[0] * 1e3f, ms[1] * 1e3f,
+             p.hint_use[fam] ? "hinted" : "plain");
+  }
+  p.A.cold = p.hint_use[fam] == 1 ? p.d_cold : nullptr;
+  return true;
+}
+
 bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y,
                   bool allow_uneven_switch);
 
@@ -1135,6 +1262,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
     // such tiles has no row-block imbalance of the hub-row kind)
     if (!(tun(kT_rescue_flat) && p.rowblock_ok == 0)) return run_rowblock(st, p, nullptr, alpha, beta, x, y, false);
   }
+  p.A.cold = nullptr; // (the plan-time timings below run without gather hints)
   p.flat.col16 = nullptr;
   if (tun(kT_col16) > 0) {
     if (!ensure_col16(p, st)) return false;
@@ -1143,6 +1271,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
   if (!autotune_policy(p, kFamFlat, st, [&](int pol, double *ys) { launch_flat_with(st, p, pol, 1.0, trial_beta(), x, ys); })) return false;
   if (!autotune_flat_mode(p, st, x)) return false;
   if (!autotune_flat_geometry(p, st, x)) return false;
+  if (!autotune_hint(p, kFamFlat, st, [&](double *ys) { launch_flat_with(st, p, policy_for(p, kFamFlat), 1.0, trial_beta(), x, ys); })) return false;
   launch_flat_with(st, p, policy_for(p, kFamFlat), alpha, beta, x, y);
   return true;
 }
@@ -1329,7 +1458,13 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
 }
 
 bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y) {
+  p.A.cold = nullptr; // (the prepare timings run without hints)
   if (!run_plus_prepare(p, h_rowptr, st, x)) return false;
+  if (!autotune_hint(p, kFamPlus, st, [&](double *ys) {
+        launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk_tiles), policy_for(p, kFamPlus),
+                    p.d_ppartial, 1.0, trial_beta(), x, ys, next_reverse(p));
+      }))
+    return false;
   launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk_tiles),
               policy_for(p, kFamPlus), p.d_ppartial, alpha, beta, x, y, next_reverse(p));
   return true;

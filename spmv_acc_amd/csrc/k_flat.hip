@@ -70,7 +70,8 @@ struct Col16Dev {
 // are flagged in LDS, every lane scans its NPT consecutive products in place (restarting at a flag), the lanes' open sums cross
 // by a segmented scan over the 256 lanes (shuffles inside a wave, LDS across the four waves), and a row's sum is the scanned
 // value at its last product.  No lane-group width, no dependence on the tile's row-length mix; one lane per row afterwards.
-template <int NPT, bool NTC, bool NTV, bool EARLY, bool C16 = false, bool SEGSUM = false>
+// HINT: gather hints (k_hint.hip): the tile's gathers take their cache policy from the plan's cold bits.
+template <int NPT, bool NTC, bool NTV, bool EARLY, bool C16 = false, bool SEGSUM = false, bool HINT = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY || NPT > 8 ? 1 : 7, 8))) void flat_tile_kernel(int m, int nnz, int ntiles, double alpha, double beta,
                                                              const int *__restrict__ rp, const int *__restrict__ bp,
                                                              const int *__restrict__ ci,
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
                                                              int xcd_chunk, int reach,
                                                              const int *__restrict__ guard, int *__restrict__ stale,
                                                              Col16Dev c16, int reverse, int cache_ends,
-                                                             const int4v *__restrict__ dig) {
+                                                             const int4v *__restrict__ dig, const unsigned char *__restrict__ cold) {
   check_plan_guard(rp, m, guard, stale);
   // reach: a tile finishes its last row itself when it ends at most `reach` (0 or kFlatFinish) non-zeros past the tile
   constexpr int STRIDE = kThreads * NPT;
@@ -161,8 +162,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
     stage_products_col16<kThreads, NPT, NTV>(lds, t0, t1, c16.d16, c16.base, c16.esc_start, c16.esc_cols, v, x);
   else if (EARLY && early) stage_finish<kThreads, EARLY ? NPT : 4>(lds, early_regs, x);
   else if (NTC && NTV && cache_ends > 0 && (t < cache_ends || t >= ntiles - cache_ends)) // (k_rowblock.hip: cacheable grid ends)
-    stage_products<kThreads, NPT, false, false>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
-  else stage_products<kThreads, NPT, NTC, NTV>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0);
+    stage_products<kThreads, NPT, false, false, HINT>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0, cold);
+  else stage_products<kThreads, NPT, NTC, NTV, HINT>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0, cold);
 
   double fin_extra = 0.0; // this lane's share of the overhang (first wave, finish mode)
   if (fin) {
@@ -378,11 +379,11 @@ void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P,
   if (P.early_stream)
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest));
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
   else
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest));
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
 }
 // the segmented-scan reduction (reference option FLAT_SEGMENT_SUM_REDUCE): 2048-non-zero tiles, values / colindex under the plan's policy
 template <bool NTC, bool NTV>
@@ -392,7 +393,16 @@ void launch_flat_segsum(hipStream_t stream, const CsrDev &A, const FlatPlan &P, 
   hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
                      P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
-                     static_cast<const int4v *>(P.digest));
+                     static_cast<const int4v *>(P.digest), nullptr);
+}
+// gather hints: 2048-non-zero tiles, break-point chain first
+template <bool NTC, bool NTV>
+void launch_flat_hint(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x, double *y) {
+  const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
+                     A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
+                     static_cast<const int4v *>(P.digest), A.cold);
 }
 // opt-in 16-bit columns: NPT 8 tiles (a multiple of the 256-non-zero chunk), values under the plan's cache policy
 template <bool NTV>
@@ -401,7 +411,7 @@ void launch_flat_col16(hipStream_t stream, const CsrDev &A, const FlatPlan &P, d
   const Col16Dev c = {P.col16->d16, P.col16->base, P.col16->esc_start, P.col16->esc_cols};
   hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, true, NTV, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
-                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, c, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest));
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, c, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
 }
 template <int NPT>
 void launch_flat_policy(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
@@ -437,6 +447,13 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
     case 2: launch_flat_segsum<false, true>(stream, A, P, alpha, beta, x, y); break;
     case 3: launch_flat_segsum<true, false>(stream, A, P, alpha, beta, x, y); break;
     default: launch_flat_segsum<true, true>(stream, A, P, alpha, beta, x, y); break;
+    }
+  } else if (A.cold != nullptr && !P.col16 && !P.early_stream && npt == kNnzPerThread) {
+    switch (P.stream_policy & 3) {
+    case 1: launch_flat_hint<false, false>(stream, A, P, alpha, beta, x, y); break;
+    case 2: launch_flat_hint<false, true>(stream, A, P, alpha, beta, x, y); break;
+    case 3: launch_flat_hint<true, false>(stream, A, P, alpha, beta, x, y); break;
+    default: launch_flat_hint<true, true>(stream, A, P, alpha, beta, x, y); break;
     }
   } else if (P.col16 && npt == kNnzPerThread) {
     // values default for policies 1 (both default) and 3 (values default), non-temporal otherwise

@@ -68,13 +68,14 @@ __global__ __launch_bounds__(256) void plus_digest_kernel(int m, int nblocks, in
   blk[g] = rec;
 }
 
-template <bool NTC, bool NTV>
+template <bool NTC, bool NTV, bool HINT>
 __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, int xcd_chunk, double alpha, double beta,
                                                         const int4v *__restrict__ blk, const int *__restrict__ rp,
                                                         const int *__restrict__ ci, const double *__restrict__ v,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         double *__restrict__ partial, int m,
-                                                        const int *__restrict__ guard, int *__restrict__ stale, int reverse) {
+                                                        const int *__restrict__ guard, int *__restrict__ stale, int reverse,
+                                                        const unsigned char *__restrict__ cold) {
   check_plan_guard(rp, m, guard, stale);
   __shared__ __attribute__((aligned(16))) double lds[kPlusTile]; // written 16 B at a time
   __shared__ double row_acc[kPlusMaxRows];
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
     }
     double acc = 0.0;
     for (int off = a0; off < s1; off += kPlusTile) {
-      stage_products<kThreads, kPlusNpt, NTC, NTV>(lds, off, s1, nnz, ci, v, x);
+      stage_products<kThreads, kPlusNpt, NTC, NTV, HINT>(lds, off, s1, nnz, ci, v, x, true, cold);
       __syncthreads();
       const int lo = (r0 > off ? r0 : off) - off;
       const int hi = (r1 < off + kPlusTile ? r1 : off + kPlusTile) - off;
@@ -122,12 +123,22 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
       // issued back to back; the slice start is aligned down to a multiple of 4 and the (at most 3 + 3) foreign elements
       // at its ends are masked out of the sum.  (One 4-/8-byte load per lane per step ran a matrix made of long rows only
       // at 4.9 TB/s against 6.0-6.4 for the tile kernels.)
+      const XGather xr = make_xgather(x, HINT);
       for (int base = (j0 & ~3) + 4 * static_cast<int>(threadIdx.x); base < j1; base += 4 * kThreads) {
         if (base + 4 <= nnz) {
           const int4v c = load_stream_i4<NTC>(ci + base);
           const double2v a0 = load_stream_d2<NTV>(v + base);
           const double2v a1 = load_stream_d2<NTV>(v + base + 2);
-          const double p0 = a0.x * x[c.x], p1 = a0.y * x[c.y], p2 = a1.x * x[c.z], p3 = a1.y * x[c.w];
+          double p0, p1, p2, p3;
+          if (HINT) {
+            const unsigned nib = static_cast<unsigned>(cold[base >> 3]) >> (base & 4);
+            p0 = a0.x * gather_hinted(xr, c.x, nib & 1u);
+            p1 = a0.y * gather_hinted(xr, c.y, nib & 2u);
+            p2 = a1.x * gather_hinted(xr, c.z, nib & 4u);
+            p3 = a1.y * gather_hinted(xr, c.w, nib & 8u);
+          } else {
+            p0 = a0.x * x[c.x], p1 = a0.y * x[c.y], p2 = a1.x * x[c.z], p3 = a1.y * x[c.w];
+          }
           s += (base + 0 >= j0 && base + 0 < j1) ? p0 : 0.0;
           s += (base + 1 >= j0 && base + 1 < j1) ? p1 : 0.0;
           s += (base + 2 >= j0 && base + 2 < j1) ? p2 : 0.0;
@@ -193,14 +204,24 @@ void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *
                  bool has_long_rows, int xcd_chunk, int stream_policy, double *partial, double alpha, double beta,
                  const double *x, double *y, bool reverse) {
   if (nblocks <= 0) return;
-#define SPMV_ACC_LAUNCH_PLUS(NC, NV)                                                                                \
-  hipLaunchKernelGGL((plus_kernel<NC, NV>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk,   \
-                     alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial, A.m, A.guard, A.stale, reverse ? 1 : 0)
-  switch (stream_policy & 3) {
-  case 1: SPMV_ACC_LAUNCH_PLUS(false, false); break;
-  case 2: SPMV_ACC_LAUNCH_PLUS(false, true); break;
-  case 3: SPMV_ACC_LAUNCH_PLUS(true, false); break;
-  default: SPMV_ACC_LAUNCH_PLUS(true, true); break;
+#define SPMV_ACC_LAUNCH_PLUS(NC, NV, H)                                                                             \
+  hipLaunchKernelGGL((plus_kernel<NC, NV, H>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk, \
+                     alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial, A.m, A.guard, A.stale, reverse ? 1 : 0, \
+                     A.cold)
+  if (A.cold != nullptr) { // gather hints (kernels.hpp): cold gathers non-temporal
+    switch (stream_policy & 3) {
+    case 1: SPMV_ACC_LAUNCH_PLUS(false, false, true); break;
+    case 2: SPMV_ACC_LAUNCH_PLUS(false, true, true); break;
+    case 3: SPMV_ACC_LAUNCH_PLUS(true, false, true); break;
+    default: SPMV_ACC_LAUNCH_PLUS(true, true, true); break;
+    }
+  } else {
+    switch (stream_policy & 3) {
+    case 1: SPMV_ACC_LAUNCH_PLUS(false, false, false); break;
+    case 2: SPMV_ACC_LAUNCH_PLUS(false, true, false); break;
+    case 3: SPMV_ACC_LAUNCH_PLUS(true, false, false); break;
+    default: SPMV_ACC_LAUNCH_PLUS(true, true, false); break;
+    }
   }
 #undef SPMV_ACC_LAUNCH_PLUS
   if (has_long_rows) {

@@ -21,6 +21,10 @@ struct CsrDev {
   // the flag when the matrix behind these pointers is no longer the one the plan was built for.  Null: no check.
   const int *guard = nullptr;
   int *stale = nullptr;
+  // Gather hints (engine.cpp ensure_hint, k_hint.hip): one bit per non-zero, set where the non-zero's x line is NOT among the
+  // hot lines that fit an L2; kernels that take hints issue those gathers non-temporal.  Null: no hints (set per launch by the
+  // engine: only while the plan's timed comparison says they pay, and only where x is below 4 GB).  Speed only.
+  const unsigned char *cold = nullptr;
 };
 constexpr int kGuardSamples = 64; // rowptr[k * m / 63], k = 0 .. 63 (includes rowptr[0] and rowptr[m] = nnz)
 void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard);
@@ -95,6 +99,14 @@ struct Col16 {
   int *esc_cols = nullptr;       // the escaped columns in non-zero order
   int escapes = 0;
 };
+// gather hints (k_hint.hip)
+constexpr int kHintLineShift = 4;       // an x line = 16 columns = 128 B (the L2 line)
+constexpr int kHintBins = 4096;         // census histogram: lines / sampled hits per count value, last bin open-ended
+constexpr int kHintSamples = 8 << 20;   // non-zeros sampled by the census (all of them below this)
+void launch_hint_census(hipStream_t stream, const int *ci, int nnz, int ncols, int stride, int samples, unsigned *counts);
+void launch_hint_hist(hipStream_t stream, const unsigned *counts, int nlines, unsigned *hist_lines, unsigned long long *hist_hits);
+void launch_hint_bits(hipStream_t stream, const int *ci, int nnz, int ncols, const unsigned *counts, unsigned threshold, unsigned char *bits);
+
 size_t col16_scan_bytes(int nchunks);
 void launch_col16_base(hipStream_t stream, const int *ci, int nnz, int nchunks, int *base, int *esc_count);
 bool launch_col16_scan(hipStream_t stream, int nchunks, const int *esc_count, int *esc_start, void *tmp, size_t tmp_bytes);

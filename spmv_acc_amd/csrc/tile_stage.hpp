@@ -20,10 +20,16 @@ namespace dev {
 //   nnz : total non-zeros (array length) -- only the last, ragged group of the arrays takes the scalar path
 // Slots of lds whose non-zero index is < a-block's-first-nnz or >= hi hold unspecified values; no
 // reader touches them.
-template <int THREADS, int NPT, bool NTC = true, bool NTV = true>
+//
+// HINT (gather hints, engine.cpp ensure_hint): `cold` holds one bit per non-zero, set where the plan's column census found the
+// x line of that non-zero outside the set of hot lines that fit an L2.  Cold gathers are issued non-temporal, so the lines they
+// bring do not displace the hot ones (skewed_gather_bench.hip: 66 -> 74-76 G gathers/s on R-MAT columns; non-temporal for ALL
+// gathers: 43).  The bits only steer the cache policy: stale or arbitrary bits cannot change a sum.
+template <int THREADS, int NPT, bool NTC = true, bool NTV = true, bool HINT = false>
 __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0, int hi, int nnz,
                                                const int *__restrict__ ci, const double *__restrict__ v,
-                                               const double *__restrict__ x, bool allow_fast = true) {
+                                               const double *__restrict__ x, bool allow_fast = true,
+                                               const unsigned char *__restrict__ cold = nullptr) {
   static_assert(NPT % 4 == 0, "NPT must be a multiple of 4");
   constexpr int K = NPT / 4;
   // Branch-free form (wave-uniform test): a0 is a multiple of 4, so the last 4-group that starts below `hi` ends at
@@ -37,6 +43,7 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
   if (allow_fast && ((hi + 3) & ~3) <= nnz) {
     int4v c[K];
     double2v va[K], vb[K];
+    unsigned nib[K]; // HINT: the cold bits of this lane's four non-zeros
     bool wave_has[K]; // wave-uniform: does any lane of this wave have a group below hi in step k?
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -48,16 +55,25 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
         c[k] = load_stream_i4<NTC>(ci + jc);
         va[k] = load_stream_d2<NTV>(v + jc);
         vb[k] = load_stream_d2<NTV>(v + jc + 2);
+        if (HINT) nib[k] = static_cast<unsigned>(cold[jc >> 3]) >> (jc & 4); // (jc is a multiple of 4; a wave reads 32 consecutive bytes)
       }
     }
     double xg[K][4];
+    const XGather xr = make_xgather(x, HINT);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (wave_has[k]) {
-        xg[k][0] = x[c[k].x];
-        xg[k][1] = x[c[k].y];
-        xg[k][2] = x[c[k].z];
-        xg[k][3] = x[c[k].w];
+        if (HINT) {
+          xg[k][0] = gather_hinted(xr, c[k].x, nib[k] & 1u);
+          xg[k][1] = gather_hinted(xr, c[k].y, nib[k] & 2u);
+          xg[k][2] = gather_hinted(xr, c[k].z, nib[k] & 4u);
+          xg[k][3] = gather_hinted(xr, c[k].w, nib[k] & 8u);
+        } else {
+          xg[k][0] = x[c[k].x];
+          xg[k][1] = x[c[k].y];
+          xg[k][2] = x[c[k].z];
+          xg[k][3] = x[c[k].w];
+        }
       }
     }
 #pragma unroll

@@ -694,7 +694,12 @@ def test_measurement_switches_keep_parity(torch_dev, oracle, hiplib):
                 ("flat", {"cache_ends_mb": 1, "stream_plain": 0}), ("flat", {"cache_ends_mb": 4000, "stream_plain": 0}),
                 # the segmented-scan reduction of a flat tile (the reference's FLAT_SEGMENT_SUM_REDUCE)
                 ("flat", {"flat_reduce": 1}), ("flat", {"flat_reduce": 1, "flat_finish": 0}), ("flat", {"flat_reduce": 1, "flat_finish": 1, "stream_plain": 1}),
-                ("flat", {"flat_reduce": 1, "flat_npt": 4}), ("flat", {"flat_reduce": 1, "stage_fast": 0})]
+                ("flat", {"flat_reduce": 1, "flat_npt": 4}), ("flat", {"flat_reduce": 1, "stage_fast": 0}),
+                # gather hints (cold gathers non-temporal): forced on, tiny and huge hot sets
+                ("adaptive_plus", {"gather_hint": 1}), ("adaptive_plus", {"gather_hint": 1, "hint_budget_kb": 1}),
+                ("adaptive_plus", {"gather_hint": 1, "hint_budget_kb": 100000}), ("flat", {"gather_hint": 1, "flat_npt": 8, "flat_early": 0}),
+                ("flat", {"gather_hint": 1, "hint_budget_kb": 8, "flat_npt": 8, "flat_early": 0, "flat_finish": 0}),
+                ("adaptive", {"gather_hint": 1, "hint_budget_kb": 16})]
     try:
         for strat, knobs in variants:
             hiplib.spmv_acc_reset_tunables()

@@ -481,3 +481,48 @@ def test_flat_segmented_scan_reduction(torch_dev, oracle, hiplib):
             spmv_acc_amd.release_plans(drp)
     finally:
         hiplib.spmv_acc_reset_tunables()
+
+
+def test_gather_hints_change_no_bit(torch_dev, oracle, hiplib):
+    """Gather hints (k_hint.hip: the plan's column census marks the non-zeros whose x line lies outside the hot set, and the row-block-plus /
+    flat kernels gather those non-temporally) steer a cache policy only: with hints forced on, y is bit-identical to the plain kernels' and
+    matches the oracle -- on power-law columns with hub rows (the long-row slices of row-block-plus), for hot sets from one line to
+    everything, for nnz that is no multiple of 8, and for the automatic mode (census + timed choice) on a matrix too small to want them."""
+    torch = torch_dev
+    rng = np.random.default_rng(909)
+    m, n = 30011, 200000
+    lens = np.minimum(rng.zipf(1.7, size=m), 9000)
+    lens[5] = 25000                                   # a hub row: several dedicated long-row blocks
+    rowptr = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(lens, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    cols = np.minimum((rng.pareto(0.9, size=nnz) * 40).astype(np.int64), n - 1).astype(np.int32)   # a few hot columns, a long cold tail
+    vals = rng.uniform(-1.0, 1.0, size=nnz)
+    rowptr = rowptr.astype(np.int32)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+    ref = oracle.host_spmv(0.5, -2.0, rowptr, cols, vals, x, y0)
+    try:
+        # (the plans' other timed choices -- block size, cut-row form -- are pinned: they regroup sums, and a fresh plan may time them differently)
+        for strat, base in (("adaptive_plus", {"plus_min_nnz": 1024}), ("adaptive_plus", {"plus_min_nnz": 1920}),
+                            ("flat", {"flat_npt": 8, "flat_early": 0, "flat_finish": 1}), ("flat", {"flat_npt": 8, "flat_early": 0, "flat_finish": 0})):
+            outs = {}
+            for tag, knobs in (("plain", {"gather_hint": 0}), ("one_line", {"gather_hint": 1, "hint_budget_kb": 1}),
+                               ("l2", {"gather_hint": 1, "hint_budget_kb": 64}), ("all", {"gather_hint": 1, "hint_budget_kb": 1 << 20}),
+                               ("auto", {"gather_hint": -1})):
+                hiplib.spmv_acc_reset_tunables()
+                for k, val in {**base, **knobs}.items():
+                    assert hiplib.spmv_acc_set_tunable(k.encode(), val) == 0, k
+                spmv_acc_amd.release_plans(drp)
+                for _ in range(2):  # both walking directions
+                    dy = dev(torch, y0)
+                    spmv_acc_amd.csr_spmv(0.5, -2.0, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat)
+                    torch.cuda.synchronize()
+                    got = dy.cpu().numpy()
+                    assert oracle.scaled_error(got, ref, 0.5, -2.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, (strat, tag)
+                outs[tag] = got
+            for tag, got in outs.items():
+                assert np.array_equal(got, outs["plain"]), (strat, base, tag)
+    finally:
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans(drp)

@@ -10,12 +10,16 @@ from spmv_acc_amd import synth
 lib = spmv_acc_amd.load_library()
 strat, names, variants = sys.argv[1], sys.argv[2].split(","), sys.argv[3].split(";")
 for name in names:
-    m, n, nnz, rp, ci, v = synth.sweep_standin_torch(name)
+    if name.startswith("rmat"):  # rmat25 = BASELINE configs[3]
+        m, n, nnz, rp, ci, v = synth.rmat_torch(int(name[4:]), device="cuda", seed=0xC4)
+    else:
+        m, n, nnz, rp, ci, v = synth.sweep_standin_torch(name)
     x = torch.rand(n, device="cuda", dtype=torch.float64)
     y = torch.zeros(m, device="cuda", dtype=torch.float64)
     torch.cuda.synchronize()
-    iters = 200 if nnz < 20_000_000 else 80
+    iters = 200 if nnz < 20_000_000 else (80 if nnz < 200_000_000 else 20)
     out = []
+    first_y = {}
     for rnd in range(2):
         for var in variants:
             lib.spmv_acc_reset_tunables()
@@ -27,6 +31,15 @@ for name in names:
                 spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
             t = spmv_acc_amd.time_spmv_total(strat, iters, 1.0, 1.0, m, n, nnz, rp, ci, v, x, y) / iters * 1e3
             out.append((rnd, var, t))
-    print(name, strat, " | ".join(f"[{var or 'default'}] " + " ".join(f"{t:.2f}" for r, v2, t in out if v2 == var) for var in variants), flush=True)
+            if rnd == 0:  # the variants are speed matters only: one SpMV from y = 0 must give the same vector under each
+                y.zero_()
+                spmv_acc_amd.csr_spmv(1.0, 0.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
+                torch.cuda.synchronize()
+                first_y[var] = y.clone()
+                y.zero_()
+    ref = first_y[variants[0]]
+    scale = float(ref.abs().max()) or 1.0
+    worst = max(float((first_y[var] - ref).abs().max()) / scale for var in variants)
+    print(name, strat, f"max difference between variants {worst:.1e} |", " | ".join(f"[{var or 'default'}] " + " ".join(f"{t:.2f}" for r, v2, t in out if v2 == var) for var in variants), flush=True)
     lib.spmv_acc_reset_tunables()
     spmv_acc_amd.release_plans(rp)
