@@ -46,10 +46,10 @@ __device__ __forceinline__ void issue_gather(double &r, const double *p, int col
 
 // The same without hand-written loads: buffer loads, whose cache policy is an immediate operand of the builtin -- two calls that differ in
 // it cannot be folded into one, and the compiler does the waiting itself.  (32-bit byte offsets: x below 4 GB.)
-__device__ __forceinline__ double gather_buffer(__amdgpu_buffer_rsrc_t rsrc, int col, bool cold) {
+template <int AUX> __device__ __forceinline__ double gather_buffer(__amdgpu_buffer_rsrc_t rsrc, int col, bool cold) {
   typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
   uint2v r;
-  if (cold) r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, col * 8, 0, 2); // aux 2 = nt
+  if (cold) r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, col * 8, 0, AUX); // aux: 1 sc0, 2 nt, 16 sc1 (gfx940 cache-policy bits)
   else r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, col * 8, 0, 0);
   return __hiloint2double(static_cast<int>(r.y), static_cast<int>(r.x));
 }
@@ -73,12 +73,13 @@ template <int MODE> __global__ __launch_bounds__(256) void k(const int *idx, con
   if (MODE == 0) {
     if (fa) s += va0.x * x[a.x] + va0.y * x[a.y] + va1.x * x[a.z] + va1.y * x[a.w];
     if (fb) s += vb0.x * x[b.x] + vb0.y * x[b.y] + vb1.x * x[b.z] + vb1.y * x[b.w];
-  } else if (MODE == 6) {
+  } else if (MODE >= 6) {
+    constexpr int AUX = MODE == 6 ? 2 : MODE == 7 ? 1 : MODE == 8 ? 16 : MODE == 9 ? 17 : MODE == 10 ? 18 : 19;
     const int c[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     double g[8];
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = gather_buffer(rsrc, c[e], __popc(c[e]) > 6);
+    for (int e = 0; e < 8; ++e) g[e] = gather_buffer<AUX>(rsrc, c[e], __popc(c[e]) > 6);
     s += va0.x * g[0] + va0.y * g[1] + va1.x * g[2] + va1.y * g[3] + vb0.x * g[4] + vb0.y * g[5] + vb1.x * g[6] + vb1.y * g[7];
   } else {
     // (out-of-range lanes gather x[0]: valid, and weighted by 0)
@@ -105,9 +106,9 @@ int main(int argc, char **argv) {
   const long long n4 = n / 4;
   const int grid = static_cast<int>((n4 + 511) / 512);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const char *names[7] = {"plain", "nt (all gathers)", "nt where popcount > 5", "nt where popcount > 6", "nt where popcount > 7", "nt where popcount > 8", "popcount > 6, compiler loads"};
+  const char *names[12] = {"plain", "nt (all gathers)", "nt where popcount > 5", "nt where popcount > 6", "nt where popcount > 7", "nt where popcount > 8", "popcount > 6, buffer loads nt", "popcount > 6: sc0", "popcount > 6: sc1", "popcount > 6: sc0 sc1", "popcount > 6: nt sc1", "popcount > 6: nt sc0 sc1"};
   for (int round = 0; round < 2; ++round)
-    for (int mode = 0; mode < 7; ++mode) {
+    for (int mode = 0; mode < 12; ++mode) {
       float best = 1e30f;
       for (int r = 0; r < 4; ++r) {
         hipEventRecord(e0);
@@ -118,10 +119,15 @@ int main(int argc, char **argv) {
         if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(grid), dim3(256), 0, 0, d_idx, d_val, n4, d_x, d_out);
         if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(grid), dim3(256), 0, 0, d_idx, d_val, n4, d_x, d_out);
         if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(grid), dim3(256), 0, 0, d_idx, d_val, n4, d_x, d_out);
+        if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(grid), dim3(256), 0, 0, d_idx, d_val, n4, d_x, d_out);
+        if (mode == 8) hipLaunchKernelGGL(k<8>, dim3(grid), dim3(256), 0, 0, d_idx, d_val, n4, d_x, d_out);
+        if (mode == 9) hipLaunchKernelGGL(k<9>, dim3(grid), dim3(256), 0, 0, d_idx, d_val, n4, d_x, d_out);
+        if (mode == 10) hipLaunchKernelGGL(k<10>, dim3(grid), dim3(256), 0, 0, d_idx, d_val, n4, d_x, d_out);
+        if (mode == 11) hipLaunchKernelGGL(k<11>, dim3(grid), dim3(256), 0, 0, d_idx, d_val, n4, d_x, d_out);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
       }
-      if (round == 1) printf("%lld M skewed gathers + 12 B/gather of stream, %-24s: %8.1f us  %6.1f G gathers/s\n", n / 1000000, names[mode], best * 1e3, n / (best * 1e-3) / 1e9);
+      if (round == 1) printf("%lld M skewed gathers + 12 B/gather of stream, %-30s: %8.1f us  %6.1f G gathers/s\n", n / 1000000, names[mode], best * 1e3, n / (best * 1e-3) / 1e9);
     }
   return 0;
 }
