@@ -49,9 +49,11 @@ for case in range(cases):
     nnz = int(rp[-1].item())
     n = int(rng.choice([m, max(1, m // 7), 3 * m + 5, 1000]))
     rows = torch.repeat_interleave(torch.arange(m, device="cuda"), lens, output_size=nnz)
-    cols_law = rng.choice(["near", "clusters", "uniform"])
+    cols_law = rng.choice(["near", "clusters", "uniform", "powerlaw"])
     if cols_law == "uniform":
         ci = torch.randint(0, n, (nnz,), generator=g, device="cuda")
+    elif cols_law == "powerlaw":  # a few hot columns, a long cold tail (what the plan's column census looks for)
+        ci = (torch.rand(nnz, generator=g, device="cuda", dtype=torch.float64) ** float(rng.choice([3, 6, 12])) * n).long().clamp_(0, n - 1)
     else:
         ci = (rows * n // max(m, 1)) + torch.randint(-40, 41, (nnz,), generator=g, device="cuda")
         if cols_law == "clusters":
