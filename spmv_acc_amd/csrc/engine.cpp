@@ -1146,6 +1146,7 @@ bool ensure_hint(Plan &p, hipStream_t st) {
   if (mode == 0 || A.nnz < 8 || A.n <= 0 || static_cast<long long>(A.n) * 8 >= (1LL << 32)) return true;
   if (mode < 0 && static_cast<long long>(A.n) * 8 < (8LL << 20)) return true;
   ++t_plan_work;
+  const auto census_t0 = std::chrono::steady_clock::now();
   const int nlines = (A.n + (1 << kHintLineShift) - 1) >> kHintLineShift;
   const int stride = (A.nnz + kHintSamples - 1) / kHintSamples;
   const int samples = (A.nnz + stride - 1) / stride;
@@ -1183,11 +1184,14 @@ bool ensure_hint(Plan &p, hipStream_t st) {
       threshold = static_cast<unsigned>(b);
     }
     p.hint_hot_share = total ? static_cast<double>(hot) / static_cast<double>(total) : 0.0;
-    // worth a timed look: the hot set takes a real share of the gathers, is a small part of the lines the matrix touches (else
-    // everything is hot and nothing needs protecting), and enough cold gathers exist to do the displacing
-    const bool candidate = lines > 0 && p.hint_hot_share >= 0.10 && p.hint_hot_share <= 0.95 && touched >= 4 * lines;
-    tune_log("m %d nnz %d column census: %d samples, %lld of %lld touched x lines hot (count >= %u), %.1f %% of the gathers%s", A.m, A.nnz,
-             samples, lines, touched, threshold, 100.0 * p.hint_hot_share, candidate || mode > 0 ? "" : " -> no hints");
+    // worth a timed look (bits pass + two timings): the hot set takes a real share of the gathers, its lines are at least three times
+    // as popular as the average touched line (FEM-like matrices: every line is touched about equally often, ratio ~1; R-MAT 25: 12),
+    // and enough cold gathers exist to do the displacing
+    const bool candidate = lines > 0 && p.hint_hot_share >= 0.15 && p.hint_hot_share <= 0.95 &&
+                           p.hint_hot_share * static_cast<double>(touched) >= 3.0 * static_cast<double>(lines);
+    tune_log("m %d nnz %d column census (%.2f ms): %d samples, %lld of %lld touched x lines hot (count >= %u), %.1f %% of the gathers%s", A.m, A.nnz,
+             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - census_t0).count(), samples, lines, touched, threshold,
+             100.0 * p.hint_hot_share, candidate || mode > 0 ? "" : " -> no hints");
     if (candidate || mode > 0) {
       const size_t nbytes = (static_cast<size_t>(A.nnz) + 7) / 8 + 16;
       ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_cold), nbytes), "hipMalloc hint bits") &&
