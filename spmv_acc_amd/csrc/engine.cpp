@@ -1144,7 +1144,10 @@ bool ensure_hint(Plan &p, hipStream_t st) {
   const CsrDev &A = p.A;
   // hinted gathers address x by 32-bit byte offsets; a matrix whose x fits an L2 several times over has nothing to protect
   if (mode == 0 || A.nnz < 8 || A.n <= 0 || static_cast<long long>(A.n) * 8 >= (1LL << 32)) return true;
-  if (mode < 0 && static_cast<long long>(A.n) * 8 < (8LL << 20)) return true;
+  // (and while x lives in the 256 MB Infinity Cache beside the rest of the working set a cold gather is a hit there, which a non-temporal
+  // load forfeits: R-MAT scale 21 / 22 / 23, x = 16 / 32 / 64 MB: hinted 268 / 604 / 1343 us against 212 / 477 / 1250 plain; scale 24 / 25,
+  // x = 128 / 256 MB: 3.03 / 7.2 ms against 3.38 / 8.2 -- the timed choice gets all five right, this bound just saves the census)
+  if (mode < 0 && static_cast<long long>(A.n) * 8 < (96LL << 20)) return true;
   ++t_plan_work;
   const auto census_t0 = std::chrono::steady_clock::now();
   const int nlines = (A.n + (1 << kHintLineShift) - 1) >> kHintLineShift;
