@@ -1157,10 +1157,22 @@ bool ensure_hint(Plan &p, hipStream_t st) {
   unsigned long long *hist_hits = nullptr;
   std::vector<unsigned> h_lines(kHintBins);
   std::vector<unsigned long long> h_hits(kHintBins);
-  bool ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&counts), sizeof(unsigned) * static_cast<size_t>(nlines)), "hipMalloc hint census") &&
-            hip_ok(hipMalloc(reinterpret_cast<void **>(&hist_lines), sizeof(unsigned) * kHintBins), "hipMalloc hint histogram") &&
-            hip_ok(hipMalloc(reinterpret_cast<void **>(&hist_hits), sizeof(unsigned long long) * kHintBins), "hipMalloc hint histogram") &&
-            hip_ok(hipMemsetAsync(counts, 0, sizeof(unsigned) * static_cast<size_t>(nlines), st), "memset hint census") &&
+  // (hints are optional: a matrix that fills the card leaves no room for them, and that must not fail the SpMV)
+  auto optional_alloc = [](void **ptr, size_t bytes) {
+    if (hipMalloc(ptr, bytes) == hipSuccess) return true;
+    (void)hipGetLastError(); // clear the sticky out-of-memory error
+    *ptr = nullptr;
+    return false;
+  };
+  if (!optional_alloc(reinterpret_cast<void **>(&counts), sizeof(unsigned) * static_cast<size_t>(nlines)) ||
+      !optional_alloc(reinterpret_cast<void **>(&hist_lines), sizeof(unsigned) * kHintBins) ||
+      !optional_alloc(reinterpret_cast<void **>(&hist_hits), sizeof(unsigned long long) * kHintBins)) {
+    if (counts) (void)hipFree(counts);
+    if (hist_lines) (void)hipFree(hist_lines);
+    if (hist_hits) (void)hipFree(hist_hits);
+    return true;
+  }
+  bool ok = hip_ok(hipMemsetAsync(counts, 0, sizeof(unsigned) * static_cast<size_t>(nlines), st), "memset hint census") &&
             hip_ok(hipMemsetAsync(hist_lines, 0, sizeof(unsigned) * kHintBins, st), "memset hint histogram") &&
             hip_ok(hipMemsetAsync(hist_hits, 0, sizeof(unsigned long long) * kHintBins, st), "memset hint histogram");
   if (ok) {
@@ -1197,13 +1209,13 @@ bool ensure_hint(Plan &p, hipStream_t st) {
              100.0 * p.hint_hot_share, candidate || mode > 0 ? "" : " -> no hints");
     if (candidate || mode > 0) {
       const size_t nbytes = (static_cast<size_t>(A.nnz) + 7) / 8 + 16;
-      ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_cold), nbytes), "hipMalloc hint bits") &&
-           hip_ok(hipMemsetAsync(p.d_cold, 0, nbytes, st), "memset hint bits");
-      if (ok) {
+      const bool room = optional_alloc(reinterpret_cast<void **>(&p.d_cold), nbytes);
+      ok = !room || hip_ok(hipMemsetAsync(p.d_cold, 0, nbytes, st), "memset hint bits");
+      if (ok && room) {
         launch_hint_bits(st, A.ci, A.nnz, A.n, counts, threshold, p.d_cold);
         ok = hip_ok(hipStreamSynchronize(st), "sync hint bits");
       }
-      if (ok) p.hint_state = 1;
+      if (ok && room) p.hint_state = 1;
       else if (p.d_cold) {
         (void)hipFree(p.d_cold);
         p.d_cold = nullptr;
