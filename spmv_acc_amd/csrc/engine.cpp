@@ -1422,9 +1422,15 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
   const int chunk = tun(kT_xcd_chunk);
   const int base_flags = (tun(kT_xcd_remap) ? 1 : 0) | (tun(kT_early_y) ? 2 : 0) |
                          (chunk > 0 ? (4 | (chunk << 8)) : 0) | (tun(kT_stage_fast) ? 0 : 8);
+  p.A.cold = nullptr; // (the policy timing runs without gather hints)
   if (!autotune_policy(p, kFamRowblock, st, [&](int pol, double *ys) {
         const int zz = next_reverse(p) ? 64 : 0;
         launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (pol << 4) | zz, 1.0, trial_beta(), x, ys, dg, cache_ends);
+      }))
+    return false;
+  if (!autotune_hint(p, kFamRowblock, st, [&](double *ys) {
+        const int zz = next_reverse(p) ? 64 : 0;
+        launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p, kFamRowblock) << 4) | zz, 1.0, trial_beta(), x, ys, dg, cache_ends);
       }))
     return false;
   const int zz = next_reverse(p) ? 64 : 0;

@@ -44,7 +44,8 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
   return v + (r > 0 ? t0 : 0) + (r > 1 ? t1 : 0) + (r > 2 ? t2 : 0);
 }
 
-template <int VEC, bool NTC, bool NTV, bool LENS>
+// HINT: gather hints (k_hint.hip): the block's gathers take their cache policy from the plan's cold bits.
+template <int VEC, bool NTC, bool NTV, bool LENS, bool HINT = false>
 __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nnz, int nblocks, int rpb, int flags,
                                                                    double alpha, double beta,
                                                                    const int *__restrict__ rp,
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
                                                                    const int *__restrict__ guard,
                                                                    int *__restrict__ stale,
                                                                    const unsigned char *__restrict__ lens,
-                                                                   const int *__restrict__ base, int cache_ends) {
+                                                                   const int *__restrict__ base, int cache_ends,
+                                                                   const unsigned char *__restrict__ cold) {
   check_plan_guard(rp, m, guard, stale);
   __shared__ int wave_tot[kThreads / kWave];
   // rpb rows per workgroup, rpb <= kThreads / VEC (not necessarily a power of two: it is chosen so that
@@ -114,9 +116,9 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
     // blocks the next SpMV starts with (Hardesty3-sized 155.0 -> 152.9 us; 8 / 16 / 24 / 32 / 48 / 100 MB: 153.5 / 152.9 / 152.9 /
     // 152.9 / 153.3 / 155.1).
     if (NTC && NTV && cache_ends > 0 && (b < cache_ends || b >= nblocks - cache_ends))
-      stage_products<kThreads, kNnzPerThread, false, false>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0);
+      stage_products<kThreads, kNnzPerThread, false, false, HINT>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0, cold);
     else
-      stage_products<kThreads, kNnzPerThread, NTC, NTV>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0);
+      stage_products<kThreads, kNnzPerThread, NTC, NTV, HINT>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0, cold);
     __syncthreads();
     if (LENS && from_lens && off == (s0 & ~3)) {
       const int w = threadIdx.x / kWave;
@@ -196,16 +198,20 @@ void launch_vec(hipStream_t stream, const CsrDev &A, const RowDigest *D, int rpb
   const int remap = ((xcd & 1) && nblocks >= 64 ? 1 : 0) | (xcd & ~1);
   // bits 4-5 of the flags: cache policy of the stream loads (0 nt/nt, 1 plain/plain, 2 colindex plain + values nt,
   // 3 colindex nt + values plain)
+#define SPMV_ACC_LAUNCH_RB_H(NC, NV, LN, H)                                                                         \
+  hipLaunchKernelGGL((rowblock_stream_kernel<VEC, NC, NV, LN, H>), dim3(nblocks), dim3(kThreads), 0, stream, A.m,   \
+                     A.nnz, nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y, A.guard, A.stale,             \
+                     LN ? D->lens : static_cast<const unsigned char *>(nullptr),                                   \
+                     LN ? D->base : static_cast<const int *>(nullptr), cache_ends, A.cold)
 #define SPMV_ACC_LAUNCH_RB(NC, NV)                                                                                  \
   do {                                                                                                             \
-    if (D && D->lens)                                                                                              \
-      hipLaunchKernelGGL((rowblock_stream_kernel<VEC, NC, NV, true>), dim3(nblocks), dim3(kThreads), 0, stream,     \
-                         A.m, A.nnz, nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y, A.guard, A.stale,    \
-                         D->lens, D->base, cache_ends);                                                            \
-    else                                                                                                           \
-      hipLaunchKernelGGL((rowblock_stream_kernel<VEC, NC, NV, false>), dim3(nblocks), dim3(kThreads), 0, stream,    \
-                         A.m, A.nnz, nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y, A.guard, A.stale,    \
-                         static_cast<const unsigned char *>(nullptr), static_cast<const int *>(nullptr), cache_ends); \
+    if (D && D->lens) {                                                                                            \
+      if (A.cold) SPMV_ACC_LAUNCH_RB_H(NC, NV, true, true);                                                        \
+      else SPMV_ACC_LAUNCH_RB_H(NC, NV, true, false);                                                              \
+    } else {                                                                                                       \
+      if (A.cold) SPMV_ACC_LAUNCH_RB_H(NC, NV, false, true);                                                       \
+      else SPMV_ACC_LAUNCH_RB_H(NC, NV, false, false);                                                             \
+    }                                                                                                              \
   } while (0)
   // one set of kernels for every base-pointer alignment: their 16-B loads go through under-aligned vector types
   // (device_utils.hpp), the same instruction with the same cache policy whether or not the caller's arrays are 16-B aligned
@@ -216,6 +222,7 @@ void launch_vec(hipStream_t stream, const CsrDev &A, const RowDigest *D, int rpb
   default: SPMV_ACC_LAUNCH_RB(true, true); break;
   }
 #undef SPMV_ACC_LAUNCH_RB
+#undef SPMV_ACC_LAUNCH_RB_H
 }
 
 } // namespace

@@ -22,7 +22,7 @@ struct CsrDev {
   const int *guard = nullptr;
   int *stale = nullptr;
   // Gather hints (engine.cpp ensure_hint, k_hint.hip): one bit per non-zero, set where the non-zero's x line is NOT among the
-  // hot lines that fit an L2; kernels that take hints issue those gathers non-temporal.  Null: no hints (set per launch by the
+  // hot lines that fit an L2; the tile kernels (row blocks, row-block-plus, flat) issue those gathers non-temporal.  Null: no hints (set per launch by the
   // engine: only while the plan's timed comparison says they pay, and only where x is below 4 GB).  Speed only.
   const unsigned char *cold = nullptr;
 };

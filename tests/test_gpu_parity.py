@@ -699,7 +699,8 @@ def test_measurement_switches_keep_parity(torch_dev, oracle, hiplib):
                 ("adaptive_plus", {"gather_hint": 1}), ("adaptive_plus", {"gather_hint": 1, "hint_budget_kb": 1}),
                 ("adaptive_plus", {"gather_hint": 1, "hint_budget_kb": 100000}), ("flat", {"gather_hint": 1, "flat_npt": 8, "flat_early": 0}),
                 ("flat", {"gather_hint": 1, "hint_budget_kb": 8, "flat_npt": 8, "flat_early": 0, "flat_finish": 0}),
-                ("adaptive", {"gather_hint": 1, "hint_budget_kb": 16})]
+                ("adaptive", {"gather_hint": 1, "hint_budget_kb": 16}), ("line_enhance", {"gather_hint": 1, "hint_budget_kb": 16}),
+                ("line_enhance", {"gather_hint": 1, "rowblock_guard": 0, "rowlen": 1}), ("default", {"gather_hint": 1, "hint_budget_kb": 1})]
     try:
         for strat, knobs in variants:
             hiplib.spmv_acc_reset_tunables()

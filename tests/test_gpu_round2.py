@@ -485,7 +485,7 @@ def test_flat_segmented_scan_reduction(torch_dev, oracle, hiplib):
 
 def test_gather_hints_change_no_bit(torch_dev, oracle, hiplib):
     """Gather hints (k_hint.hip: the plan's column census marks the non-zeros whose x line lies outside the hot set, and the row-block-plus /
-    flat kernels gather those non-temporally) steer a cache policy only: with hints forced on, y is bit-identical to the plain kernels' and
+    flat / row-block kernels gather those non-temporally) steer a cache policy only: with hints forced on, y is bit-identical to the plain kernels' and
     matches the oracle -- on power-law columns with hub rows (the long-row slices of row-block-plus), for hot sets from one line to
     everything, for nnz that is no multiple of 8, and for the automatic mode (census + timed choice) on a matrix too small to want them."""
     torch = torch_dev
@@ -505,6 +505,8 @@ def test_gather_hints_change_no_bit(torch_dev, oracle, hiplib):
     try:
         # (the plans' other timed choices -- block size, cut-row form -- are pinned: they regroup sums, and a fresh plan may time them differently)
         for strat, base in (("adaptive_plus", {"plus_min_nnz": 1024}), ("adaptive_plus", {"plus_min_nnz": 1920}),
+                            ("line_enhance", {"rowblock_guard": 0}), ("line_enhance", {"rowblock_guard": 0, "rowlen": 1, "rowblock_vec": 2}),
+                            ("line", {"rowblock_guard": 0, "rowblock_vec": 16}),
                             ("flat", {"flat_npt": 8, "flat_early": 0, "flat_finish": 1}), ("flat", {"flat_npt": 8, "flat_early": 0, "flat_finish": 0})):
             outs = {}
             for tag, knobs in (("plain", {"gather_hint": 0}), ("one_line", {"gather_hint": 1, "hint_budget_kb": 1}),

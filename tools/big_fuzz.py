@@ -85,7 +85,7 @@ for case in range(cases):
     lib = spmv_acc_amd.load_library()
     failures = []
     # the shipped configuration of every family, then the round-2 variants the per-matrix timings may or may not pick
-    variants = [("flat", {"flat_reduce": 1}), ("adaptive_plus", {"gather_hint": 1, "hint_budget_kb": 256}),
+    variants = [("line_enhance", {"gather_hint": 1, "hint_budget_kb": 256}), ("flat", {"flat_reduce": 1}), ("adaptive_plus", {"gather_hint": 1, "hint_budget_kb": 256}),
                 ("flat", {"gather_hint": 1, "hint_budget_kb": 256, "flat_npt": 8, "flat_early": 0}), ("adaptive", {}), ("line_enhance", {}), ("flat", {}), ("adaptive_plus", {}), ("default", {}), ("vector_row", {}),
                 ("line_enhance", {"rowlen": 1}), ("line_enhance", {"rowlen": 0}), ("flat", {"flat_early": 1, "flat_npt": 4}),
                 ("flat", {"flat_early": 1, "flat_npt": 8}), ("flat", {"flat_finish": 1, "flat_npt": 4}), ("flat", {"col16": 1}),
