@@ -525,6 +525,24 @@ def test_gather_hints_change_no_bit(torch_dev, oracle, hiplib):
                 outs[tag] = got
             for tag, got in outs.items():
                 assert np.array_equal(got, outs["plain"]), (strat, base, tag)
+        # stale bits: colindex edited in place (same rowptr) under a live plan whose cold bits were derived from the old columns -- the plan is
+        # kept (the guard watches rowptr only), the bits now describe other columns, and the result must still be the new matrix' product
+        hiplib.spmv_acc_reset_tunables()
+        assert hiplib.spmv_acc_set_tunable(b"gather_hint", 1) == 0 and hiplib.spmv_acc_set_tunable(b"hint_budget_kb", 64) == 0
+        spmv_acc_amd.release_plans(drp)
+        cols2 = np.sort(rng.integers(0, n, size=nnz)).astype(np.int32)  # any valid columns
+        ref2 = oracle.host_spmv(0.5, -2.0, rowptr, cols2, vals, x, y0)
+        for strat in ("adaptive_plus", "flat", "line_enhance"):
+            dci.copy_(dev(torch, cols))
+            dy = dev(torch, y0)
+            spmv_acc_amd.csr_spmv(0.5, -2.0, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat)   # builds the plan and its bits from `cols`
+            torch.cuda.synchronize()
+            dci.copy_(dev(torch, cols2))                                                          # ... which now describe other columns
+            dy = dev(torch, y0)
+            spmv_acc_amd.csr_spmv(0.5, -2.0, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat)
+            torch.cuda.synchronize()
+            assert hiplib.spmv_acc_last_error() == 0
+            assert oracle.scaled_error(dy.cpu().numpy(), ref2, 0.5, -2.0, rowptr, cols2, vals, x, y0) <= SCALED_TOL, strat
     finally:
         hiplib.spmv_acc_reset_tunables()
         spmv_acc_amd.release_plans(drp)
