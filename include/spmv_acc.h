@@ -80,6 +80,18 @@ void spmv_acc_csr_spmv_strategy(int strategy, int trans, double alpha, double be
                                 const int *h_rowptr, const int *d_rowptr, const int *d_colindex,
                                 const double *d_value, const double *dx, double *dy);
 
+/* ---- out-of-place form (new) ---------------------------------------------------------------------------
+ *     y_out = alpha * A * x + beta * y_in
+ * replaces: nothing callable in the reference -- every entry there updates y in place (api/spmv.h:13-18), and its drivers
+ * re-upload y0 before each call (cli/main.cpp:101,116).  A caller that keeps both vectors (x_{k+1} = f(y_k) iterations, the
+ * row-sharded step below: old slice in one buffer, new slice inside the gathered vector) would otherwise copy y once per SpMV
+ * (2 x 8 B per row; 61 of 218 us per sharded step on the headline matrix).  Same kernels, same sums: bit-identical to the
+ * in-place entry on a copy of y_in.  strategy < 0: the active strategy.  dy_in may be NULL or equal to dy_out (in place);
+ * the two vectors must not overlap partially (SPMV_ACC_ERR_BAD_ARGUMENT); dy_in is not read when beta == 0. */
+void spmv_acc_csr_spmv_oop(int strategy, int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
+                           const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx,
+                           const double *dy_in, double *dy_out);
+
 /* ---- row-block preprocessing pass, device form ---------------------------------------------------------
  * replaces: pre_calc_break_point<STRIDE, BLOCKS, int><<<1024,512>>>(row_ptr, m, break_points, bp_len)
  *           -- src/acc/hip-flat/flat_imp.inl:108-131, launched from flat.cpp:25,43.
@@ -177,6 +189,10 @@ double spmv_acc_last_prepare_us(void);
  * that permute a few rows in place still have to call spmv_acc_release_plans. */
 void spmv_acc_release_plans(const int *d_rowptr);
 int spmv_acc_cached_plans(void);
+/* spmv_acc_last_error() asks the plan the CALLING THREAD used last (one load, no lock).  This one looks at every cached plan,
+ * any thread's: drops the stale ones, returns how many there were (and records SPMV_ACC_ERR_BAD_ARGUMENT if any).  Call after a
+ * device synchronisation. */
+int spmv_acc_check_plans(void);
 /* plan introspection: fills out[9] = {nnz, adaptive_branch, vec, flat_tiles, plus_blocks, aligned16, stream_policy,
  * flat_fixup, adaptive_family};
  * stream_policy: cache policy of the stream loads chosen by timing at plan time (0 nt, 1 default, 3 values default,
@@ -184,10 +200,17 @@ int spmv_acc_cached_plans(void);
  * plan yet; adaptive_family: the kernel family adaptive settled on by timing (0 fixed row blocks, 1 row-block-plus, 2 flat,
  * -1 not timed); returns 1 if a plan exists */
 int spmv_acc_query_plan(const int *d_rowptr, int m, int *out);
+/* adaptive's timed kernel family for the beta == 0 class alone (out[8] above reports the beta != 0 class when it has been
+ * timed): the families are timed per class because the ranking changes with the y read; -2 = no such plan */
+int spmv_acc_query_plan_beta0(const int *d_rowptr, int m);
 
-void spmv_acc_set_stream(void *hip_stream); /* hipStream_t; NULL = the NULL stream (reference behaviour).  Steady-state calls are
+void spmv_acc_set_stream(void *hip_stream); /* hipStream_t; NULL = the NULL stream (reference behaviour).  The stream belongs to the
+                                             * CALLING HOST THREAD, like HIP's current device: N threads driving N GPUs each set
+                                             * their own and cannot redirect one another.  Steady-state calls are
                                              * launches only and may be captured into a hipGraph; the first call on a matrix
-                                             * (plan: allocations, synchronisation, timings) must run outside a capture. */
+                                             * (plan: allocations, synchronisation, timings) must run outside a capture: a call that
+                                             * would need such work inside a capture enqueues nothing and reports
+                                             * SPMV_ACC_ERR_BAD_ARGUMENT (timed choices that are merely missing are skipped instead). */
 void *spmv_acc_get_stream(void);
 
 int spmv_acc_last_error(void); /* 0 = ok; see enum below.  Per host thread, like errno. */

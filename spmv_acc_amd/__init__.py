@@ -36,7 +36,8 @@ C_ABI_SYMBOLS = (
     "spmv_acc_set_stream", "spmv_acc_get_stream", "spmv_acc_last_error", "spmv_acc_last_error_string",
     "spmv_acc_clear_error", "spmv_acc_time_spmv", "spmv_acc_version", "spmv_acc_set_tunable",
     "spmv_acc_get_tunable", "spmv_acc_reset_tunables", "spmv_acc_time_spmv_total", "spmv_acc_copy_ceiling_gbs", "spmv_acc_adaptive_plus_analyze_device", "spmv_acc_prepare",
-    "spmv_acc_last_prepare_us", "spmv_acc_sharded_spmv",
+    "spmv_acc_last_prepare_us", "spmv_acc_sharded_spmv", "spmv_acc_csr_spmv_oop", "spmv_acc_check_plans",
+    "spmv_acc_query_plan_beta0",
 )
 
 _lib = None
@@ -106,6 +107,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_copy_ceiling_gbs.restype = cd
     lib.spmv_acc_last_prepare_us.restype = cd
     lib.spmv_acc_sharded_spmv.argtypes = [vp, ci, cd, cd, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+    lib.spmv_acc_csr_spmv_oop.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+    lib.spmv_acc_csr_spmv_oop.restype = None
+    lib.spmv_acc_query_plan_beta0.argtypes = [vp, ci]
     if path is None:
         _lib = lib
     return lib
@@ -189,10 +193,16 @@ def sparse_spmv(trans: int, alpha: float, beta: float, m: int, n: int, rowptr, c
 
 
 def csr_spmv(alpha: float, beta: float, m: int, n: int, nnz: int, rowptr, colindex, value, x, y,
-             strategy=None, h_rowptr=None, trans: int = 0) -> None:
-    """Descriptor entry (sparse_csr_spmv flattened).  ``h_rowptr``: optional host (numpy int32) rowptr."""
+             strategy=None, h_rowptr=None, trans: int = 0, y_in=None) -> None:
+    """Descriptor entry (sparse_csr_spmv flattened).  ``h_rowptr``: optional host (numpy int32) rowptr.
+    ``y_in``: out-of-place form, y = alpha*A*x + beta*y_in (spmv_acc_csr_spmv_oop); None = in place."""
     lib = load_library()
-    _csr_args(lib, m, n, nnz, rowptr, colindex, value, x, y)
+    _csr_args(lib, m, n, nnz, rowptr, colindex, value, x, y, y_in)
+    if y_in is not None:
+        lib.spmv_acc_csr_spmv_oop(-1 if strategy is None else strategy_id(strategy), trans, alpha, beta, m, n, nnz,
+                                  _ptr(h_rowptr), _ptr(rowptr), _ptr(colindex), _ptr(value), _ptr(x), _ptr(y_in), _ptr(y))
+        _check(lib)
+        return
     args = (trans, alpha, beta, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr), _ptr(colindex), _ptr(value), _ptr(x), _ptr(y))
     if strategy is None:
         lib.spmv_acc_csr_spmv(*args)
@@ -319,6 +329,12 @@ def copy_ceiling_gbs(dst, src, reps: int = 5) -> float:
 
 def release_plans(rowptr=None) -> None:
     load_library().spmv_acc_release_plans(_ptr(rowptr))
+
+
+def check_plans() -> int:
+    """After a device synchronisation: drop every cached plan (any thread's) whose stale-plan guard has fired; returns how
+    many.  ``_check`` / spmv_acc_last_error only ask the plan the calling thread used last."""
+    return int(load_library().spmv_acc_check_plans())
 
 
 def query_plan(rowptr, m: int):

@@ -133,6 +133,13 @@ void spmv_acc_csr_spmv_strategy(int strategy, int trans, double alpha, double be
   run_spmv(strategy, trans, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy);
 }
 
+void spmv_acc_csr_spmv_oop(int strategy, int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
+                           const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx,
+                           const double *dy_in, double *dy_out) {
+  run_spmv(strategy < 0 ? active_strategy() : strategy, trans, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx,
+           dy_out, dy_in);
+}
+
 int spmv_acc_break_points_len(int nnz, int stride) {
   if (stride <= 0 || nnz < 0) return -1;
   return nnz / stride + (nnz % stride ? 1 : 0) + 1;
@@ -271,6 +278,7 @@ int spmv_acc_free_device(void *p) {
 
 void spmv_acc_release_plans(const int *d_rowptr) { release_plans(d_rowptr); }
 int spmv_acc_cached_plans(void) { return cached_plan_count(); }
+int spmv_acc_check_plans(void) { return check_plans(); }
 int spmv_acc_query_plan(const int *d_rowptr, int m, int *out) {
   PlanInfo info;
   if (!out || !query_plan(d_rowptr, m, &info)) return 0;
@@ -284,6 +292,10 @@ int spmv_acc_query_plan(const int *d_rowptr, int m, int *out) {
   out[7] = info.flat_fixup;
   out[8] = info.adaptive_family;
   return 1;
+}
+int spmv_acc_query_plan_beta0(const int *d_rowptr, int m) {
+  PlanInfo info;
+  return query_plan(d_rowptr, m, &info) ? info.adaptive_family_beta0 : -2;
 }
 
 void spmv_acc_set_stream(void *hip_stream) { set_stream(static_cast<hipStream_t>(hip_stream)); }

@@ -177,8 +177,12 @@ __device__ __forceinline__ void check_plan_guard(const int *__restrict__ rp, int
 
 // y update with the documented semantics y = alpha*A*x + beta*y (api/spmv.h:14).  beta == 0 does
 // not read y (BLAS convention; for finite y it equals the reference's alpha*s + 0*y).
-__device__ __forceinline__ void store_y(double *y, int row, double alpha, double beta, double s) {
-  y[row] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[row];
+// yin: where the OLD y is read.  The reference's entries update y in place (yin == y, what every in-place entry passes); the
+// out-of-place entry (spmv_acc_csr_spmv_oop: y_out = alpha*A*x + beta*y_in) passes another vector, which saves an iteration
+// that keeps both vectors (and the row-sharded step, whose old slice and new slice live in different buffers) a copy of y per
+// SpMV.  Neither pointer is __restrict__ in the kernels: they may be the same vector.
+__device__ __forceinline__ void store_y(double *y, const double *yin, int row, double alpha, double beta, double s) {
+  y[row] = (beta == 0.0) ? alpha * s : alpha * s + beta * yin[row];
 }
 
 } // namespace dev

@@ -31,7 +31,11 @@ namespace spmv_acc {
 namespace {
 thread_local int g_err = kOk;
 thread_local std::string g_err_msg;
-hipStream_t g_stream = nullptr;
+// The library stream belongs to the calling host thread, like HIP's current device: a process that drives N GPUs from N
+// host threads (one hipSetDevice + one stream each; spmv-cli --gpus N, spmv_acc_sharded_spmv with ncclCommInitAll) gives every
+// thread its own, and nothing one thread sets can redirect another thread's launches.  NULL (the reference's behaviour)
+// until the thread calls spmv_acc_set_stream.
+thread_local hipStream_t t_stream = nullptr;
 std::mutex g_mu;
 
 bool hip_ok(hipError_t e, const char *what) {
@@ -46,13 +50,15 @@ void set_error(int code, const std::string &what) {
   g_err_msg = what;
 }
 namespace {
-bool report_stale_plans(); // below, with the plan cache
+bool report_stale_last_plan(); // below, with the plan cache
 }
-// Besides the calling thread's own error this reports a stale plan: a kernel of an earlier call found that the matrix behind a
-// cached plan's pointers is no longer the one the plan was built for (the caller should synchronise first, as it must
-// before reading y anyway).  The stale plan is dropped here; the next call on those pointers rebuilds it.
+// Besides the calling thread's own error this reports that the plan the calling thread used LAST is stale: a kernel of that call
+// (or of an earlier one) found that the matrix behind the plan's pointers is no longer the one the plan was built for.  The
+// kernels run asynchronously, so the flag is there only after the caller has synchronised -- as it must before reading y anyway:
+// synchronise, then ask.  One relaxed load of a pinned int; no lock, no walk over the plan cache (other threads' plans are
+// theirs to ask about; spmv_acc_check_plans() looks at every plan).  The stale plan is dropped; the next call rebuilds it.
 int last_error() {
-  if (g_err == kOk) (void)report_stale_plans();
+  if (g_err == kOk) (void)report_stale_last_plan();
   return g_err;
 }
 const char *last_error_string() { return g_err_msg.c_str(); }
@@ -69,8 +75,8 @@ thread_local unsigned t_plan_work = 0; // bumped by every once-per-matrix step (
 
 double last_prepare_us() { return t_last_prepare_us; }
 
-void set_stream(hipStream_t s) { g_stream = s; }
-hipStream_t get_stream() { return g_stream; }
+void set_stream(hipStream_t s) { t_stream = s; }
+hipStream_t get_stream() { return t_stream; }
 
 // ---- tunables (A/B switches for measurement; defaults are the shipped configuration) ----------------------
 namespace {
@@ -400,7 +406,10 @@ constexpr int kGuardSlots = 4096;
 struct GuardPool {
   int *d_guard = nullptr; // kGuardSlots * kGuardSamples ints
   int *h_flags = nullptr; // kGuardSlots ints, hipHostMalloc (coherent, device-visible)
-  std::deque<int> free_slots;
+  // free slots, oldest first.  A slot released by a plan that had launched kernels carries an event recorded behind the plan's
+  // last launch: the slot gets a new owner only once that event has completed, so a kernel of the dropped plan that is still
+  // in flight can never raise the flag of the slot's next owner (first-in first-out alone only made that unlikely).
+  std::deque<std::pair<int, hipEvent_t>> free_slots;
   bool failed = false;
 };
 std::mutex g_guard_mu; // not g_mu: plans die (and return their slot) both under g_mu and outside it
@@ -421,26 +430,54 @@ int guard_acquire(int device, const int **d_guard, int **h_flag) {
       return -1;
     }
     std::memset(P.h_flags, 0, sizeof(int) * kGuardSlots);
-    for (int i = 0; i < kGuardSlots; ++i) P.free_slots.push_back(i);
+    for (int i = 0; i < kGuardSlots; ++i) P.free_slots.emplace_back(i, nullptr);
   }
-  if (P.free_slots.empty()) return -1;
-  const int slot = P.free_slots.front();
-  P.free_slots.pop_front();
+  int slot = -1;
+  for (size_t tries = P.free_slots.size(); tries > 0 && slot < 0; --tries) {
+    const std::pair<int, hipEvent_t> cand = P.free_slots.front();
+    P.free_slots.pop_front();
+    if (cand.second && hipEventQuery(cand.second) == hipErrorNotReady) {
+      P.free_slots.push_back(cand); // its last owner's kernels are still running: not yet
+      continue;
+    }
+    (void)hipGetLastError();
+    if (cand.second) (void)hipEventDestroy(cand.second);
+    slot = cand.first;
+  }
+  if (slot < 0) return -1; // (this plan runs unguarded)
   __atomic_store_n(&P.h_flags[slot], 0, __ATOMIC_RELAXED);
   *d_guard = P.d_guard + static_cast<size_t>(slot) * kGuardSamples;
   *h_flag = P.h_flags + slot;
   return slot;
 }
-void guard_release(int device, int slot) {
+// `launched`: the plan has enqueued kernels, the last of them on `last_stream` (a stream of `device`)
+void guard_release(int device, int slot, bool launched, hipStream_t last_stream) {
   if (slot < 0) return;
+  hipEvent_t ev = nullptr;
+  if (launched) {
+    int cur = -1;
+    const bool switched = hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+    if (ev && hipEventRecord(ev, last_stream) != hipSuccess) { // (e.g. the caller has destroyed that stream: its work is done)
+      (void)hipEventDestroy(ev);
+      ev = nullptr;
+    }
+    (void)hipGetLastError();
+    if (switched) (void)hipSetDevice(cur);
+  }
   std::lock_guard<std::mutex> lk(g_guard_mu);
-  g_guard_pools[device].free_slots.push_back(slot);
+  g_guard_pools[device].free_slots.emplace_back(slot, ev);
 }
 
 enum Family { kFamRowblock = 0, kFamPlus = 1, kFamFlat = 2, kFamVector = 3, kFamilyCount = 4 };
 
+typedef std::tuple<int, const void *, const void *, const void *, int, int> PlanKey;
+
 struct Plan {
   int device = 0;
+  PlanKey key;                     // where the plan sits in g_plans
+  hipStream_t last_stream = nullptr; // stream of the plan's latest launches (a plan may be used from several streams in turn)
+  bool launched = false;           // some kernel carrying this plan's guard slot has been enqueued
   unsigned long long last_use = 0; // plan-cache clock at the last call that used this plan
   std::mutex mu;                   // held by run_spmv for the whole call: plan fields, carry buffers and tunings are per matrix
   unsigned long long calls = 0;    // SpMV calls served by this plan (the first one builds and tunes it)
@@ -461,7 +498,9 @@ struct Plan {
   int rowblock_rpb = 0;
   int max_block_nnz = 0;
   bool rowblock_uneven = false; // many row blocks far from the average block (balance probe)
-  int adaptive_family = -1;     // adaptive's timed choice: 0 fixed row blocks, 1 row-block-plus, 2 flat; -1 not timed yet
+  // adaptive's timed choice per beta class ([0]: beta == 0, [1]: y is read too -- the ranking flips between the classes where rows
+  // hold one or two non-zeros): 0 fixed row blocks, 1 row-block-plus, 2 flat; -1 not timed yet
+  int adaptive_family[2] = {-1, -1};
   RowDigest digest;             // row-block family: 1-byte row lengths + per-block bases (built for digest.rpb rows per block)
   // flat
   int flat_tiles = -1;
@@ -488,7 +527,7 @@ struct Plan {
 
   ~Plan() {
     free_device();
-    guard_release(device, guard_slot);
+    guard_release(device, guard_slot, launched, last_stream);
   }
   bool is_stale() const { return A.stale && __atomic_load_n(A.stale, __ATOMIC_RELAXED) != 0; }
   void free_col16() {
@@ -533,8 +572,20 @@ struct Plan {
   }
 };
 
-typedef std::tuple<int, const void *, const void *, const void *, int, int> PlanKey;
 std::map<PlanKey, std::shared_ptr<Plan>> g_plans; // a running call keeps its plan alive through its own reference
+thread_local std::weak_ptr<Plan> t_last_plan;     // the plan this thread's latest run_spmv used (last_error asks it, and only it)
+
+// Is the calling thread inside a stream capture (set by run_spmv)?  Plan work -- allocations, synchronisation, timings -- would
+// invalidate the capture: required work is refused with an error that says so, optional work (timed choices) is skipped and the
+// call runs with what the plan already holds.
+thread_local bool t_capturing = false;
+bool plan_work_allowed(const char *what) {
+  if (!t_capturing) return true;
+  set_error(kErrBadArgument, std::string("this call needs plan work (") + what +
+                                 ") that allocates or synchronises and cannot run inside a stream capture: run the same call "
+                                 "(or spmv_acc_prepare with this strategy) once outside the capture first; nothing was enqueued");
+  return false;
+}
 constexpr size_t kMaxPlans = 1024; // beyond this the least recently used plan is dropped
 unsigned long long g_use_clock = 0;
 
@@ -558,6 +609,7 @@ const int *host_view(const int *h) { return host_readable(h) ? h : nullptr; }
 
 bool fetch_samples(Plan &p, const int *h_rowptr) {
   if (p.have_samples) return true;
+  if (!plan_work_allowed("reading the rowptr samples")) return false;
   ++t_plan_work;
   h_rowptr = host_view(h_rowptr);
   const int m = p.A.m;
@@ -586,9 +638,11 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_plans.find(key);
   if (it != g_plans.end() && it->second->is_stale()) {
+    if (!plan_work_allowed("rebuilding a stale plan")) return nullptr;
     set_error(kErrBadArgument,
               "the matrix behind a cached plan changed (same pointers and shape, different rowptr) without "
-              "spmv_acc_release_plans: the previous result on it is invalid; the plan has been rebuilt");
+              "spmv_acc_release_plans: the results of the EARLIER calls made on it since the change are invalid; the plan has "
+              "been rebuilt, so the call that reports this ran on the matrix as it is now and its y is valid");
     g_plans.erase(it);
     it = g_plans.end();
   }
@@ -598,8 +652,10 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
       return it->second;
     }
     // same buffers, different nnz: the caller rebuilt the matrix in place
+    if (!plan_work_allowed("rebuilding the plan of a matrix whose nnz changed")) return nullptr;
     g_plans.erase(it);
   }
+  if (!plan_work_allowed("building the plan of a matrix seen for the first time")) return nullptr;
   if (g_plans.size() >= kMaxPlans) {
     auto oldest = g_plans.begin();
     for (auto jt = g_plans.begin(); jt != g_plans.end(); ++jt)
@@ -619,6 +675,7 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
   }
   std::shared_ptr<Plan> p = std::make_shared<Plan>();
   p->device = dev;
+  p->key = key;
   p->A.m = m;
   p->A.n = n;
   p->A.nnz = nnz;
@@ -630,29 +687,53 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
   p->last_use = ++g_use_clock;
   p->guard_slot = guard_acquire(dev, &p->A.guard, &p->A.stale);
   if (p->guard_slot >= 0) {
-    launch_guard_fill(g_stream, rp, m, const_cast<int *>(p->A.guard));
-    if (!hip_ok(hipStreamSynchronize(g_stream), "record the plan guard")) return nullptr; // (a later call may use another stream)
+    launch_guard_fill(t_stream, rp, m, const_cast<int *>(p->A.guard));
+    if (!hip_ok(hipStreamSynchronize(t_stream), "record the plan guard")) return nullptr; // (a later call may use another stream)
   }
   g_plans[key] = p;
   return p;
 }
 
-bool report_stale_plans() {
+const char *const kStaleText =
+    "the matrix behind a cached plan changed (same pointers and shape, different rowptr) without spmv_acc_release_plans: the "
+    "results of the calls made on it since the change -- including the calling thread's most recent SpMV on these pointers -- "
+    "are invalid; the plan has been dropped and the next call on the matrix rebuilds it";
+
+// O(1): the plan the calling thread used last, nothing else
+bool report_stale_last_plan() {
+  const std::shared_ptr<Plan> p = t_last_plan.lock();
+  if (!p || !p->is_stale()) return false;
+  set_error(kErrBadArgument, kStaleText);
+  t_last_plan.reset();
   std::lock_guard<std::mutex> lk(g_mu);
-  for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
+  auto it = g_plans.find(p->key);
+  if (it != g_plans.end() && it->second == p) g_plans.erase(it);
+  return true;
+}
+} // namespace
+
+// Every cached plan (any thread's): drops the stale ones, returns how many there were.  For callers that edit matrices in place
+// from several threads and want one check after a device-wide synchronisation; not on any hot path.
+int check_plans() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int dropped = 0;
+  for (auto it = g_plans.begin(); it != g_plans.end();) {
     if (it->second->is_stale()) {
-      set_error(kErrBadArgument,
-                "the matrix behind a cached plan changed (same pointers and shape, different rowptr) without "
-                "spmv_acc_release_plans: the last result on it is invalid; the plan has been dropped");
-      g_plans.erase(it);
-      return true;
+      it = g_plans.erase(it);
+      ++dropped;
+    } else {
+      ++it;
     }
   }
-  return false;
+  if (dropped) set_error(kErrBadArgument, kStaleText);
+  return dropped;
 }
+
+namespace {
 
 // Break points, carry buffers and the two plan-time probes of a flat plan with `stride` non-zeros per tile.
 bool build_flat_plan(const CsrDev &A, int stride, hipStream_t stream, FlatPlan &F) {
+  if (!plan_work_allowed("flat: break points and tile digests")) return false;
   ++t_plan_work;
   Plan::free_flat_plan(F);
   const int nnz = A.nnz;
@@ -692,7 +773,7 @@ bool build_flat_plan(const CsrDev &A, int stride, hipStream_t stream, FlatPlan &
   F.max_tile_rows = h_flag[1];
   F.can_finish = h_flag[0] == 0;
   F.needs_fixup = true; // until run_flat has timed both forms on this matrix
-  F.mode_tuned = false;
+  F.mode_tuned[0] = F.mode_tuned[1] = false;
   return true;
 }
 
@@ -784,6 +865,7 @@ bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) 
   const int want_vec =
       tun(kT_plus_ref_vec) ? plus_pick_vec(p.A.m, p.A.nnz) : plus_pick_vec_tuned(p.A.m, p.A.nnz, min_nnz);
   if (p.plus_blocks >= 0 && p.plus_vec == want_vec && p.plus_min == min_nnz) return true;
+  if (!plan_work_allowed("row-block analysis")) return false;
   ++t_plan_work;
   auto drop_tables = [&p] { // also the exit of every failure below: nothing half-built stays behind
     if (p.d_pbp) (void)hipFree(p.d_pbp);
@@ -974,6 +1056,7 @@ template <typename Launch> bool autotune_policy(Plan &p, int fam, hipStream_t st
 bool ensure_col16(Plan &p, hipStream_t st) {
   constexpr size_t kWarpPad = 64;
   if (p.col16.d16) return true;
+  if (!plan_work_allowed("the 16-bit column encoding")) return false;
   ++t_plan_work;
   Col16 &C = p.col16;
   const int nchunks = (p.A.nnz + kCol16Chunk - 1) / kCol16Chunk;
@@ -1046,8 +1129,13 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
     F.needs_fixup = forced == 0;
     return true;
   }
-  if (F.mode_tuned) {
-    F.needs_fixup = F.tuned_fixup;
+  const int cls = t_beta_class; // (the fix-up kernel re-reads the old y of every cut row: the two forms rank per beta class)
+  if (F.mode_tuned[cls]) {
+    F.needs_fixup = F.tuned_fixup[cls];
+    return true;
+  }
+  if (t_capturing) { // not timed in this class yet and no timing inside a capture: the other class' choice, else finish in the tile
+    F.needs_fixup = F.mode_tuned[cls ^ 1] ? F.tuned_fixup[cls ^ 1] : false;
     return true;
   }
   if (t_coarse_tuning && p.A.nnz >= kFlatSmallNnz) { // (small matrices: the timings are cheap and decide the comparison)
@@ -1066,9 +1154,9 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
     ok = timer.time(st, [&] { launch_flat_with(st, p, policy_for(p, kFamFlat), 1.0, trial_beta(), x, scratch); }, &ms[mode]);
   }
   (void)hipFree(scratch);
-  F.tuned_fixup = F.needs_fixup = !(ok && ms[1] < ms[0]);
-  F.mode_tuned = ok;
-  if (ok) tune_log("m %d nnz %d flat cut rows: carries + fix-up %.2f us, finished in the tile %.2f us", p.A.m, p.A.nnz, ms[0] * 1e3f, ms[1] * 1e3f);
+  F.tuned_fixup[cls] = F.needs_fixup = !(ok && ms[1] < ms[0]);
+  F.mode_tuned[cls] = ok;
+  if (ok) tune_log("m %d nnz %d beta class %d flat cut rows: carries + fix-up %.2f us, finished in the tile %.2f us", p.A.m, p.A.nnz, cls, ms[0] * 1e3f, ms[1] * 1e3f);
   return ok;
 }
 
@@ -1076,7 +1164,7 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
 // per matrix and keep the fastest.  The other tile size gets its own break points / carries; its cut rows are finished in
 // the tile whenever that is legal (no second launch: what wins on short kernels).
 bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
-  if (p.flat_geometry_tuned || tun(kT_col16) > 0 || flat_segment_sum()) return true;
+  if (p.flat_geometry_tuned || tun(kT_col16) > 0 || flat_segment_sum() || t_capturing) return true;
   if (p.A.nnz >= kFlatSmallNnz || p.flat.ntiles <= 1) {
     p.flat_geometry_tuned = true;
     return true;
@@ -1096,8 +1184,8 @@ bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
     const int other = p.flat.stride == kThreads * 4 ? kThreads * kNnzPerThread : kThreads * 4;
     ok = build_flat_plan(p.A, other, st, alt);
     if (ok) {
-      alt.needs_fixup = alt.tuned_fixup = !alt.can_finish;
-      alt.mode_tuned = true;
+      alt.needs_fixup = alt.tuned_fixup[0] = alt.tuned_fixup[1] = !alt.can_finish;
+      alt.mode_tuned[0] = alt.mode_tuned[1] = true;
       plans[1] = &alt;
     }
   }
@@ -1299,6 +1387,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
 // and every later call (until its plan is released) instead of sending a kernel out of bounds.
 bool validate_plan(Plan &p, hipStream_t st) {
   if (p.invalid < 0) {
+    if (!plan_work_allowed("validating the matrix")) return false;
     ++t_plan_work;
     int *d_flags = nullptr;
     int h = -1;
@@ -1328,6 +1417,7 @@ bool validate_plan(Plan &p, hipStream_t st) {
 // (power-law matrices: R-MAT hub rows put millions of non-zeros into one workgroup.)
 bool probe_rowblock(Plan &p, int rpb, hipStream_t st) {
   if (p.rowblock_ok >= 0 && p.rowblock_rpb == rpb) return true;
+  if (!plan_work_allowed("the row-block balance probe")) return false;
   ++t_plan_work;
   p.rowblock_rpb = rpb;
   int *d_max = nullptr;
@@ -1360,6 +1450,7 @@ bool probe_rowblock(Plan &p, int rpb, hipStream_t st) {
 // Row digest of the row-block family (kernels.hpp RowDigest): derived from rowptr alone, like everything else a plan holds.
 bool ensure_digest(Plan &p, int rpb, hipStream_t st) {
   if (p.digest.lens && p.digest.rpb == rpb) return true;
+  if (!plan_work_allowed("the row digest")) return false;
   ++t_plan_work;
   p.free_digest();
   const size_t nblocks = (static_cast<size_t>(p.A.m) + rpb - 1) / rpb;
@@ -1409,8 +1500,12 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
   // (auto: rows of <= 8 non-zeros on average, where rowptr is >= 3.5 % of the traffic; measured at 12.6 per row the scan costs
   // more than the bytes save -- largebasis-sized 17.8 vs 17.4 us)
   if (want_lens > 0 || (want_lens < 0 && static_cast<long long>(p.A.nnz) <= 8LL * p.A.m)) {
-    if (!ensure_digest(p, rpb, st)) return false;
-    dg = &p.digest;
+    // (inside a capture a digest that does not exist yet is simply not used: the kernel reads rowptr, same result)
+    const bool have = p.digest.lens && p.digest.rpb == rpb;
+    if (have || !t_capturing) {
+      if (!ensure_digest(p, rpb, st)) return false;
+      dg = &p.digest;
+    }
   }
   // blocks at each end of the grid whose streams stay cacheable (tunable cache_ends_mb; 12 B per non-zero of stream)
   int cache_ends = 0;
@@ -1452,6 +1547,8 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
     return ensure_plus(p, h_rowptr, st, forced > 0 ? forced : kPlusMinNnz) && autotune_policy(p, kFamPlus, st, launch);
   }
   if (p.plus_tuned_min > 0) return ensure_plus(p, h_rowptr, st, p.plus_tuned_min) && autotune_policy(p, kFamPlus, st, launch);
+  // (inside a capture: the row blocks the plan already holds, whatever block size they were analysed with; none yet -> refused)
+  if (t_capturing) return (p.plus_blocks >= 0 || ensure_plus(p, h_rowptr, st, 1536)) && autotune_policy(p, kFamPlus, st, launch);
   // (coarse: 1024 where the balance probe found hub rows -- the block size that wins on power-law matrices -- else 1536)
   if (t_coarse_tuning)
     return ensure_plus(p, h_rowptr, st, p.rowblock_ok == 0 ? kPlusMinNnz : 1536) && autotune_policy(p, kFamPlus, st, launch);
@@ -1509,7 +1606,14 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
     default: return run_flat(st, p, a, b, x, yy);
     }
   };
-  if (p.adaptive_family < 0) {
+  const int cls = t_beta_class;
+  if (p.adaptive_family[cls] < 0 && t_capturing) {
+    // no timing inside a capture: the family the other beta class settled on (prepared matrices: spmv_acc_prepare times beta = 1),
+    // whose plan exists; with neither class timed the call is refused
+    if (p.adaptive_family[cls ^ 1] >= 0) return run_family(p.adaptive_family[cls ^ 1], alpha, beta, y);
+    return plan_work_allowed("adaptive: timing the kernel families on this matrix");
+  }
+  if (p.adaptive_family[cls] < 0) {
     ++t_plan_work;
     double *scratch = nullptr;
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
@@ -1548,9 +1652,9 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
              beta != 0.0 ? "!=" : "==", ms[0] * 1e3f, ms[1] * 1e3f, ms[2] * 1e3f, best_family);
     (void)hipFree(scratch);
     if (!ok) return false;
-    p.adaptive_family = best_family;
+    p.adaptive_family[cls] = best_family;
   }
-  return run_family(p.adaptive_family, alpha, beta, y);
+  return run_family(p.adaptive_family[cls], alpha, beta, y);
 }
 
 } // namespace
@@ -1559,7 +1663,8 @@ FlatSegmentSumScope::FlatSegmentSumScope() : prev(t_flat_segment_sum) { t_flat_s
 FlatSegmentSumScope::~FlatSegmentSumScope() { t_flat_segment_sum = prev; }
 
 void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
-              const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx, double *dy) {
+              const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx, double *dy,
+              const double *dy_in) {
   if (trans != 0) {
     // the reference never reads `trans` (only operation_none is supported, api/spmv.h:13); it computes
     // the non-transposed product.  Same here, but the mismatch is reported out of band.
@@ -1575,12 +1680,29 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     set_error(kErrBadArgument, "null rowptr / x / y");
     return;
   }
+  if (dy_in == dy) dy_in = nullptr; // in place after all
+  if (dy_in && beta != 0.0) {
+    // out of place: every row reads y_in[row] and writes y_out[row] exactly once, so the two vectors may be anything but
+    // PARTLY overlapping (a shifted view of the same buffer would let one row's store land on another row's unread old value)
+    const uintptr_t a = reinterpret_cast<uintptr_t>(dy_in), b = reinterpret_cast<uintptr_t>(dy), bytes = sizeof(double) * static_cast<uintptr_t>(m);
+    if (a < b + bytes && b < a + bytes) {
+      set_error(kErrBadArgument, "y_in and y_out overlap without being the same vector");
+      return;
+    }
+  }
+  hipStream_t st = t_stream;
+  {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    t_capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    (void)hipGetLastError();
+  }
   if (strategy < 0 || strategy >= kStrategyCount) {
     set_error(kErrUnknownStrategy, "unknown strategy id");
     return;
   }
   const std::shared_ptr<Plan> p = get_plan(m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value);
   if (!p) return;
+  t_last_plan = p;
   // one call at a time per matrix: plan fields, the per-matrix timings and the carry buffers of flat / row-block-plus belong
   // to the plan (two host threads on DIFFERENT matrices do not meet here; this lock is never held together with g_mu)
   std::lock_guard<std::mutex> plan_lock(p->mu);
@@ -1598,11 +1720,18 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     }
   } prepare_clock{t_plan_work, std::chrono::steady_clock::now()};
   if (p->calls++ == 0) ++t_plan_work; // the plan itself (nnz / guard samples) was just made by get_plan
-  hipStream_t st = g_stream;
   (void)hipGetLastError(); // errors of earlier, unrelated HIP calls of this thread are not this call's
+  p->last_stream = st;
+  p->launched = true;
+  // where this call's kernels read the old y (kernels.hpp CsrDev::yin); the plan's lock is held until the launches are enqueued
+  struct YinScope {
+    CsrDev &A;
+    ~YinScope() { A.yin = nullptr; }
+  } yin_scope{p->A};
+  p->A.yin = beta != 0.0 ? dy_in : nullptr;
 
   if (p->A.nnz == 0) {
-    launch_scale_y(st, m, beta, dy);
+    launch_scale_y(st, m, beta, dy, p->A.yin);
     return;
   }
   if (!d_colindex || !d_value) {
@@ -1737,12 +1866,14 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->plus_blocks = p.plus_blocks;
       out->aligned16 = p.A.aligned16 ? 1 : 0;
       // the policy of the family that runs this matrix: adaptive's choice if it was timed, else the first family tuned
-      int fam = p.adaptive_family >= 0 ? p.adaptive_family : -1;
+      const int afam = p.adaptive_family[1] >= 0 ? p.adaptive_family[1] : p.adaptive_family[0]; // (beta != 0 first: the reference's protocol)
+      int fam = afam;
       for (int f = 0; fam < 0 && f < kFamilyCount; ++f)
         if (p.stream_policy[f][1] >= 0 || p.stream_policy[f][0] >= 0) fam = f;
       out->stream_policy = fam < 0 ? -1 : (p.stream_policy[fam][1] >= 0 ? p.stream_policy[fam][1] : p.stream_policy[fam][0]);
       out->flat_fixup = p.flat_tiles > 0 ? (p.flat.needs_fixup ? 1 : 0) : -1;
-      out->adaptive_family = p.adaptive_family;
+      out->adaptive_family = afam;
+      out->adaptive_family_beta0 = p.adaptive_family[0];
       return true;
     }
   }

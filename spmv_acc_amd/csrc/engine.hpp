@@ -58,6 +58,7 @@ void reset_tunables();
 // 0 when the plan already existed.
 double last_prepare_us();
 
+// the calling host thread's library stream (thread-local, like HIP's current device; NULL until set)
 void set_stream(hipStream_t s);
 hipStream_t get_stream();
 
@@ -103,8 +104,10 @@ int plus_pick_vec_tuned(int m, int nnz, int min_nnz); // row cap chosen so block
 // One SpMV y = alpha*A*x + beta*y with the given strategy.  h_rowptr may be null: the four samples
 // and (for adaptive-plus) the whole rowptr are then fetched from the device once and cached in the
 // plan.  nnz < 0 means "unknown": it is read from d_rowptr[m] once.
+// dy_in: where the old y is read (out-of-place form y_out = alpha*A*x + beta*y_in); null or == dy: in place, the reference's form.
 void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
-              const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx, double *dy);
+              const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx, double *dy,
+              const double *dy_in = nullptr);
 
 // Drop cached plans (all, or those keyed on this rowptr).  Call when a matrix' structure changes in
 // place or its buffers are freed.
@@ -120,9 +123,13 @@ struct PlanInfo {
   int aligned16 = 0;
   int stream_policy = -1; // kStreamPolicy* chosen by the plan-time timing, -1 = not tuned yet
   int flat_fixup = -1;    // 1: flat folds cut rows with the fix-up kernel, 0: tiles finish them, -1: no flat plan yet
-  int adaptive_family = -1; // adaptive's timed choice: 0 fixed row blocks, 1 row-block-plus, 2 flat, -1 not timed
+  int adaptive_family = -1; // adaptive's timed choice: 0 fixed row blocks, 1 row-block-plus, 2 flat, -1 not timed (the beta != 0
+                            // class if it has been timed, else the beta == 0 class)
+  int adaptive_family_beta0 = -1; // ... of the beta == 0 class alone
 };
 bool query_plan(const int *d_rowptr, int m, PlanInfo *out);
 int cached_plan_count();
+// Drops every cached plan whose stale flag is up (any thread's) and returns how many; records SPMV_ACC_ERR_BAD_ARGUMENT if any.
+int check_plans();
 
 } // namespace spmv_acc

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
                                                              const int *__restrict__ rp, const int *__restrict__ bp,
                                                              const int *__restrict__ ci,
                                                              const double *__restrict__ v,
-                                                             const double *__restrict__ x, double *__restrict__ y,
+                                                             const double *__restrict__ x, double *y, const double *yin,
                                                              double *__restrict__ head, double *__restrict__ tail,
                                                              int *__restrict__ tail_row, int *__restrict__ tail_end,
                                                              int xcd_chunk, int reach,
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
   }
   const bool early_y = beta != 0.0;
   double y_old0 = 0.0;
-  if (early_y && live0 && lane == 0) y_old0 = y[first + vec_id]; // read for cut rows too (<= 2 per tile): harmless
+  if (early_y && live0 && lane == 0) y_old0 = yin[first + vec_id]; // read for cut rows too (<= 2 per tile): harmless
 
   // Finish mode (reach > 0): the tile's last row, when it starts here and runs at most `reach` non-zeros past the tile, is
   // completed by this tile's first wave.  Its overhang [t1, row end) is requested NOW, next to the stream loads -- the row's
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
       if (a >= t0 && b <= t1) {
         // complete row (possibly empty): final value
         if (base == 0 && early_y) y[r] = alpha * s + beta * y_old0;
-        else store_y(y, r, alpha, beta, s);
+        else store_y(y, yin, r, alpha, beta, s);
       } else if (a < t0) {
         // row started in an earlier tile.  Its owner (the tile it starts in) finishes a short overhang itself; only a
         // row that runs more than kFlatFinish non-zeros past its owner's end is folded from carries.
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
       } else if (b - t1 <= reach) {
         sh_tail_sum = s; // row starts here and ends at most kFlatFinish non-zeros into the next tile(s): finished below
         sh_tail_row = r;
-        sh_tail_yold = (base == 0 && early_y) ? y_old0 : (early_y ? y[r] : 0.0);
+        sh_tail_yold = (base == 0 && early_y) ? y_old0 : (early_y ? yin[r] : 0.0);
       } else {
         tail[t] = s; // long row: carry, folded by the fix-up kernel in tile order
         tail_row[t] = r;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void flat_fixup_kernel(int ntiles, int stride,
                                                          const double *__restrict__ head,
                                                          const double *__restrict__ tail,
                                                          const int *__restrict__ tail_row,
-                                                         const int *__restrict__ tail_end, double *__restrict__ y) {
+                                                         const int *__restrict__ tail_end, double *y, const double *yin) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   // no early return: every lane of a wave takes part in wave_range_sum
   int r = -1;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void flat_fixup_kernel(int ntiles, int stride,
     s = tail[t];
   }
   s += wave_range_sum(head, k0, k1);
-  if (r >= 0) store_y(y, r, alpha, beta, s);
+  if (r >= 0) store_y(y, yin, r, alpha, beta, s);
 }
 
 } // namespace
@@ -378,11 +378,11 @@ void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P,
   const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
   if (P.early_stream)
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
-                       P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
+                       P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
                        P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
   else
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
-                       P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
+                       P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
                        P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
 }
 // the segmented-scan reduction (reference option FLAT_SEGMENT_SUM_REDUCE): 2048-non-zero tiles, values / colindex under the plan's policy
@@ -391,7 +391,7 @@ void launch_flat_segsum(hipStream_t stream, const CsrDev &A, const FlatPlan &P, 
                         double *y) {
   const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
-                     A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
+                     A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
                      P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
                      static_cast<const int4v *>(P.digest), nullptr);
 }
@@ -400,7 +400,7 @@ template <bool NTC, bool NTV>
 void launch_flat_hint(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x, double *y) {
   const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
-                     A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
+                     A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
                      P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
                      static_cast<const int4v *>(P.digest), A.cold);
 }
@@ -410,7 +410,7 @@ void launch_flat_col16(hipStream_t stream, const CsrDev &A, const FlatPlan &P, d
                        double *y) {
   const Col16Dev c = {P.col16->d16, P.col16->base, P.col16->esc_start, P.col16->esc_cols};
   hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, true, NTV, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
-                     A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, P.head, P.tail, P.tail_row, P.tail_end,
+                     A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
                      P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, c, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
 }
 template <int NPT>
@@ -464,7 +464,7 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
   else launch_flat_policy<8>(stream, A, P, alpha, beta, x, y);
   if (P.ntiles > 1 && P.needs_fixup) {
     hipLaunchKernelGGL(flat_fixup_kernel, dim3((P.ntiles - 1 + 255) / 256), dim3(256), 0, stream, P.ntiles, P.stride,
-                       alpha, beta, P.head, P.tail, P.tail_row, P.tail_end, y);
+                       alpha, beta, P.head, P.tail, P.tail_row, P.tail_end, y, A.yin ? A.yin : y);
   }
 }
 

@@ -72,7 +72,7 @@ template <bool NTC, bool NTV, bool HINT>
 __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, int xcd_chunk, double alpha, double beta,
                                                         const int4v *__restrict__ blk, const int *__restrict__ rp,
                                                         const int *__restrict__ ci, const double *__restrict__ v,
-                                                        const double *__restrict__ x, double *__restrict__ y,
+                                                        const double *__restrict__ x, double *y, const double *yin,
                                                         double *__restrict__ partial, int m,
                                                         const int *__restrict__ guard, int *__restrict__ stale, int reverse,
                                                         const unsigned char *__restrict__ cold) {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
       if (off + kPlusTile < s1) __syncthreads(); // the next round overwrites the tile
     }
     acc = group_sum_dyn(acc, w);
-    if (live && lane == 0) store_y(y, row, alpha, beta, acc);
+    if (live && lane == 0) store_y(y, yin, row, alpha, beta, acc);
   } else {
     // ---- slice [rec.z, rec.w) of the long row `row_begin` ----
     double s = 0.0;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
 __global__ __launch_bounds__(256) void plus_fixup_kernel(int m, int nblocks, double alpha, double beta,
                                                          const int *__restrict__ bp, const int *__restrict__ fbr,
                                                          const double *__restrict__ partial,
-                                                         double *__restrict__ y) {
+                                                         double *y, const double *yin) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   // no early return: every lane of a wave takes part in wave_range_sum
   int r = -1, k0 = 0, k1 = 0;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void plus_fixup_kernel(int m, int nblocks, dou
     }
   }
   const double s = wave_range_sum(partial, k0, k1);
-  if (r >= 0) store_y(y, r, alpha, beta, s);
+  if (r >= 0) store_y(y, yin, r, alpha, beta, s);
 }
 
 } // namespace
@@ -206,7 +206,7 @@ void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *
   if (nblocks <= 0) return;
 #define SPMV_ACC_LAUNCH_PLUS(NC, NV, H)                                                                             \
   hipLaunchKernelGGL((plus_kernel<NC, NV, H>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk, \
-                     alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, partial, A.m, A.guard, A.stale, reverse ? 1 : 0, \
+                     alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, partial, A.m, A.guard, A.stale, reverse ? 1 : 0, \
                      A.cold)
   if (A.cold != nullptr) { // gather hints (kernels.hpp): cold gathers non-temporal
     switch (stream_policy & 3) {
@@ -226,7 +226,7 @@ void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *
 #undef SPMV_ACC_LAUNCH_PLUS
   if (has_long_rows) {
     hipLaunchKernelGGL(plus_fixup_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, A.m, nblocks, alpha, beta,
-                       bp, fbr, partial, y);
+                       bp, fbr, partial, y, A.yin ? A.yin : y);
   }
 }
 

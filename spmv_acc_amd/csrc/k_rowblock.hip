@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
                                                                    const int *__restrict__ ci,
                                                                    const double *__restrict__ v,
                                                                    const double *__restrict__ x,
-                                                                   double *__restrict__ y,
+                                                                   double *y, const double *yin,
                                                                    const int *__restrict__ guard,
                                                                    int *__restrict__ stale,
                                                                    const unsigned char *__restrict__ lens,
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   const bool writer = live && lane == 0;
   double y_old = 0.0;
   const bool early_y = (flags & 2) && beta != 0.0;
-  if (early_y && writer) y_old = y[row]; // (non-temporal y loads / stores were A/B-tested in round 2: no effect on any stand-in)
+  if (early_y && writer) y_old = yin[row]; // (non-temporal y loads / stores were A/B-tested in round 2: no effect on any stand-in)
 
   double acc = 0.0;
   int incl = 0;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   acc = group_sum<VEC>(acc);
   if (writer) {
     if (early_y) y[row] = alpha * acc + beta * y_old;
-    else store_y(y, row, alpha, beta, acc);
+    else store_y(y, yin, row, alpha, beta, acc);
   }
 }
 
@@ -200,7 +200,7 @@ void launch_vec(hipStream_t stream, const CsrDev &A, const RowDigest *D, int rpb
   // 3 colindex nt + values plain)
 #define SPMV_ACC_LAUNCH_RB_H(NC, NV, LN, H)                                                                         \
   hipLaunchKernelGGL((rowblock_stream_kernel<VEC, NC, NV, LN, H>), dim3(nblocks), dim3(kThreads), 0, stream, A.m,   \
-                     A.nnz, nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y, A.guard, A.stale,             \
+                     A.nnz, nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, A.guard, A.stale,             \
                      LN ? D->lens : static_cast<const unsigned char *>(nullptr),                                   \
                      LN ? D->base : static_cast<const int *>(nullptr), cache_ends, A.cold)
 #define SPMV_ACC_LAUNCH_RB(NC, NV)                                                                                  \

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(kThreads) void vector_row_kernel(int m, int row_spl
                                                               double alpha, double beta,
                                                               const int *__restrict__ rp, const int *__restrict__ ci,
                                                               const double *__restrict__ v,
-                                                              const double *__restrict__ x, double *__restrict__ y,
+                                                              const double *__restrict__ x, double *y, const double *yin,
                                                               const int *__restrict__ guard, int *__restrict__ stale) {
   check_plan_guard(rp, m, guard, stale);
   const bool second = static_cast<int>(blockIdx.x) >= nb0;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void vector_row_kernel(int m, int row_spl
 #pragma unroll
   for (int k = 0; k < kVecRows; ++k) {
     const double sum = group_sum_dyn(s[k], w); // every lane takes part (DPP needs a full exec mask)
-    if (live[k] && lane == 0) store_y(y, static_cast<int>(first + static_cast<long long>(k) * groups), alpha, beta, sum);
+    if (live[k] && lane == 0) store_y(y, yin, static_cast<int>(first + static_cast<long long>(k) * groups), alpha, beta, sum);
   }
 }
 
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))
                                                                int rpb1, int xcd_chunk, double alpha, double beta,
                                                                const int *__restrict__ rp, const int *__restrict__ ci,
                                                                const double *__restrict__ v, const double *__restrict__ x,
-                                                               double *__restrict__ y, const int *__restrict__ guard,
+                                                               double *y, const double *yin, const int *__restrict__ guard,
                                                                int *__restrict__ stale, int reverse) {
   check_plan_guard(rp, m, guard, stale);
   __shared__ __attribute__((aligned(16))) double lds[kTile];
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))
   for (int k = 0; k < kVecTileRows; ++k) {
     const double s = group_sum_dyn(acc[k], w); // every lane takes part
     const int row = row_base + vec_id + k * vecs;
-    if (row < row_end && lane == 0) store_y(y, row, alpha, beta, s);
+    if (row < row_end && lane == 0) store_y(y, yin, row, alpha, beta, s);
   }
 }
 
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))
 __global__ __launch_bounds__(kThreads) void wave_row_kernel(int m, int nnz, double alpha, double beta,
                                                             const int *__restrict__ rp, const int *__restrict__ ci,
                                                             const double *__restrict__ v,
-                                                            const double *__restrict__ x, double *__restrict__ y,
+                                                            const double *__restrict__ x, double *y, const double *yin,
                                                             const int *__restrict__ guard, int *__restrict__ stale) {
   check_plan_guard(rp, m, guard, stale);
   const int lane = threadIdx.x & (kWave - 1);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void wave_row_kernel(int m, int nnz, doub
     }
   }
   s = group_sum<64>(s);
-  if (live && lane == 0) store_y(y, row, alpha, beta, s);
+  if (live && lane == 0) store_y(y, yin, row, alpha, beta, s);
 }
 
 // the stale-plan guard's samples: rowptr[k * m / 63], k = 0 .. 63 (same indices as device_utils.hpp::check_plan_guard)
@@ -248,9 +248,9 @@ __global__ __launch_bounds__(kWave) void guard_fill_kernel(const int *__restrict
   guard[threadIdx.x] = rp[static_cast<int>(static_cast<long long>(threadIdx.x) * m / (kWave - 1))];
 }
 
-__global__ __launch_bounds__(kThreads) void scale_y_kernel(int m, double beta, double *__restrict__ y) {
+__global__ __launch_bounds__(kThreads) void scale_y_kernel(int m, double beta, double *y, const double *yin) {
   const long long i = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
-  if (i < m) y[i] = (beta == 0.0) ? 0.0 : beta * y[i];
+  if (i < m) y[i] = (beta == 0.0) ? 0.0 : beta * yin[i];
 }
 
 // Opt-in structural check of the caller's arrays (tunable `validate`): bit 0 rowptr decreases or is negative, bit 1
@@ -312,10 +312,10 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
   if (nb0 + nb1 == 0) return;
   if (rows == 1)
     hipLaunchKernelGGL(vector_row_kernel<1>, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1, alpha, beta,
-                       A.rp, A.ci, A.v, x, y, A.guard, A.stale);
+                       A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, A.guard, A.stale);
   else
     hipLaunchKernelGGL(vector_row_kernel<4>, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1, alpha, beta,
-                       A.rp, A.ci, A.v, x, y, A.guard, A.stale);
+                       A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, A.guard, A.stale);
 }
 
 void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int w0, int w1, double avg0, double avg1,
@@ -337,7 +337,7 @@ void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int 
   if (nb0 + nb1 == 0) return;
 #define SPMV_ACC_LAUNCH_VT(NC, NV)                                                                                    \
   hipLaunchKernelGGL((vector_tile_kernel<NC, NV>), dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, A.nnz, row_split, nb0, \
-                     w0, w1, rpb0, rpb1, xcd_chunk, alpha, beta, A.rp, A.ci, A.v, x, y, A.guard, A.stale, reverse ? 1 : 0)
+                     w0, w1, rpb0, rpb1, xcd_chunk, alpha, beta, A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, A.guard, A.stale, reverse ? 1 : 0)
   switch (stream_policy & 3) {
   case 1: SPMV_ACC_LAUNCH_VT(false, false); break;
   case 2: SPMV_ACC_LAUNCH_VT(false, true); break;
@@ -351,7 +351,7 @@ void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double b
   if (A.m <= 0) return;
   const int grid = ceil_div_ll(A.m, kThreads / kWave);
   hipLaunchKernelGGL(wave_row_kernel, dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci, A.v,
-                     x, y, A.guard, A.stale);
+                     x, y, A.yin ? A.yin : y, A.guard, A.stale);
 }
 
 void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes, bool non_temporal) {
@@ -381,9 +381,9 @@ void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard) {
   hipLaunchKernelGGL(guard_fill_kernel, dim3(1), dim3(kWave), 0, stream, rp, m, d_guard);
 }
 
-void launch_scale_y(hipStream_t stream, int m, double beta, double *y) {
+void launch_scale_y(hipStream_t stream, int m, double beta, double *y, const double *yin) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(scale_y_kernel, dim3(ceil_div_ll(m, kThreads)), dim3(kThreads), 0, stream, m, beta, y);
+  hipLaunchKernelGGL(scale_y_kernel, dim3(ceil_div_ll(m, kThreads)), dim3(kThreads), 0, stream, m, beta, y, yin ? yin : y);
 }
 
 } // namespace spmv_acc

@@ -25,6 +25,9 @@ struct CsrDev {
   // hot lines that fit an L2; the tile kernels (row blocks, row-block-plus, flat) issue those gathers non-temporal.  Null: no hints (set per launch by the
   // engine: only while the plan's timed comparison says they pay, and only where x is below 4 GB).  Speed only.
   const unsigned char *cold = nullptr;
+  // Out-of-place call (spmv_acc_csr_spmv_oop): where the old y is read; null = the y that is written (every reference entry).
+  // Set per call by the engine, under the plan's lock; every launcher passes `yin ? yin : y` to its kernels.
+  const double *yin = nullptr;
 };
 constexpr int kGuardSamples = 64; // rowptr[k * m / 63], k = 0 .. 63 (includes rowptr[0] and rowptr[m] = nnz)
 void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard);
@@ -137,8 +140,8 @@ struct FlatPlan {
   int cache_ends = 0;       // tiles at each end of the grid that stay cacheable under the non-temporal policy (set per launch)
   bool segment_sum = false; // rows reduced by the segmented scan over the tile (reference option FLAT_SEGMENT_SUM_REDUCE), 2048-tile only
   const Col16 *col16 = nullptr; // opt-in: columns from the plan's 16-bit encoding instead of colindex (NPT 8 tiles only)
-  bool mode_tuned = false;  // tuned_fixup holds the timed choice
-  bool tuned_fixup = true;
+  bool mode_tuned[2] = {false, false};  // per beta class ([0]: beta == 0): tuned_fixup holds the timed choice
+  bool tuned_fixup[2] = {true, true};
 };
 // A tile finishes its last row itself when the row ends at most this many non-zeros past the tile (one wave, two
 // unrolled steps).  If any row of the matrix overhangs further, the plan uses head/tail carries and the fix-up kernel
@@ -174,7 +177,7 @@ void plus_analyze_device_emit(hipStream_t stream, const int *rp, int m, int min_
 void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes, bool non_temporal);
 
 // y[i] = beta * y[i] (used for m > 0, nnz == 0 and as a building block)
-void launch_scale_y(hipStream_t stream, int m, double beta, double *y);
+void launch_scale_y(hipStream_t stream, int m, double beta, double *y, const double *yin = nullptr);
 void launch_validate_csr(hipStream_t stream, const CsrDev &A, int *d_flags); // *d_flags pre-zeroed; bits: see kernel
 
 } // namespace spmv_acc

@@ -1,0 +1,75 @@
+"""bench.py's launch contract for N > 1, on CPU (no GPU needed for the launch logic): `python bench.py --gpus N` without
+WORLD_SIZE starts its own N ranks as child processes and relays rank 0's ONE JSON line; launched by torch.distributed.run it
+is an ordinary rank; a failing rank makes the whole call fail.  SPMV_ACC_BENCH_DRYRUN=1 replaces the GPU work by a gloo
+rendezvous + one all-reduce."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SPMV_ACC_BENCH_CHILD")}
+    env.update(kw)
+    return env
+
+
+def test_gpus_n_without_world_size_launches_its_own_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1"], env=_env(SPMV_ACC_BENCH_DRYRUN="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # ONE JSON line on stdout, whatever the launcher and the ranks print elsewhere
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["ranks_sum"] == 3.0  # both ranks took part in the collective
+    assert out["launched_by"] == "self"
+    assert "launching 2 ranks" in r.stderr
+
+
+def test_launched_by_torch_distributed_run_it_is_an_ordinary_rank():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=_env(SPMV_ACC_BENCH_DRYRUN="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["launched_by"] == "external launcher"
+    assert "launching" not in r.stderr  # no second level of ranks
+
+
+def test_a_failing_rank_fails_the_call():
+    """Without the dry-run switch the ranks need a GPU; on a CPU-only host they exit non-zero -- and so must the parent, with no
+    JSON line.  (On a GPU box this test has nothing to show and is skipped.)"""
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("a GPU is present: the ranks would run")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "1"], env=_env(), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_the_parent_of_a_self_launch_never_loads_torch_or_the_library():
+    """The parent must not touch the GPU (a process that has may not start other GPU programs by exec, and must not hold the
+    card while its children need it): it imports neither torch nor spmv_acc_amd."""
+    code = (
+        "import sys, runpy, subprocess\n"
+        "class P:\n"
+        "    def __init__(self, *a, **k):\n"
+        "        bad = [m for m in ('torch', 'spmv_acc_amd') if m in sys.modules]\n"
+        "        print('LOADED', bad)\n"
+        "        raise SystemExit(0)\n"
+        "subprocess.Popen = P\n"
+        f"sys.argv = [{BENCH!r}, '--gpus', '4']\n"
+        f"runpy.run_path({BENCH!r}, run_name='__main__')\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=300)
+    assert "LOADED []" in r.stdout, (r.stdout, r.stderr[-1500:])

@@ -254,10 +254,23 @@ def test_bench_line_carries_every_baseline_config(torch_dev):
     d = json.loads(out[0])
     assert d["n_gpus"] == 1 and d["config"]["strategy"] == "adaptive" and "Hardesty3" in d["config"]["workload"]
     assert set(d["sweep"]) == set(synth.SWEEP_NAMES)
+    def both_protocols(leg, tag):
+        # every figure is quoted on the reference harness's per-launch protocol (y reset, median) with the back-to-back mean beside it
+        assert leg["per_launch_reset_ms_median"] > 0 and leg["back_to_back_ms_mean"] > 0, (tag, leg)
+        assert abs(leg["us"] - 1e3 * leg["per_launch_reset_ms_median"]) <= 0.011, (tag, leg)  # us / frac follow the former
+        assert leg["frac_back_to_back"] > 0
+
     for name, row in d["sweep"].items():
         for strat in ("flat", "adaptive"):
             assert row[strat]["us"] > 0 and 0.05 < row[strat]["frac"] < 1.2, (name, strat, row[strat])
+            both_protocols(row[strat], (name, strat))
+    assert "ge_0.70" in d["sweep_summary"]["flat"] and "ge_0.70_back_to_back" in d["sweep_summary"]["flat"]
     assert d["rmat25"]["nnz"] > 480_000_000 and d["rmat25"]["line_enhance"]["us"] > 1000
+    both_protocols(d["rmat25"]["line_enhance"], "rmat25")
     assert d["banded_shard"]["rows"] == 32_000_000 and 0.3 < d["banded_shard"]["adaptive"]["frac"] < 1.2
+    both_protocols(d["banded_shard"]["adaptive"], "banded_shard")
+    assert d["per_launch_reset_ms_median"] > 0 and d["back_to_back_ms_mean"] > 0
+    assert abs(d["roofline"]["launch_ms_mean"] - d["per_launch_reset_ms_median"]) < 1e-9  # roofline.frac: the reset protocol
+    assert d["roofline"]["back_to_back"]["frac"] > 0 and "builder-run" in d["roofline"]["traffic_source"]
     assert d["roofline"]["traffic"] is not None and d["roofline"]["traffic_lower_bound"] is not None
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1

@@ -1,0 +1,343 @@
+"""GPU suite, round 3 (-m gpu): the out-of-place entry, per-thread library streams, plan work inside a stream capture,
+stale-plan attribution, per-beta-class choices.  Same tolerances as tests/test_gpu_parity.py (scaled error <= 1e-12 against the
+CPU oracle; bit-exact where two library paths must agree)."""
+import threading
+
+import numpy as np
+import pytest
+
+import spmv_acc_amd
+from spmv_acc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SCALED_TOL = 1e-12
+ALL = spmv_acc_amd.STRATEGIES
+
+
+@pytest.fixture(scope="module")
+def torch_dev(hiplib):
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---- out-of-place entry (spmv_acc_csr_spmv_oop) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,m,avg", [("powerlaw", 40000, 9), ("uniform", 60000, 5), ("uniform", 9000, 70), ("longrows", 3000, 40)])
+def test_out_of_place_is_bitwise_the_in_place_result(torch_dev, oracle, hiplib, kind, m, avg):
+    """y_out = alpha*A*x + beta*y_in through every strategy: bit-identical to the in-place entry run on a copy of y_in (same
+    kernels, same sums), y_in untouched, and within tolerance of the oracle.  Flat is run in both of its cut-row forms (carries +
+    fix-up kernel, rows finished in the tile) and adaptive-plus with long rows sliced over blocks -- the kernels that read the old y
+    in a second kernel."""
+    torch = torch_dev
+    if kind == "longrows":
+        rowptr, cols, vals = synth.random_csr(m, 50000, avg, seed=5, kind="uniform")
+        # a few rows of tens of thousands of non-zeros: sliced by adaptive-plus, carried across many flat tiles
+        rng = np.random.default_rng(3)
+        lens = np.diff(rowptr).astype(np.int64)
+        lens[[7, m // 2, m - 2]] = (30000, 9000, 20001)
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        nnz = int(rowptr[-1])
+        cols = rng.integers(0, 50000, nnz).astype(np.int32)
+        vals = rng.standard_normal(nnz)
+        n = 50000
+    else:
+        rowptr, cols, vals = synth.random_csr(m, m, avg, seed=21, kind=kind)
+        n = m
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(8)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    try:
+        for alpha, beta in ((1.0, 1.0), (0.5, -2.0), (2.0, 0.0)):
+            ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+            for strat in ALL:
+                variants = [{}]
+                if strat == "flat":
+                    variants = [{"flat_finish": 0}, {"flat_finish": 1}, {"flat_reduce": 1}]
+                for tun in variants:
+                    for k, v in tun.items():
+                        hiplib.spmv_acc_set_tunable(k.encode(), v)
+                    try:
+                        inplace = dy0.clone()
+                        spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, inplace, strategy=strat)
+                        y_in = dy0.clone()
+                        y_out = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+                        spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y_out, strategy=strat, y_in=y_in)
+                        torch.cuda.synchronize()
+                        tag = (strat, tun, alpha, beta)
+                        assert torch.equal(y_in, dy0), (tag, "y_in was written")
+                        assert torch.equal(y_out, inplace), (tag, "out-of-place differs from in-place")
+                        got = y_out.cpu().numpy()
+                        assert oracle.scaled_error(got, ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL, tag
+                    finally:
+                        hiplib.spmv_acc_reset_tunables()
+    finally:
+        spmv_acc_amd.release_plans(drp)
+
+
+def test_out_of_place_edge_cases(torch_dev, oracle, hiplib):
+    """y_in == y_out is the in-place call; partially overlapping vectors are refused and nothing is written; a matrix without
+    non-zeros scales y_in into y_out; beta == 0 never reads y_in (NaNs there do not reach y_out)."""
+    torch = torch_dev
+    m = n = 5000
+    rowptr, cols, vals = synth.random_csr(m, n, 6, seed=2, kind="uniform")
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(4)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+    try:
+        ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+        y = dev(torch, y0)
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy="adaptive", y_in=y)
+        torch.cuda.synchronize()
+        assert oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL
+        big = torch.zeros(m + 8, dtype=torch.float64, device="cuda")
+        big[:m].copy_(dev(torch, y0))
+        before = big.clone()
+        with pytest.raises(spmv_acc_amd.SpmvAccError, match="overlap"):
+            spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, big[8:], strategy="flat", y_in=big[:m])
+        torch.cuda.synchronize()
+        assert torch.equal(big, before)
+        hiplib.spmv_acc_clear_error()
+        # beta == 0: y_in is not read
+        poison = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+        ref0 = oracle.host_spmv(1.5, 0.0, rowptr, cols, vals, x, y0)
+        for strat in ("adaptive", "flat", "line_enhance", "adaptive_plus", "vector_row", "wf_row"):
+            out = torch.empty(m, dtype=torch.float64, device="cuda")
+            spmv_acc_amd.csr_spmv(1.5, 0.0, m, n, nnz, drp, dci, dv, dx, out, strategy=strat, y_in=poison)
+            torch.cuda.synchronize()
+            assert oracle.scaled_error(out.cpu().numpy(), ref0, 1.5, 0.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, strat
+    finally:
+        spmv_acc_amd.release_plans(drp)
+    # no non-zeros at all: y_out = beta * y_in
+    erp = torch.zeros(m + 1, dtype=torch.int32, device="cuda")
+    eci = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ev = torch.zeros(1, dtype=torch.float64, device="cuda")
+    y_in = dev(torch, y0)
+    y_out = torch.zeros(m, dtype=torch.float64, device="cuda")
+    spmv_acc_amd.csr_spmv(3.0, -0.5, m, n, 0, erp, eci, ev, dx, y_out, strategy="adaptive", y_in=y_in)
+    torch.cuda.synchronize()
+    assert np.array_equal(y_out.cpu().numpy(), -0.5 * y0) and np.array_equal(y_in.cpu().numpy(), y0)
+    spmv_acc_amd.release_plans(erp)
+
+
+# ---- per-thread library stream -----------------------------------------------------------------------------------------------
+def test_two_host_threads_two_streams(torch_dev, oracle, hiplib):
+    """The library stream belongs to the calling host thread.  Two threads, each with its own non-NULL stream and its own matrix,
+    call concurrently (ctypes releases the GIL): every launch lands on its thread's stream -- checked by holding ONE of the streams
+    back with a long sleep kernel: the other thread's results are complete while the held stream's y is still untouched -- and every
+    result is right.  A third thread that never set a stream sees NULL."""
+    torch = torch_dev
+    mats = []
+    for seed, m, avg in ((1, 40000, 7), (2, 52000, 12)):
+        rowptr, cols, vals = synth.random_csr(m, m, avg, seed=seed, kind="powerlaw")
+        rng = np.random.default_rng(seed)
+        x, y0 = rng.standard_normal(m), rng.standard_normal(m)
+        mats.append(dict(rowptr=rowptr, cols=cols, vals=vals, x=x, y0=y0, m=m, nnz=int(rowptr[-1]),
+                         d=[dev(torch, a) for a in (rowptr, cols, vals, x)], dy0=dev(torch, y0)))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    seen_streams, results, errors = [None, None], [None, None], []
+    go = threading.Barrier(2)
+    held = threading.Event()
+
+    def worker(i):
+        try:
+            A = mats[i]
+            drp, dci, dv, dx = A["d"]
+            with torch.cuda.stream(streams[i]):
+                # plans first (first calls synchronise), one strategy of each kernel family
+                for strat in ("adaptive", "flat", "adaptive_plus"):
+                    y = A["dy0"].clone()
+                    spmv_acc_amd.csr_spmv(1.0, 1.0, A["m"], A["m"], A["nnz"], drp, dci, dv, dx, y, strategy=strat)
+                streams[i].synchronize()
+                go.wait()
+                if i == 0:
+                    torch.cuda._sleep(int(2e9))  # ~1 s on this stream only
+                    held.set()
+                else:
+                    held.wait()
+                outs = []
+                for it in range(30):
+                    y = A["dy0"].clone()  # (device-side copy on this thread's stream)
+                    spmv_acc_amd.csr_spmv(1.0, 1.0, A["m"], A["m"], A["nnz"], drp, dci, dv, dx, y,
+                                          strategy=("adaptive", "flat", "adaptive_plus")[it % 3])
+                    outs.append(y)
+                seen_streams[i] = hiplib.spmv_acc_get_stream()
+                if i == 1:
+                    streams[1].synchronize()  # must not wait for stream 0's sleep
+                    results[1] = [o.cpu().numpy() for o in outs]
+                    # stream 0 is still asleep: had thread 0's launches gone to this thread's stream they would be done now
+                    results[0] = "pending" if not streams[0].query() else "stream 0 already idle"
+                else:
+                    streams[0].synchronize()
+                    results[0] = [o.cpu().numpy() for o in outs]
+        except Exception as ex:  # noqa: BLE001
+            errors.append((i, repr(ex)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    ts[1].join()
+    pending_seen = results[0]
+    ts[0].join()
+    try:
+        assert not errors, errors
+        assert pending_seen == "pending", "stream 0 finished before thread 1: the sleep did not hold it (test is void)"
+        assert seen_streams[0] == streams[0].cuda_stream and seen_streams[1] == streams[1].cuda_stream
+        for i in range(2):
+            A = mats[i]
+            ref = oracle.host_spmv(1.0, 1.0, A["rowptr"], A["cols"], A["vals"], A["x"], A["y0"])
+            for got in results[i]:
+                assert oracle.scaled_error(got, ref, 1.0, 1.0, A["rowptr"], A["cols"], A["vals"], A["x"], A["y0"]) <= SCALED_TOL, i
+        other = []
+        t = threading.Thread(target=lambda: other.append(hiplib.spmv_acc_get_stream()))
+        t.start()
+        t.join()
+        assert other == [None]
+    finally:
+        for A in mats:
+            spmv_acc_amd.release_plans(A["d"][0])
+
+
+# ---- plan work inside a stream capture ----------------------------------------------------------------------
+def test_capture_of_an_unprepared_strategy_is_refused_not_broken(torch_dev, oracle, hiplib):
+    """A matrix prepared with strategy A and then captured with strategy B: B's structural plan work (break points, row-block
+    analysis) would allocate and synchronise inside the capture.  The call enqueues nothing and reports
+    SPMV_ACC_ERR_BAD_ARGUMENT naming the cause; the capture itself stays valid (it ends cleanly and replays); after one call of B
+    outside a capture B captures and replays bit-exactly.  Merely missing TIMED choices do not refuse the call: a matrix prepared
+    at beta = 1 captures at beta = 0."""
+    torch = torch_dev
+    m = n = 30000
+    rowptr, cols, vals = synth.random_csr(m, n, 9, seed=77, kind="powerlaw")
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(5)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    side = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(side):
+            spmv_acc_amd.prepare(m, n, nnz, drp, dci, dv, dx, strategy="line_enhance")
+        for other in ("flat", "adaptive_plus", "adaptive"):
+            static_y = dy0.clone()
+            marker = torch.zeros(4, device="cuda")
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                marker.add_(1.0)  # something the capture does record
+                with pytest.raises(spmv_acc_amd.SpmvAccError, match="capture"):
+                    spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, static_y, strategy=other)
+            hiplib.spmv_acc_clear_error()
+            g.replay()
+            torch.cuda.synchronize()
+            assert float(marker[0].item()) == 1.0, "the capture was invalidated"
+            assert torch.equal(static_y, dy0), "a refused call wrote y"
+            # once outside a capture, then it captures
+            with torch.cuda.stream(side):
+                eager = dy0.clone()
+                spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, eager, strategy=other)
+            side.synchronize()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=side):
+                spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, static_y, strategy=other)
+            static_y.copy_(dy0)
+            g2.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(static_y, eager), other
+            # the other beta class was never timed: captured all the same (choices fall back to the timed class)
+            g3 = torch.cuda.CUDAGraph()
+            z = torch.zeros(m, dtype=torch.float64, device="cuda")
+            with torch.cuda.graph(g3, stream=side):
+                spmv_acc_amd.csr_spmv(2.0, 0.0, m, n, nnz, drp, dci, dv, dx, z, strategy=other)
+            g3.replay()
+            torch.cuda.synchronize()
+            ref0 = oracle.host_spmv(2.0, 0.0, rowptr, cols, vals, x, y0)
+            assert oracle.scaled_error(z.cpu().numpy(), ref0, 2.0, 0.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, other
+    finally:
+        hiplib.spmv_acc_set_stream(None)
+        spmv_acc_amd.release_plans(drp)
+
+
+# ---- stale-plan attribution ----------------------------------------------------------------------------------
+def test_stale_plan_is_reported_to_the_thread_that_used_it(torch_dev, hiplib):
+    """spmv_acc_last_error() asks the plan the CALLING thread used last and nothing else: a plan made stale by thread A is not
+    reported to thread B working on another matrix; thread A gets it (after synchronising), and spmv_acc_check_plans() finds it
+    from any thread."""
+    torch = torch_dev
+    m = n = 20000
+
+    def matrix(seed):
+        rp, ci, v = synth.random_csr(m, n, 8, seed=seed, kind="uniform")
+        return rp, ci, v
+
+    rpA, ciA, vA = matrix(1)
+    lens = np.diff(rpA)[::-1].copy()  # same nnz, other structure
+    rpA2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rpB, ciB, vB = matrix(2)
+    dA = [dev(torch, a) for a in (rpA, ciA, vA)]
+    dB = [dev(torch, a) for a in (rpB, ciB, vB)]
+    x = torch.ones(n, dtype=torch.float64, device="cuda")
+    out = {}
+
+    def thread_a():
+        y = torch.zeros(m, dtype=torch.float64, device="cuda")
+        spmv_acc_amd.csr_spmv(1.0, 0.0, m, n, int(rpA[-1]), *dA, x, y, strategy="flat")
+        torch.cuda.synchronize()
+        dA[0].copy_(dev(torch, rpA2))  # structure rewritten in place, no release
+        torch.cuda.synchronize()
+        hiplib.spmv_acc_csr_spmv_strategy(spmv_acc_amd.strategy_id("flat"), 0, 1.0, 0.0, m, n, int(rpA[-1]), None,
+                                          dA[0].data_ptr(), dA[1].data_ptr(), dA[2].data_ptr(), x.data_ptr(), y.data_ptr())
+        torch.cuda.synchronize()
+        out["a_ready"] = True
+
+    def thread_b():
+        y = torch.zeros(m, dtype=torch.float64, device="cuda")
+        spmv_acc_amd.csr_spmv(1.0, 0.0, m, n, int(rpB[-1]), *dB, x, y, strategy="flat")
+        torch.cuda.synchronize()
+        out["b_err"] = hiplib.spmv_acc_last_error()
+        out["b_plans"] = hiplib.spmv_acc_cached_plans()
+
+    try:
+        hiplib.spmv_acc_clear_error()
+        ta = threading.Thread(target=thread_a)
+        ta.start()
+        ta.join()
+        tb = threading.Thread(target=thread_b)
+        tb.start()
+        tb.join()
+        assert out["b_err"] == 0 and out["b_plans"] == 2, out  # thread B: its own plan is fine, A's stale plan is not its business
+        assert hiplib.spmv_acc_last_error() == 0  # nor the main thread's (it has used no plan)
+        assert hiplib.spmv_acc_check_plans() == 1  # the explicit all-plans check finds and drops it
+        assert hiplib.spmv_acc_last_error() == 2 and b"changed" in hiplib.spmv_acc_last_error_string()
+        hiplib.spmv_acc_clear_error()
+        assert hiplib.spmv_acc_cached_plans() == 1
+    finally:
+        hiplib.spmv_acc_clear_error()
+        spmv_acc_amd.release_plans()
+
+
+def test_adaptive_family_is_kept_per_beta_class(torch_dev, hiplib):
+    """adaptive times the kernel families in the caller's beta class and keeps one choice per class (the ranking flips where rows
+    hold one or two non-zeros); spmv_acc_prepare (beta = 1) leaves the beta == 0 class untimed until a beta == 0 call arrives."""
+    torch = torch_dev
+    m = n = 200000
+    rowptr, cols, vals = synth.random_csr(m, n, 2, seed=9, kind="uniform")
+    nnz = int(rowptr[-1])
+    drp, dci, dv = (dev(torch, a) for a in (rowptr, cols, vals))
+    x = torch.ones(n, dtype=torch.float64, device="cuda")
+    try:
+        spmv_acc_amd.prepare(m, n, nnz, drp, dci, dv, x, strategy="adaptive")
+        info = spmv_acc_amd.query_plan(drp, m)
+        assert info["adaptive_family"] in (0, 1, 2)
+        assert hiplib.spmv_acc_query_plan_beta0(drp.data_ptr(), m) == -1
+        y = torch.zeros(m, dtype=torch.float64, device="cuda")
+        spmv_acc_amd.csr_spmv(1.0, 0.0, m, n, nnz, drp, dci, dv, x, y, strategy="adaptive")
+        torch.cuda.synchronize()
+        assert hiplib.spmv_acc_query_plan_beta0(drp.data_ptr(), m) in (0, 1, 2)
+        assert hiplib.spmv_acc_query_plan_beta0(torch.zeros(4, dtype=torch.int32, device="cuda").data_ptr(), 3) == -2
+    finally:
+        spmv_acc_amd.release_plans(drp)
