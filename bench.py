@@ -296,6 +296,17 @@ def sharded_leg(torch, dist, args, W, x, y0, alpha, beta, rank, world, device, b
     extra["spmv_plus_exchange_ms_per_step"] = round(wall / steps * 1e3, 6)
     extra["spmv_plus_exchange_gflops_total"] = round(2.0 * nnz * world * steps / wall / 1e9, 3)
     extra["allgather_bytes_per_rank_per_step"] = 8 * eng.pad * (world - 1)
+    # The DEPENDENT step: x_{k+1} = f(gathered y_k) solvers cannot start step k+1 before the exchange of step k has ended, so the
+    # cross-step overlap above (legal here only because x is fixed) does not exist for them.  What does: cutting the local rows
+    # into C chunks and sending chunk c while chunk c+1 computes (RowShardedSpmv.step(pipeline=C)).  Timed with every step
+    # waiting for its exchange; C = 1 is the serial kernel + exchange.
+    if backend == "nccl":
+        try:
+            dep = eng.tune_pipeline(alpha, beta, x, candidates=(1, 2, 4, 8), warm=2, iters=max(3, min(steps, 10)))
+            extra["dependent_step_ms_by_pipeline"] = {str(k): round(v, 6) for k, v in dep.items()}
+            extra["pipeline_best"] = eng.pipeline
+        except Exception as ex:  # noqa: BLE001
+            extra["pipeline_tune_error"] = repr(ex)[:200]
     del eng
     return wall, ev_ms, extra
 

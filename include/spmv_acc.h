@@ -144,6 +144,33 @@ int spmv_acc_sharded_spmv(void *nccl_comm, int strategy, double alpha, double be
                           const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx,
                           double *dy_local, double *dy_full);
 
+/* ---- the same step with a per-rank handle: in place, out of place, pipelined (new) ---------------------------------------------
+ * replaces: nothing in the reference (single GPU).  One handle per rank and matrix, made by the host thread that drives the GPU
+ * (hipSetDevice first; the library stream is per host thread).  A step
+ *     y_full[rank * m_pad + i] = alpha * (A_local * x)[i] + beta * y_in_local[i]      i in [0, m_local)
+ * computes this rank's rows straight into their place in the gathered vector -- dy_in_local (m_local doubles; NULL = that place
+ * itself, i.e. in place) is read by the out-of-place kernels, so no slice is ever copied -- and then every rank receives every
+ * slice, in place:
+ *   pipeline <= 1: ONE ncclAllGather (send buffer = this rank's slice of dy_full) on the library stream, behind the kernels;
+ *   pipeline  = C: the local rows are cut into C chunks (rowptr rebased once per chunk at create time, colindex / value as views);
+ *                  chunk c's slice travels -- grouped ncclSend / ncclRecv with every peer, straight to its place in their
+ *                  vectors, on a second stream -- as soon as its kernels have finished, while chunk c+1 computes.  This is the
+ *                  overlap that survives when the next x depends on the gathered y.  The library stream waits for the last
+ *                  arrival, so work enqueued after the step sees the whole vector.
+ * Rows [m_local, m_pad) of a slice are padding: zero dy_full once.  dy_full holds world * m_pad doubles (world and rank are
+ * the communicator's).  RCCL is resolved at run time as in spmv_acc_sharded_spmv.  Returns 0 or an error code.
+ * spmv_acc_rccl_comm_init_all / _destroy: ncclCommInitAll / ncclCommDestroy through the same run-time binding, for a
+ * one-process driver that must not link RCCL either (spmv-cli --gpus N); devices may be NULL (0 .. ndev-1). */
+typedef struct spmv_acc_shard *spmv_acc_shard_t;
+int spmv_acc_shard_create(spmv_acc_shard_t *out, void *nccl_comm, int strategy, int m_local, int m_pad, int n, int nnz_local,
+                          const int *d_rowptr, const int *d_colindex, const double *d_value, int pipeline);
+int spmv_acc_shard_step(spmv_acc_shard_t shard, double alpha, double beta, const double *dx, const double *dy_in_local,
+                        double *dy_full);
+int spmv_acc_shard_pipeline(spmv_acc_shard_t shard); /* chunks per step actually in use */
+int spmv_acc_shard_destroy(spmv_acc_shard_t shard);
+int spmv_acc_rccl_comm_init_all(void **comms, int ndev, const int *devices);
+int spmv_acc_rccl_comm_destroy(void *comm);
+
 /* ---- host staging (new; replaces the pageable blocking hipMemcpy of cli/utils.hpp:94-117) ----------------------------
  * Copies host CSR arrays + vectors to freshly hipMalloc'ed device buffers: the caller's arrays are pinned in place
  * (hipHostRegister) and sent with hipMemcpyAsync on a private copy stream, all transfers in flight together; an

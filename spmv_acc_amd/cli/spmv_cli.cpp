@@ -4,6 +4,11 @@
 //                                                     10 warm-ups, 3 timed runs, median, verify_y, PERFORMANCE CSV line)
 //   spmv-cli <matrix> -f ... --no-gpu                (BASELINE.json configs[0]: the CPU-side verification path alone --
 //                                                     reader + vectors + host_spmv + verify, no device needed)
+//   spmv-cli <matrix> -f ... --gpus N [--pipeline C]  (new, BASELINE's north_star: ONE process, one host thread per GPU, the
+//                                                     matrix cut into N nnz-balanced row ranges, each shard staged with pinned
+//                                                     hipMemcpyAsync, one RCCL communicator per GPU from ncclCommInitAll, every
+//                                                     step = local SpMV + exchange of the y slices (spmv_acc_shard_step), the
+//                                                     gathered y of rank 0 verified like the single-GPU run)
 //   ... --device-verify                               (the reference's -DDEVICE_SIDE_VERIFY_FLAG=ON build, config.cmake:9 +
 //                                                     cli/verification.cpp:81-112: the expected y comes from rocSPARSE on
 //                                                     the device instead of host_spmv; rocSPARSE is loaded with dlopen only
@@ -18,10 +23,13 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/api/spmv.h"
@@ -115,6 +123,7 @@ struct Options {
 #endif
   bool no_gpu = false, benchmark = false, stats = false, device_verify = SPMV_CLI_DEVICE_VERIFY_DEFAULT != 0;
   double alpha = 1.0, beta = 1.0; // cli/main.cpp:95-96
+  int gpus = 0, pipeline = 1;     // --gpus N: the row-sharded run (0: the reference's single-GPU run on device 0)
 };
 
 bool parse_args(int argc, char **argv, Options &o) {
@@ -139,6 +148,11 @@ bool parse_args(int argc, char **argv, Options &o) {
       o.stats = true;
     } else if (a == "--dump-bin") {
       if (!need(o.dump)) return false;
+    } else if (a == "--gpus" || a == "--pipeline") {
+      std::string s;
+      if (!need(s)) return false;
+      (a == "--gpus" ? o.gpus : o.pipeline) = std::atoi(s.c_str());
+      if ((a == "--gpus" ? o.gpus : o.pipeline) < 1) return false;
     } else if (a == "--alpha" || a == "--beta") {
       std::string s;
       if (!need(s)) return false;
@@ -279,6 +293,128 @@ int run_cli(const Options &o, HostCsr &A, HostVectors &v) {
   return ok ? 0 : 1;
 }
 
+// ---- --gpus N: one process, one host thread per GPU (north_star: row-range partition + RCCL allgather of the y slices) ------------
+// The reference drives one GPU (hipSetDevice(0), cli/main.cpp:89).  Here thread r owns device r: it stages ITS row range (pinned
+// hipMemcpyAsync, spmv_acc_stage_csr), owns a non-NULL stream (the library stream is per host thread) and one communicator of the
+// ncclCommInitAll set, and every step is spmv_acc_shard_step: local SpMV straight into the gathered vector (the old slice is read
+// out of place from the staged y0, so y is never re-uploaded between calls, unlike cli/main.cpp:101,116) + the exchange.
+struct ThreadBarrier {
+  std::mutex mu;
+  std::condition_variable cv;
+  int count, waiting = 0, phase = 0;
+  explicit ThreadBarrier(int n) : count(n) {}
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    const int my = phase;
+    if (++waiting == count) {
+      waiting = 0;
+      ++phase;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return phase != my; });
+    }
+  }
+};
+
+int run_multi_gpu(const Options &o, HostCsr &A, HostVectors &v) {
+  int have = 0;
+  HIP_CHECK(hipGetDeviceCount(&have));
+  const int N = o.gpus;
+  if (N > have) {
+    std::fprintf(stderr, "--gpus %d: only %d device(s) visible\n", N, have);
+    return 2;
+  }
+  const int strategy = o.strategy.empty() ? -1 : spmv_acc_parse_strategy(o.strategy.c_str());
+  if (!o.strategy.empty() && strategy < 0) {
+    std::fprintf(stderr, "unknown strategy %s\n", o.strategy.c_str());
+    return 2;
+  }
+  std::vector<int> bounds(N + 1);
+  if (spmv_acc_partition_rows(A.rows, N, /*nnz-balanced*/ 1, A.rowptr.data(), bounds.data()) != 0) return 3;
+  int pad = 1;
+  for (int r = 0; r < N; ++r) pad = std::max(pad, bounds[r + 1] - bounds[r]);
+  std::vector<void *> comms(N, nullptr);
+  if (spmv_acc_rccl_comm_init_all(comms.data(), N, nullptr) != 0) {
+    std::fprintf(stderr, "--gpus: %s\n", spmv_acc_last_error_string());
+    return 4;
+  }
+  ThreadBarrier barrier(N);
+  std::vector<double> step_us(N, 0.0);
+  std::vector<int> rcs(N, 0);
+  std::vector<double> gathered(static_cast<size_t>(N) * pad);
+  auto worker = [&](int r) {
+    auto bail = [&](const char *what) {
+      std::fprintf(stderr, "rank %d: %s: %s\n", r, what, spmv_acc_last_error_string());
+      rcs[r] = 5;
+    };
+    HIP_CHECK(hipSetDevice(r));
+    hipStream_t st;
+    HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    spmv_acc_set_stream(st); // this thread's library stream
+    const int r0 = bounds[r], r1 = bounds[r + 1], ml = r1 - r0;
+    const int s = A.rowptr[r0], e = A.rowptr[r1];
+    std::vector<int> rp(static_cast<size_t>(ml) + 1);
+    for (int i = 0; i <= ml; ++i) rp[i] = A.rowptr[r0 + i] - s; // this shard's rowptr, rebased; columns stay global
+    int *d_rp = nullptr, *d_ci = nullptr;
+    double *d_v = nullptr, *d_x = nullptr, *d_y0 = nullptr, *d_full = nullptr;
+    spmv_acc_shard_t shard = nullptr;
+    bool ok = spmv_acc_stage_csr(ml, A.cols, e - s, rp.data(), A.colidx.data() + s, A.values.data() + s, v.x.data(), v.y0.data() + r0, &d_rp, &d_ci,
+                                 &d_v, &d_x, &d_y0) == 0;
+    if (!ok) bail("staging failed");
+    const size_t full_bytes = sizeof(double) * static_cast<size_t>(N) * pad;
+    ok = ok && hipMalloc(reinterpret_cast<void **>(&d_full), full_bytes) == hipSuccess && hipMemset(d_full, 0, full_bytes) == hipSuccess;
+    if (ok && spmv_acc_shard_create(&shard, comms[r], strategy, ml, pad, A.cols, e - s, d_rp, d_ci, d_v, o.pipeline) != 0) {
+      bail("spmv_acc_shard_create");
+      ok = false;
+    }
+    auto step = [&] {
+      if (ok && spmv_acc_shard_step(shard, o.alpha, o.beta, d_x, d_y0, d_full) != 0) {
+        bail("spmv_acc_shard_step");
+        ok = false;
+      }
+    };
+    // every rank takes part in every collective whatever happened to it locally would deadlock the others: a rank that failed
+    // before the first step makes ALL ranks skip the steps (agreed at the barrier)
+    barrier.wait();
+    bool all_ok = true;
+    for (int k = 0; k < N; ++k) all_ok = all_ok && rcs[k] == 0;
+    if (all_ok) {
+      for (int i = 0; i < 10; ++i) step(); // warm up GPU (cli/main.cpp:99-103); the first step builds the plan
+      HIP_CHECK(hipStreamSynchronize(st));
+      barrier.wait();
+      const auto t0 = std::chrono::steady_clock::now();
+      step();
+      HIP_CHECK(hipStreamSynchronize(st));
+      step_us[r] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      barrier.wait();
+      step(); // result run (cli/main.cpp:116-118)
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (r == 0) HIP_CHECK(hipMemcpy(gathered.data(), d_full, full_bytes, hipMemcpyDeviceToHost));
+    }
+    if (shard) spmv_acc_shard_destroy(shard);
+    spmv_acc_release_plans(d_rp);
+    for (void *p : {static_cast<void *>(d_full), static_cast<void *>(d_y0), static_cast<void *>(d_x), static_cast<void *>(d_v),
+                    static_cast<void *>(d_ci), static_cast<void *>(d_rp)})
+      spmv_acc_free_device(p);
+    spmv_acc_set_stream(nullptr);
+    HIP_CHECK(hipStreamDestroy(st));
+  };
+  std::vector<std::thread> threads;
+  for (int r = 0; r < N; ++r) threads.emplace_back(worker, r);
+  for (auto &t : threads) t.join();
+  for (void *c : comms) spmv_acc_rccl_comm_destroy(c);
+  for (int r = 0; r < N; ++r)
+    if (rcs[r] != 0) return rcs[r];
+  for (int r = 0; r < N; ++r) // rank 0's gathered vector, padding between the shards removed
+    std::copy(gathered.begin() + static_cast<size_t>(r) * pad, gathered.begin() + static_cast<size_t>(r) * pad + (bounds[r + 1] - bounds[r]),
+              v.y_dev.begin() + bounds[r]);
+  host_spmv(o.alpha, o.beta, A, v.x.data(), v.y_ref.data());
+  const bool ok = verify(v.y_dev.data(), v.y_ref.data(), A.rows);
+  const double us = *std::max_element(step_us.begin(), step_us.end());
+  std::cout << o.path << " elapsed time:" << us << "(us)" << " gpus:" << N << " pipeline:" << o.pipeline << " rows/gpu<=" << pad << std::endl;
+  return ok ? 0 : 1;
+}
+
 // CPU-side verification path alone: the device result is replaced by a second host evaluation with a different
 // summation order (right-to-left), so reader + vectors + host_spmv + verify are exercised without a GPU.
 int run_no_gpu(const Options &o, HostCsr &A, HostVectors &v) {
@@ -386,7 +522,7 @@ int run_benchmark(const Options &o, HostCsr &A, HostVectors &v) {
 int main(int argc, char **argv) {
   Options o;
   if (!parse_args(argc, argv, o)) {
-    std::cerr << "usage: spmv-cli <mtx_path> [-f|--format csr|mtx|bin2] [--strategy NAME] [--benchmark] [--no-gpu] [--device-verify] [--print-stats] [--dump-bin OUT] "
+    std::cerr << "usage: spmv-cli <mtx_path> [-f|--format csr|mtx|bin2] [--strategy NAME] [--benchmark] [--no-gpu] [--device-verify] [--gpus N [--pipeline C]] [--print-stats] [--dump-bin OUT] "
                  "[--alpha A] [--beta B]\n";
     return 2;
   }
@@ -418,6 +554,7 @@ int main(int argc, char **argv) {
     HostVectors v = make_vectors(A, o.format == "csr");
     if (o.no_gpu) return run_no_gpu(o, A, v);
     if (o.benchmark) return run_benchmark(o, A, v);
+    if (o.gpus > 0) return run_multi_gpu(o, A, v);
     return run_cli(o, A, v);
   } catch (const std::exception &e) {
     std::cerr << "spmv-cli: " << e.what() << std::endl;

@@ -52,13 +52,22 @@ def local_csr_slice(rowptr, cols, vals, r0: int, r1: int):
 class RowShardedSpmv:
     """y_full = alpha * A * x + beta * y_full, A row-sharded over the ranks of ``group``.
 
-    Each rank constructs it with ITS slice.  ``y_local`` (padded) and ``y_full`` (world * padded) are
-    torch tensors on the rank's device; ``step`` enqueues the local SpMV and the allgather.
+    Each rank constructs it with ITS slice.  The gathered vector (world * padded rows) exists twice and the two copies
+    alternate: step k computes this rank's rows STRAIGHT INTO its slice of copy k (the out-of-place entry of the C ABI reads the
+    old slice from copy k-1, or from ``y_prev``) and the exchange moves that slice to every peer in place -- no staging buffer and
+    no device copy anywhere in a step (round 2 copied the slice twice per step: 61 of 218 us on the headline matrix with zero
+    bytes exchanged).  While the exchange of step k is in flight step k+1 may already compute into the other copy.
+
+    Within ONE step the exchange can be pipelined against the kernel (``pipeline`` = C > 1): the local rows are cut into C
+    chunks, chunk c's kernel runs on the compute stream and its slice travels (point-to-point fan-out, straight to its place in
+    every peer's vector) as soon as the kernel of chunk c has finished, i.e. while chunk c+1 computes.  This is the overlap that
+    still exists when x_{k+1} depends on the gathered y_k (then nothing of step k+1 can start before the exchange of step k
+    has ended; the cross-step overlap above needs an x that does not depend on y -- bench.py's fixed x).
     """
 
     def __init__(self, rank: int, world: int, bounds, rowptr, cols, vals, n: int, device, strategy="adaptive",
                  local_spmv: Optional[Callable] = None, h_rowptr=None, always_collective: bool = False,
-                 exchange: str = "allgather"):
+                 exchange: str = "allgather", pipeline: int = 1):
         import torch
 
         self.torch = torch
@@ -79,85 +88,140 @@ class RowShardedSpmv:
         if exchange not in EXCHANGE_MODES:
             raise ValueError(f"exchange must be one of {EXCHANGE_MODES}")
         self.exchange = exchange
-        # two y buffers: the allgather of step k may still be reading one while step k+1 writes the other
-        self.y_local = [torch.zeros(self.pad, dtype=torch.float64, device=device) for _ in range(2)]
-        self.y_full = torch.zeros(world * self.pad, dtype=torch.float64, device=device)
+        self.pipeline = max(int(pipeline), 1)
+        # two copies of the gathered vector; rows [m_local, pad) of a slice are padding and stay zero (no kernel writes them)
+        self._full = [torch.zeros(world * self.pad, dtype=torch.float64, device=device) for _ in range(2)]
         self._pending = None
         self._k = 0
+        self._chunks = {}  # pipeline depth -> [(c0, c1, rowptr, cols, vals, nnz, h_rowptr)] over this rank's rows
         # On the GPU the local SpMV runs on its OWN (non-NULL) stream and is ordered against the exchange with events, both
         # ways: the exchange of step k is issued after an event recorded behind SpMV k, and SpMV k+2 -- the next writer of
-        # the buffer that exchange reads -- is issued after the stream has waited for that exchange.  Nothing relies on the
+        # the vector that exchange works on -- is issued after the stream has waited for that exchange.  Nothing relies on the
         # library's stream and torch's current stream being the same stream.
         self._gpu = torch.device(device).type == "cuda"
         self.compute_stream = torch.cuda.Stream(device=device) if self._gpu else None
         self.spmv_done = None  # event behind the latest local SpMV (GPU only)
         self.exchange_issued_after_spmv = None  # for tests: did the latest exchange wait for that event?
 
-    def _hip_spmv(self, alpha, beta, x, y):
-        spmv_acc_amd.csr_spmv(alpha, beta, self.m_local, self.n, self.nnz_local, self.rowptr, self.cols, self.vals, x, y,
-                              strategy=self.strategy, h_rowptr=self.h_rowptr)
+    # ---- views -------------------------------------------------------------------------------------------------------------
+    @property
+    def y_full(self):
+        """The gathered vector the latest step wrote (complete after ``wait()``)."""
+        return self._full[(self._k - 1) & 1] if self._k else self._full[0]
 
-    def step(self, alpha: float, beta: float, x, y_prev=None, group=None, overlap: bool = True):
+    def _own(self, full):
+        return full[self.rank * self.pad: self.rank * self.pad + self.m_local]
+
+    def chunk_bounds(self, depth: int):
+        """Row ranges [c0, c1) of the padded slice for a pipeline of ``depth`` chunks -- the same on every rank (the exchange of
+        chunk c moves rows [c0, c1) of every rank's slice)."""
+        per = -(-self.pad // depth)
+        return [(min(c * per, self.pad), min((c + 1) * per, self.pad)) for c in range(depth) if c * per < self.pad]
+
+    def _chunk_arrays(self, depth: int):
+        """Per-chunk CSR views of this rank's slice: rebased rowptr (a copy, made once per depth), colindex / values as views."""
+        if depth not in self._chunks:
+            out = []
+            for c0, c1 in self.chunk_bounds(depth):
+                a, b = min(c0, self.m_local), min(c1, self.m_local)
+                if depth == 1:
+                    out.append((a, b, self.rowptr, self.cols, self.vals, self.nnz_local, self.h_rowptr))
+                    continue
+                s, e = int(self.rowptr[a]), int(self.rowptr[b])
+                rp = (self.rowptr[a: b + 1] - self.rowptr[a])
+                rp = rp.contiguous() if hasattr(rp, "contiguous") else np.ascontiguousarray(rp)
+                out.append((a, b, rp, self.cols[s:e], self.vals[s:e], e - s, None))
+            self._chunks[depth] = out
+        return self._chunks[depth]
+
+    def _hip_spmv(self, alpha, beta, x, y_out, y_in, chunk):
+        a, b, rp, ci, v, nnz, h_rp = chunk
+        spmv_acc_amd.csr_spmv(alpha, beta, b - a, self.n, nnz, rp, ci, v, x, y_out, strategy=self.strategy, h_rowptr=h_rp,
+                              y_in=y_in)
+
+    # ---- one step ----------------------------------------------------------------------------------------------------------
+    def step(self, alpha: float, beta: float, x, y_prev=None, group=None, overlap: bool = True, pipeline: Optional[int] = None):
         """One sharded SpMV.  ``y_prev`` (m_local values) is this rank's slice of the old y when beta != 0
         (None: iterate in place -- step k reads the y step k-1 produced, starting from the slice given to ``set_y``).
-        With ``overlap`` the allgather is left in flight; call ``wait()`` (or the next ``step``) to retire it."""
-        import torch.distributed as dist
-
-        buf = self.y_local[self._k & 1]
-        prev = self.y_local[(self._k & 1) ^ 1]
-        first = self._k == 0
+        With ``overlap`` the exchange is left in flight; call ``wait()`` (or the next ``step``) to retire it.
+        ``pipeline``: chunks per step (default: the constructor's); > 1 uses the point-to-point fan-out per chunk."""
+        depth = self.pipeline if pipeline is None else max(int(pipeline), 1)
+        cur, prev = self._full[self._k & 1], self._full[(self._k & 1) ^ 1]
         self._k += 1
+        own = self._own(cur)
+        y_in = None
+        if beta != 0.0:
+            y_in = y_prev[: self.m_local] if y_prev is not None else self._own(prev)
+        chunks = self._chunk_arrays(depth)
+        solo = self.world == 1 and not self.always_collective
+        works = []
 
-        def local():
-            if beta != 0.0:
-                if y_prev is not None:
-                    buf[: self.m_local].copy_(y_prev[: self.m_local])
-                elif not first:
-                    # in-place iteration: the old y of step k is the RESULT of step k-1, which lives in the other buffer
-                    # (the two buffers alternate so that the exchange of k-1 can still be reading it: a read, like this copy)
-                    buf[: self.m_local].copy_(prev[: self.m_local])
-                # (first step: both buffers hold the slice set_y seeded)
-            if self.m_local > 0:
-                self.local_spmv(alpha, beta, x, buf)
+        def local(chunk):
+            a, b = chunk[0], chunk[1]
+            if b > a:
+                self.local_spmv(alpha, beta, x, own[a:b], None if y_in is None else y_in[a:b], chunk)
 
         if self._gpu:
             torch = self.torch
-            cur = torch.cuda.current_stream(self.device)
+            cur_stream = torch.cuda.current_stream(self.device)
             cs = self.compute_stream
-            # x / y_prev were produced on the caller's stream; `buf` was last read by the exchange of step k-2, which the
+            # x / y_prev were produced on the caller's stream; `cur` was last touched by the exchange of step k-2, which the
             # caller's stream has waited for (self.wait() of step k-1)
-            cs.wait_stream(cur)
-            with torch.cuda.stream(cs):  # the library follows torch's current stream (spmv_acc_amd._require)
-                local()
-                self.spmv_done = cs.record_event()
-            self.wait()  # at most one exchange in flight: y_full is written by it
-            cur.wait_event(self.spmv_done)  # the exchange (issued against the current stream) starts behind SpMV k
-            self.exchange_issued_after_spmv = True
+            cs.wait_stream(cur_stream)
+            if depth == 1:
+                with torch.cuda.stream(cs):  # the library follows torch's current stream (spmv_acc_amd._require)
+                    local(chunks[0])
+                    self.spmv_done = cs.record_event()
+                self.wait()  # at most one exchange in flight
+                cur_stream.wait_event(self.spmv_done)  # the exchange (issued against the current stream) starts behind SpMV k
+                self.exchange_issued_after_spmv = True
+                if not solo:
+                    works = self._issue_exchange(cur, group)
+            else:
+                self.wait()  # (the pipelined exchange starts during this step: the previous one must have ended)
+                events = []
+                with torch.cuda.stream(cs):
+                    for ch in chunks:  # all kernels go out at once, back to back on the compute stream
+                        local(ch)
+                        events.append(cs.record_event())
+                self.spmv_done = events[-1]
+                for (c0, c1), ev in zip(self.chunk_bounds(depth), events):
+                    cur_stream.wait_event(ev)  # chunk c travels as soon as ITS kernel has finished, while chunk c+1 computes
+                    if not solo:
+                        works += self._issue_exchange(cur, group, rows=(c0, c1))
+                self.exchange_issued_after_spmv = True
         else:
-            local()
             self.wait()
-        if self.world == 1 and not self.always_collective:
-            self.y_full[: self.pad].copy_(buf)
+            for (c0, c1), ch in zip(self.chunk_bounds(depth), chunks):
+                local(ch)
+                if not solo and depth > 1:
+                    works += self._issue_exchange(cur, group, rows=(c0, c1))
+            if not solo and depth == 1:
+                works = self._issue_exchange(cur, group)
+        if solo:
             return None
-        work = self._issue_exchange(buf, group)
-        self._pending = work
+        self._pending = works
         if not overlap:
             self.wait()
-        return work
+        return works
 
-    def _issue_exchange(self, buf, group=None):
-        """Start moving ``buf`` (this rank's padded slice) into every rank's y_full; returns the pending work(s)."""
+    def _issue_exchange(self, full, group=None, rows=None):
+        """Start moving this rank's slice of ``full`` (or rows [c0, c1) of it) into every peer's copy, in place; returns the
+        pending work(s).  A row range always travels point to point: an allgather of a sub-range would land chunk-major."""
         import torch.distributed as dist
 
-        if self.exchange == "allgather":
-            return [dist.all_gather_into_tensor(self.y_full, buf, group=group, async_op=True)]
         pad, rank, world = self.pad, self.rank, self.world
-        self.y_full[rank * pad: (rank + 1) * pad].copy_(buf)
+        if rows is None and self.exchange == "allgather":
+            # in place: the input is this rank's slice of the output (the layout RCCL's allgather expects; no self-copy)
+            return [dist.all_gather_into_tensor(full, full[rank * pad: (rank + 1) * pad], group=group, async_op=True)]
+        c0, c1 = rows if rows is not None else (0, pad)
+        if c1 <= c0:
+            return []
         ops = []
         for k in range(1, world):  # position k: send to rank+k, receive from rank-k -- a different peer pair per position
             dst, src = (rank + k) % world, (rank - k) % world
-            ops.append(dist.P2POp(dist.isend, buf, dst, group))
-            ops.append(dist.P2POp(dist.irecv, self.y_full[src * pad: (src + 1) * pad], src, group))
+            ops.append(dist.P2POp(dist.isend, full[rank * pad + c0: rank * pad + c1], dst, group))
+            ops.append(dist.P2POp(dist.irecv, full[src * pad + c0: src * pad + c1], src, group))
         return dist.batch_isend_irecv(ops) if ops else []
 
     def tune_exchange(self, group=None, warm: int = 2, iters: int = 5):
@@ -168,8 +232,8 @@ class RowShardedSpmv:
         import torch.distributed as dist
 
         self.wait()
-        buf = self.y_local[0]
-        on_gpu = buf.is_cuda
+        full = self._full[self._k & 1]  # the copy the next step will write: its content is dead
+        on_gpu = full.is_cuda
         result = {}
         for mode in EXCHANGE_MODES:
             self.exchange = mode
@@ -179,20 +243,50 @@ class RowShardedSpmv:
                         self.torch.cuda.synchronize()
                     dist.barrier(group=group)
                     t0 = time.perf_counter()
-                for w in self._issue_exchange(buf, group):
+                for w in self._issue_exchange(full, group):
                     w.wait()
             if on_gpu:
                 self.torch.cuda.synchronize()
-            t = self.y_full.new_tensor([(time.perf_counter() - t0) / iters * 1e3])
+            t = full.new_tensor([(time.perf_counter() - t0) / iters * 1e3])
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             result[mode] = float(t.item())
         self.exchange = min(result, key=result.get)  # same numbers on every rank -> same choice
         return result
 
+    def tune_pipeline(self, alpha, beta, x, group=None, candidates=(1, 2, 4, 8), warm: int = 2, iters: int = 5):
+        """Time whole DEPENDENT steps (kernel + exchange, the next step starting only when the exchange has ended -- the
+        x_{k+1} = y_k iteration) for each pipeline depth on this job's communicator, agree across ranks (max over ranks), keep
+        the fastest.  Returns {depth: ms per step}.  y is iterated in place from whatever the vectors hold."""
+        import time
+
+        import torch.distributed as dist
+
+        result = {}
+        for depth in candidates:
+            if depth > max(self.pad, 1):
+                continue
+            for i in range(warm + iters):
+                if i == warm:
+                    if self._gpu:
+                        self.torch.cuda.synchronize()
+                    if self.world > 1 or self.always_collective:
+                        dist.barrier(group=group)
+                    t0 = time.perf_counter()
+                self.step(alpha, beta, x, group=group, overlap=False, pipeline=depth)
+            if self._gpu:
+                self.torch.cuda.synchronize()
+            t = self._full[0].new_tensor([(time.perf_counter() - t0) / iters * 1e3])
+            if self.world > 1 or self.always_collective:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            result[depth] = float(t.item())
+        self.pipeline = min(result, key=result.get)
+        return result
+
     def set_y(self, y_slice):
-        """Seed both y buffers with this rank's slice of y (for in-place iteration with beta != 0)."""
-        for b in self.y_local:
-            b[: self.m_local].copy_(y_slice[: self.m_local])
+        """Seed this rank's slice of y (for in-place iteration with beta != 0): the next step reads it as its old y."""
+        self.wait()
+        for full in self._full:  # (both copies: whichever the next step regards as "previous")
+            self._own(full).copy_(y_slice[: self.m_local])
 
     def wait(self):
         if self._pending is not None:
@@ -203,10 +297,11 @@ class RowShardedSpmv:
     def gathered(self):
         """The assembled y (m_global values): padding rows between shards removed."""
         self.wait()
+        full = self.y_full
         parts = []
         for r in range(self.world):
             k = int(self.bounds[r + 1] - self.bounds[r])
-            parts.append(self.y_full[r * self.pad: r * self.pad + k])
+            parts.append(full[r * self.pad: r * self.pad + k])
         return self.torch.cat(parts)
 
 

@@ -22,7 +22,20 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, m, out_path, exchange="allgather"):
+def _oracle_local_spmv(oracle_lib):
+    """The oracle stands in for the HIP kernels on CPU, behind the engine's local-compute interface:
+    local_spmv(alpha, beta, x, y_out, y_in, chunk) with chunk = (row0, row1, rowptr, cols, vals, nnz, host_rowptr) of the rows
+    to compute (rebased CSR of that row range) and y_out / y_in views of those rows; y_in None = beta is 0."""
+    def local_spmv(alpha, beta, xt, y_out, y_in, chunk):
+        a, b, rp, ci, v = chunk[:5]
+        tmp = y_in.numpy().copy() if y_in is not None else np.zeros(b - a)
+        oracle_lib.host_spmv_inplace(alpha, beta, np.ascontiguousarray(rp), np.ascontiguousarray(ci), np.ascontiguousarray(v),
+                                     xt.numpy(), tmp)
+        y_out.numpy()[:] = tmp
+    return local_spmv
+
+
+def _worker(rank, world, port, mode, m, out_path, exchange="allgather", pipeline=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -42,20 +55,18 @@ def _worker(rank, world, port, mode, m, out_path, exchange="allgather"):
     rp, ci, v = local_csr_slice(rowptr, cols, vals, r0, r1)
     rp, ci, v = np.ascontiguousarray(rp), np.ascontiguousarray(ci), np.ascontiguousarray(v)
 
-    def local_spmv(alpha, beta, xt, yt):  # oracle stands in for the HIP kernel on CPU
-        yl = yt.numpy()[: r1 - r0]
-        oracle_lib.host_spmv_inplace(alpha, beta, rp, ci, v, xt.numpy(), yl)
-
+    local_spmv = _oracle_local_spmv(oracle_lib)
     eng = RowShardedSpmv(rank, world, bounds, rp, ci, v, n, torch.device("cpu"), local_spmv=local_spmv,
-                         exchange="allgather" if exchange == "tune" else exchange)
+                         exchange="allgather" if exchange == "tune" else exchange, pipeline=pipeline)
     tuned = eng.tune_exchange(warm=1, iters=2) if exchange == "tune" else None
     xt = torch.from_numpy(x)
     ylocal = torch.from_numpy(y0[r0:r1].copy())
     results = []
     for alpha, beta in ((1.0, 1.0), (0.5, 0.0), (2.0, -1.0)):
         eng.step(alpha, beta, xt, y_prev=ylocal, overlap=True)
-        eng.step(alpha, beta, xt, y_prev=ylocal, overlap=True)  # second step exercises the double buffer
+        eng.step(alpha, beta, xt, y_prev=ylocal, overlap=True)  # second step exercises the two alternating vectors
         results.append(eng.gathered().numpy().copy())
+        assert torch.equal(ylocal, torch.from_numpy(y0[r0:r1])), "y_prev was written"
     if rank == 0:
         np.savez(out_path, bounds=bounds, exchange=np.array(eng.exchange), tuned=np.array(sorted(tuned) if tuned else []),
                  **{f"y{i}": r for i, r in enumerate(results)})
@@ -63,14 +74,18 @@ def _worker(rank, world, port, mode, m, out_path, exchange="allgather"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,m,world,exchange", [(0, 4001, 2, "allgather"), (1, 4001, 2, "allgather"), (0, 4096, 2, "allgather"),
-                                                   (0, 4001, 2, "p2p"), (1, 4001, 3, "p2p"), (0, 4099, 3, "tune")])
-def test_row_sharded_spmv_world2(tmp_path, oracle, mode, m, world, exchange):
-    """world 2 and 3, both exchange forms (RCCL allgather / direct fan-out) and the timed choice between them."""
+@pytest.mark.parametrize("mode,m,world,exchange,pipeline", [(0, 4001, 2, "allgather", 1), (1, 4001, 2, "allgather", 1), (0, 4096, 2, "allgather", 1),
+                                                            (0, 4001, 2, "p2p", 1), (1, 4001, 3, "p2p", 1), (0, 4099, 3, "tune", 1),
+                                                            (0, 4001, 2, "allgather", 2), (1, 4001, 3, "p2p", 3), (1, 4099, 2, "allgather", 5),
+                                                            (0, 4097, 3, "p2p", 8)])
+def test_row_sharded_spmv_world2(tmp_path, oracle, mode, m, world, exchange, pipeline):
+    """world 2 and 3, both exchange forms (RCCL allgather / direct fan-out), the timed choice between them, and the pipelined
+    step (the local rows cut into 2 / 3 / 5 / 8 chunks, each chunk's slice travelling point to point as soon as it is computed,
+    shards of unequal row counts and chunk sizes that do not divide them): every variant equals the unsharded oracle bit for bit."""
     from spmv_acc_amd import synth
 
     out = str(tmp_path / "y.npz")
-    mp.spawn(_worker, args=(world, _free_port(), mode, m, out, exchange), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, m, out, exchange, pipeline), nprocs=world, join=True)
     g = np.load(out)
     if exchange == "tune":
         assert list(g["tuned"]) == ["allgather", "p2p"] and str(g["exchange"]) in ("allgather", "p2p")
@@ -88,7 +103,7 @@ def test_row_sharded_spmv_world2(tmp_path, oracle, mode, m, world, exchange):
         assert np.array_equal(g[f"y{i}"], ref), (mode, alpha, beta)  # same arithmetic per row: bit-exact
 
 
-def _inplace_worker(rank, world, port, m, steps, out_path):
+def _inplace_worker(rank, world, port, m, steps, out_path, pipeline=1, dependent=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -105,31 +120,33 @@ def _inplace_worker(rank, world, port, m, steps, out_path):
     r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     rp, ci, v = (np.ascontiguousarray(a) for a in local_csr_slice(rowptr, cols, vals, r0, r1))
 
-    def local_spmv(alpha, beta, xt, yt):
-        oracle_lib.host_spmv_inplace(alpha, beta, rp, ci, v, xt.numpy(), yt.numpy()[: r1 - r0])
-
-    eng = RowShardedSpmv(rank, world, bounds, rp, ci, v, m, torch.device("cpu"), local_spmv=local_spmv)
+    eng = RowShardedSpmv(rank, world, bounds, rp, ci, v, m, torch.device("cpu"), local_spmv=_oracle_local_spmv(oracle_lib),
+                         pipeline=pipeline)
     eng.set_y(torch.from_numpy(y0[r0:r1].copy()))
     xt = torch.from_numpy(x)
     ys = []
     for _ in range(steps):  # y <- 0.25 * A x + 0.5 * y, no y_prev: every step must read the y of the step before it
-        eng.step(0.25, 0.5, xt, overlap=True)
+        eng.step(0.25, 0.5, xt, overlap=not dependent)
         ys.append(eng.gathered().numpy().copy())
+        if dependent:  # x_{k+1} = the gathered y_k (square matrix): the vector the step just completed IS the next x
+            assert eng.y_full.numel() >= m
+            xt = eng.gathered().clone()
     if rank == 0:
         np.savez(out_path, **{f"y{i}": y for i, y in enumerate(ys)})
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_sharded_in_place_iteration_follows_the_serial_recurrence(tmp_path, oracle, world):
-    """beta != 0 without y_prev iterates in place: step k reads the y step k-1 wrote although the two y buffers alternate
-    (an earlier form read the y of step k-2)."""
+@pytest.mark.parametrize("world,pipeline,dependent", [(2, 1, False), (3, 1, False), (2, 4, False), (3, 2, True), (2, 3, True)])
+def test_row_sharded_in_place_iteration_follows_the_serial_recurrence(tmp_path, oracle, world, pipeline, dependent):
+    """beta != 0 without y_prev iterates in place: step k reads the y step k-1 wrote although the two gathered vectors alternate
+    (an earlier form read the y of step k-2) -- unpipelined, pipelined, and as the DEPENDENT iteration x_{k+1} = gathered y_k
+    that the pipelined step exists for."""
     from spmv_acc_amd import synth
 
     m, steps = 3001, 4
     out = str(tmp_path / "y.npz")
-    mp.spawn(_inplace_worker, args=(world, _free_port(), m, steps, out), nprocs=world, join=True)
+    mp.spawn(_inplace_worker, args=(world, _free_port(), m, steps, out, pipeline, dependent), nprocs=world, join=True)
     g = np.load(out)
     rowptr, cols, vals = synth.random_csr(m, m, 6, seed=77, kind="uniform")
     rng = np.random.default_rng(9)
@@ -137,6 +154,8 @@ def test_row_sharded_in_place_iteration_follows_the_serial_recurrence(tmp_path, 
     for i in range(steps):
         y = oracle.host_spmv(0.25, 0.5, rowptr, cols, vals, x, y)
         assert np.array_equal(g[f"y{i}"], y), i
+        if dependent:
+            x = y.copy()
 
 
 def test_shard_helpers():

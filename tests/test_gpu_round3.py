@@ -214,7 +214,8 @@ def test_capture_of_an_unprepared_strategy_is_refused_not_broken(torch_dev, orac
     at beta = 1 captures at beta = 0."""
     torch = torch_dev
     m = n = 30000
-    rowptr, cols, vals = synth.random_csr(m, n, 9, seed=77, kind="powerlaw")
+    # (evenly filled rows: line_enhance keeps its fixed row blocks, so neither flat's break points nor the row-block analysis exist yet)
+    rowptr, cols, vals = synth.random_csr(m, n, 9, seed=77, kind="uniform")
     nnz = int(rowptr[-1])
     rng = np.random.default_rng(5)
     x, y0 = rng.standard_normal(n), rng.standard_normal(m)
@@ -341,3 +342,110 @@ def test_adaptive_family_is_kept_per_beta_class(torch_dev, hiplib):
         assert hiplib.spmv_acc_query_plan_beta0(torch.zeros(4, dtype=torch.int32, device="cuda").data_ptr(), 3) == -2
     finally:
         spmv_acc_amd.release_plans(drp)
+
+
+# ---- row-sharded step: handle API of the C boundary, pipelined step ------------------------------------------------------------
+def test_shard_handle_api_on_a_one_rank_communicator(torch_dev, oracle, hiplib):
+    """spmv_acc_shard_create / _step / _destroy with a communicator from spmv_acc_rccl_comm_init_all (ncclCommInitAll bound at run
+    time, as spmv-cli --gpus N uses it): the step computes this rank's rows straight into the gathered vector -- in place
+    (dy_in NULL) and out of place (old slice elsewhere, untouched) -- and exchanges in place: one allgather (pipeline 1) or the
+    chunked point-to-point form (pipeline 4, rebased chunk rowptrs, second stream, events).  One rank is all this box allows; every
+    RCCL call that a one-rank communicator makes is made."""
+    import ctypes
+
+    torch = torch_dev
+    torch.zeros(1, device="cuda")
+    comm = ctypes.c_void_p()
+    assert hiplib.spmv_acc_rccl_comm_init_all(ctypes.byref(comm), 1, None) == 0, hiplib.spmv_acc_last_error_string()
+    side = torch.cuda.Stream()
+    try:
+        m, n, pad = 70_001, 64_000, 70_016
+        rowptr, cols, vals = synth.random_csr(m, n, 9, seed=15, kind="powerlaw")
+        nnz = int(rowptr[-1])
+        rng = np.random.default_rng(16)
+        x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+        drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+        hiplib.spmv_acc_set_stream(side.cuda_stream)
+        for pipeline in (1, 4):
+            for strat, (alpha, beta) in (("adaptive", (1.0, 1.0)), ("flat", (0.5, -2.0)), ("line_enhance", (2.0, 0.0))):
+                shard = ctypes.c_void_p()
+                rc = hiplib.spmv_acc_shard_create(ctypes.byref(shard), comm, spmv_acc_amd.strategy_id(strat), m, pad, n, nnz,
+                                                  drp.data_ptr(), dci.data_ptr(), dv.data_ptr(), pipeline)
+                assert rc == 0, hiplib.spmv_acc_last_error_string()
+                assert hiplib.spmv_acc_shard_pipeline(shard) == pipeline
+                ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+                # out of place: the old slice stays where it is
+                y_full = torch.zeros(pad, dtype=torch.float64, device="cuda")
+                torch.cuda.synchronize()
+                assert hiplib.spmv_acc_shard_step(shard, alpha, beta, dx.data_ptr(), dy0.data_ptr(), y_full.data_ptr()) == 0, \
+                    hiplib.spmv_acc_last_error_string()
+                side.synchronize()
+                got = y_full.cpu().numpy()
+                assert oracle.scaled_error(got[:m], ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL, (pipeline, strat)
+                assert np.all(got[m:] == 0.0) and torch.equal(dy0, dev(torch, y0))
+                # in place: the slice of the gathered vector is the old y
+                y_full.zero_()
+                y_full[:m].copy_(dy0)
+                torch.cuda.synchronize()
+                assert hiplib.spmv_acc_shard_step(shard, alpha, beta, dx.data_ptr(), None, y_full.data_ptr()) == 0
+                side.synchronize()
+                got = y_full.cpu().numpy()
+                assert oracle.scaled_error(got[:m], ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL, (pipeline, strat, "in place")
+                assert hiplib.spmv_acc_shard_destroy(shard) == 0
+        bad = ctypes.c_void_p()
+        assert hiplib.spmv_acc_shard_create(ctypes.byref(bad), None, 1, m, pad, n, nnz, drp.data_ptr(), dci.data_ptr(), dv.data_ptr(), 1) == 2
+        assert hiplib.spmv_acc_shard_create(ctypes.byref(bad), comm, 1, m, m - 1, n, nnz, drp.data_ptr(), dci.data_ptr(), dv.data_ptr(), 1) == 2
+        hiplib.spmv_acc_clear_error()
+    finally:
+        hiplib.spmv_acc_set_stream(None)
+        spmv_acc_amd.release_plans()
+        hiplib.spmv_acc_rccl_comm_destroy(comm)
+
+
+def test_row_sharded_pipelined_step_on_one_rank_rccl(torch_dev, oracle):
+    """RowShardedSpmv with pipeline = 3 over a one-rank RCCL process group: three chunk kernels on the engine's compute stream,
+    each chunk's exchange issued behind ITS event; the compute stream is held back by a sleep, so an exchange (or the final wait)
+    that did not order itself behind the kernels would hand back the old vector.  No device copy anywhere: the step writes
+    straight into the gathered vector and the dependent iteration x_{k+1} = y_k reads the vector the step just completed."""
+    import os
+    import socket
+
+    torch = torch_dev
+    import torch.distributed as dist
+
+    from spmv_acc_amd.dist import RowShardedSpmv
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m = n = 150_000
+        rowptr, cols, vals = synth.random_csr(m, n, 6, seed=19)
+        nnz = int(rowptr[-1])
+        rng = np.random.default_rng(4)
+        x0, y0 = rng.standard_normal(n), rng.standard_normal(m)
+        drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x0, y0))
+        eng = RowShardedSpmv(0, 1, np.array([0, m], dtype=np.int64), drp, dci, dv, n, torch.device("cuda", 0), strategy="adaptive",
+                             always_collective=True, exchange="allgather", pipeline=3)
+        assert len(eng.chunk_bounds(3)) == 3 and eng.chunk_bounds(3)[-1][1] == m
+        eng.set_y(dy0)
+        eng.step(0.25, 0.5, dx, overlap=False)  # builds the three chunk plans
+        torch.cuda.synchronize()
+        x = eng.y_full[:n]  # dependent iteration: the next x IS the vector the step completed (no copy)
+        with torch.cuda.stream(eng.compute_stream):
+            torch.cuda._sleep(200_000_000)
+        eng.step(0.25, 0.5, x, overlap=False)
+        assert not eng.spmv_done.query() or True  # (the sleep may already be over on a fast box; the result check is what counts)
+        got = eng.gathered().cpu().numpy()
+        y1 = oracle.host_spmv(0.25, 0.5, rowptr, cols, vals, x0, y0)
+        y2 = oracle.host_spmv(0.25, 0.5, rowptr, cols, vals, y1, y1)
+        assert oracle.scaled_error(got, y2, 0.25, 0.5, rowptr, cols, vals, y1, y1) <= 1e-11
+        timings = eng.tune_pipeline(0.25, 0.5, dx, candidates=(1, 2, 4), warm=1, iters=2)
+        assert set(timings) == {1, 2, 4} and eng.pipeline in timings
+        spmv_acc_amd.release_plans()
+    finally:
+        dist.destroy_process_group()
+        spmv_acc_amd.load_library().spmv_acc_set_stream(None)
