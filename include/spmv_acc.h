@@ -192,6 +192,23 @@ int spmv_acc_free_device(void *p);
  * csr_adaptive_plus_spmv.cpp:104-125). */
 int spmv_acc_prepare(int strategy, int m, int n, int nnz, const int *h_rowptr, const int *d_rowptr, const int *d_colindex,
                      const double *d_value, const double *dx, float *ms_out);
+/* The same for the beta class the caller will run in: the choices that depend on whether y is read (stream cache policy,
+ * adaptive's kernel family, flat's cut-row form) are timed and kept PER CLASS (beta == 0: y only written; beta != 0: read too).
+ * spmv_acc_prepare is the beta != 0 class (the reference's protocol, alpha = beta = 1).  A class that was never prepared is
+ * timed by its first call -- or, inside a stream capture, runs with the other class' choices. */
+int spmv_acc_prepare_beta(int strategy, double beta, int m, int n, int nnz, const int *h_rowptr, const int *d_rowptr,
+                          const int *d_colindex, const double *d_value, const double *dx, float *ms_out);
+
+/* ---- persistent choices + the deterministic switch (new) -------------------------------------------------------------------
+ * The reference's strategy choice is a pure function of its inputs (strategy_picker.cpp:19-65, adaptive.cpp:24-66) and costs
+ * nothing; this library times a handful of choices on each matrix' first call (cache policy, kernel family, tile geometry: up
+ * to 13 ms on the headline matrix), per process.  Two opt-in ways out:
+ *   spmv_acc_set_tune_cache(path) / environment SPMV_ACC_TUNE_CACHE=<file>: the choices are appended to a text file, one line per
+ *     matrix, keyed by a digest of (library version, device name, m, n, nnz, 64 rowptr samples); a later process that meets the
+ *     same matrix on the same device adopts them and only runs the structural passes (NULL or "" switches it off);
+ *   tunable "deterministic" = 1 / environment SPMV_ACC_DETERMINISTIC=1: nothing is timed at all, every choice follows a fixed
+ *     rule on the matrix' shape -- y is then bitwise equal across processes and runs (the kernels never use atomics). */
+void spmv_acc_set_tune_cache(const char *path);
 
 /* Host microseconds the calling thread's most recent SpMV call spent preparing its matrix (structural passes + per-matrix
  * timings of the FIRST call on a matrix); 0 when the plan already existed.

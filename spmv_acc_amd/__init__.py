@@ -38,7 +38,8 @@ C_ABI_SYMBOLS = (
     "spmv_acc_get_tunable", "spmv_acc_reset_tunables", "spmv_acc_time_spmv_total", "spmv_acc_copy_ceiling_gbs", "spmv_acc_adaptive_plus_analyze_device", "spmv_acc_prepare",
     "spmv_acc_last_prepare_us", "spmv_acc_sharded_spmv", "spmv_acc_csr_spmv_oop", "spmv_acc_check_plans",
     "spmv_acc_query_plan_beta0", "spmv_acc_shard_create", "spmv_acc_shard_step", "spmv_acc_shard_pipeline",
-    "spmv_acc_shard_destroy", "spmv_acc_rccl_comm_init_all", "spmv_acc_rccl_comm_destroy",
+    "spmv_acc_shard_destroy", "spmv_acc_rccl_comm_init_all", "spmv_acc_rccl_comm_destroy", "spmv_acc_set_tune_cache",
+    "spmv_acc_prepare_beta",
 )
 
 _lib = None
@@ -117,6 +118,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_shard_destroy.argtypes = [vp]
     lib.spmv_acc_rccl_comm_init_all.argtypes = [ctypes.POINTER(vp), ci, vp]
     lib.spmv_acc_rccl_comm_destroy.argtypes = [vp]
+    lib.spmv_acc_set_tune_cache.argtypes = [ctypes.c_char_p]
+    lib.spmv_acc_set_tune_cache.restype = None
+    lib.spmv_acc_prepare_beta.argtypes = [ci, cd, ci, ci, ci, vp, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     if path is None:
         _lib = lib
     return lib
@@ -218,14 +222,15 @@ def csr_spmv(alpha: float, beta: float, m: int, n: int, nnz: int, rowptr, colind
     _check(lib)
 
 
-def prepare(m: int, n: int, nnz: int, rowptr, colindex, value, x, strategy=None, h_rowptr=None) -> float:
-    """Build the plan of ``strategy`` for this matrix (structural passes + per-matrix timings) without touching any y.
-    Returns the device milliseconds it took."""
+def prepare(m: int, n: int, nnz: int, rowptr, colindex, value, x, strategy=None, h_rowptr=None, beta: float = 1.0) -> float:
+    """Build the plan of ``strategy`` for this matrix (structural passes + per-matrix timings) without touching any y, for the
+    beta class the caller will run in (beta == 0 / beta != 0).  Returns the device milliseconds it took."""
     lib = load_library()
     _csr_args(lib, m, n, nnz, rowptr, colindex, value, x)
     ms = ctypes.c_float(0.0)
     sid = lib.spmv_acc_get_strategy() if strategy is None else strategy_id(strategy)
-    rc = lib.spmv_acc_prepare(sid, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr), _ptr(colindex), _ptr(value), _ptr(x), ctypes.byref(ms))
+    rc = lib.spmv_acc_prepare_beta(sid, beta, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr), _ptr(colindex), _ptr(value), _ptr(x),
+                                   ctypes.byref(ms))
     if rc != 0:
         _check(lib)
     return float(ms.value)
@@ -336,6 +341,11 @@ def copy_ceiling_gbs(dst, src, reps: int = 5) -> float:
 
 def release_plans(rowptr=None) -> None:
     load_library().spmv_acc_release_plans(_ptr(rowptr))
+
+
+def set_tune_cache(path: Optional[str]) -> None:
+    """Persist the per-matrix timed choices in ``path`` (None: off); see include/spmv_acc.h."""
+    load_library().spmv_acc_set_tune_cache(path.encode() if path else None)
 
 
 def check_plans() -> int:

@@ -311,8 +311,15 @@ int spmv_acc_last_error(void) { return last_error(); }
 const char *spmv_acc_last_error_string(void) { return last_error_string(); }
 void spmv_acc_clear_error(void) { clear_error(); }
 
+void spmv_acc_set_tune_cache(const char *path) { set_tune_cache(path); }
+
 int spmv_acc_prepare(int strategy, int m, int n, int nnz, const int *h_rowptr, const int *d_rowptr, const int *d_colindex,
                      const double *d_value, const double *dx, float *ms_out) {
+  return spmv_acc_prepare_beta(strategy, 1.0, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, ms_out);
+}
+
+int spmv_acc_prepare_beta(int strategy, double beta, int m, int n, int nnz, const int *h_rowptr, const int *d_rowptr,
+                          const int *d_colindex, const double *d_value, const double *dx, float *ms_out) {
   if (m <= 0) return kOk;
   hipStream_t st = get_stream();
   double *scratch = nullptr;
@@ -324,10 +331,11 @@ int spmv_acc_prepare(int strategy, int m, int n, int nnz, const int *h_rowptr, c
   const bool timed = ms_out && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
   clear_error();
   if (timed) (void)hipEventRecord(e0, st);
-  // the caller's y is not involved: the first call runs into a zeroed scratch, with beta = 1 (the reference's protocol and the
-  // usual case) so that choices which depend on whether y is read (adaptive's kernel family) are made for that case
+  // the caller's y is not involved: the first call runs into a zeroed scratch, in the caller's beta CLASS (beta == 0: y is only
+  // written; else it is read too) -- the choices that depend on the y read (cache policy, adaptive's kernel family, flat's cut-row
+  // form) are timed and kept per class.  spmv_acc_prepare = beta 1, the reference's protocol.
   (void)hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(m), st);
-  run_spmv(strategy, 0, 1.0, 1.0, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, scratch);
+  run_spmv(strategy, 0, 1.0, beta != 0.0 ? 1.0 : 0.0, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, scratch);
   if (timed) (void)hipEventRecord(e1, st);
   int rc = hipStreamSynchronize(st) == hipSuccess ? kOk : kErrHip;
   if (timed && rc == kOk && hipEventElapsedTime(ms_out, e0, e1) != hipSuccess) rc = kErrHip;

@@ -89,7 +89,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kTunableCount
 };
 #ifdef FLAT_SEGMENT_SUM_REDUCE
 constexpr int kFlatReduceBuilt = 1;
@@ -148,6 +148,12 @@ Tunable g_tunables[] = {
     {"hint_budget_kb", 4608, 4608}, // size of the hot set of x lines the census keeps cacheable.  An XCD's L2 is 4 MB; measured on R-MAT scale 25
                                // (8.17-8.21 ms without hints): 1 MB 9.43, 2 MB 8.33, 3 MB 7.71, 3.5 MB 7.35, 4 MB 7.06-7.25, 4.5 MB 7.21, 5 MB 7.19,
                                // 6 MB 7.25, 8 MB 7.70, 16 MB 7.94 ms -- a hot set smaller than what LRU keeps by itself loses, one around the L2 size wins
+    {"deterministic", 0, 0},   // 1 (also: environment SPMV_ACC_DETERMINISTIC=1): NOTHING is timed.  Every choice the engine otherwise makes
+                               // by timing on the matrix -- stream cache policy, adaptive's kernel family, flat's cut-row form / tile
+                               // size / staging order, the row-block-plus block size, gather hints -- follows a fixed rule on the
+                               // matrix' shape instead (strategy_picker.cpp:19-65: the reference's choice is a pure function of its
+                               // inputs), so two processes run the same kernels in the same configuration and y is bitwise equal
+                               // across processes and runs.  Costs the per-matrix optimum (a few per cent on most stand-ins)
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -159,6 +165,8 @@ namespace {
 // SPMV_ACC_TUNABLES="validate=1,flat_finish=0": initial values for a process that cannot call spmv_acc_set_tunable
 // (the reference's executables linked against this library).  Read once, before the first lookup.
 void apply_env_tunables_once() {
+  if (const char *det = std::getenv("SPMV_ACC_DETERMINISTIC"))
+    if (*det && *det != '0') g_tunables[kT_deterministic].val = g_tunables[kT_deterministic].def = 1;
   const char *env = std::getenv("SPMV_ACC_TUNABLES");
   if (!env) return;
   std::string s(env);
@@ -508,6 +516,10 @@ struct Plan {
   Col16 col16;                  // opt-in 16-bit column encoding (tunable col16), built on first use
   int flat_npt_choice = 0;      // timed tile size (non-zeros per lane), 0 = not timed
   bool flat_geometry_tuned = false;
+  bool flat_early_choice = false;      // timed staging order (kept here as well: a FlatPlan is rebuilt when the tile size changes)
+  int flat_mode_choice[2] = {-1, -1};  // timed cut-row form per beta class: -1 not timed, 0 tiles finish their cut rows, 1 carries + fix-up
+  // persistent choices (tune cache): key of this matrix on this device, 0 = none
+  unsigned long long tune_key = 0;
   // row-block-plus
   int plus_blocks = -1;
   int plus_vec = 0;
@@ -571,6 +583,148 @@ struct Plan {
     flat_tiles = -1;
   }
 };
+
+// ---- tune cache: the per-matrix timed choices, kept across processes --------------------------------------------------------
+// The first call on a matrix times a handful of choices (13 ms on the headline matrix, 85 SpMVs' worth) and every process pays
+// again; the reference's choice is a pure function of its inputs (strategy_picker.cpp:19-65) and costs nothing.  With
+// SPMV_ACC_TUNE_CACHE=<file> (or spmv_acc_set_tune_cache) the choices are appended to a text file, one line per matrix, keyed by a
+// digest of (library version, device name, m, n, nnz, the 64 rowptr samples of the stale-plan guard); a later process that meets
+// the same matrix on the same device adopts them and only runs the structural passes.  Opt-in; the last line for a key wins;
+// a choice the current build cannot honour (a cut-row form that is not legal on this matrix) falls back to the safe one.
+struct TuneRecord {
+  int v[20]; // stream_policy[4][2], adaptive_family[2], flat_npt, flat_early, flat_geometry_tuned, flat_mode[2], plus_min, hint_state0, hint_use[4] (first 3)
+  bool operator==(const TuneRecord &o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
+};
+constexpr int kTuneFields = 20;
+std::mutex g_tune_mu;
+std::string g_tune_path;
+bool g_tune_path_set = false, g_tune_loaded = false;
+std::map<unsigned long long, TuneRecord> g_tune_db;
+
+void tune_load_locked() {
+  if (!g_tune_path_set) {
+    if (const char *e = std::getenv("SPMV_ACC_TUNE_CACHE")) g_tune_path = e;
+    g_tune_path_set = true;
+  }
+  if (g_tune_loaded || g_tune_path.empty()) return;
+  g_tune_loaded = true;
+  if (FILE *f = std::fopen(g_tune_path.c_str(), "r")) {
+    char tag[32];
+    unsigned long long key;
+    while (std::fscanf(f, "%31s %llx", tag, &key) == 2) {
+      TuneRecord r;
+      bool ok = std::strcmp(tag, "spmvacc1") == 0;
+      for (int i = 0; i < kTuneFields; ++i) ok = (std::fscanf(f, "%d", &r.v[i]) == 1) && ok;
+      if (ok) g_tune_db[key] = r;
+    }
+    std::fclose(f);
+  }
+}
+bool tune_cache_enabled() {
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  tune_load_locked();
+  return !g_tune_path.empty();
+}
+unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *samples) {
+  unsigned long long h = 1469598103934665603ULL; // FNV-1a
+  auto mix = [&h](const void *p, size_t bytes) {
+    const unsigned char *c = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < bytes; ++i) h = (h ^ c[i]) * 1099511628211ULL;
+  };
+  static const char kVersion[] = "spmv_acc_amd 0.3 tune v1";
+  mix(kVersion, sizeof(kVersion));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+    mix(prop.name, strnlen(prop.name, sizeof(prop.name)));
+    mix(prop.gcnArchName, strnlen(prop.gcnArchName, sizeof(prop.gcnArchName)));
+    mix(&prop.multiProcessorCount, sizeof(int));
+  }
+  (void)hipGetLastError();
+  mix(&m, sizeof(int));
+  mix(&n, sizeof(int));
+  mix(&nnz, sizeof(int));
+  mix(samples, sizeof(int) * kGuardSamples);
+  return h ? h : 1;
+}
+
+void tune_log(const char *fmt, ...);
+TuneRecord tune_snapshot(const Plan &p) {
+  TuneRecord r;
+  int k = 0;
+  for (int f = 0; f < kFamilyCount; ++f)
+    for (int c = 0; c < 2; ++c) r.v[k++] = p.stream_policy[f][c];
+  r.v[k++] = p.adaptive_family[0];
+  r.v[k++] = p.adaptive_family[1];
+  r.v[k++] = p.flat_npt_choice;
+  r.v[k++] = p.flat_early_choice ? 1 : 0;
+  r.v[k++] = p.flat_geometry_tuned ? 1 : 0;
+  r.v[k++] = p.flat_mode_choice[0];
+  r.v[k++] = p.flat_mode_choice[1];
+  r.v[k++] = p.plus_tuned_min;
+  r.v[k++] = p.hint_state == 0 ? 0 : -1; // only "the census found nothing to protect" is worth keeping: the bits themselves are rebuilt
+  for (int f = 0; f < 3; ++f) r.v[k++] = p.hint_use[f];
+  return r;
+}
+} // namespace
+void set_tune_cache(const char *path) {
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  g_tune_path = path ? path : "";
+  g_tune_path_set = true;
+  g_tune_loaded = false;
+  g_tune_db.clear();
+}
+namespace {
+// a fresh plan adopts what an earlier process (or an earlier plan of this process) measured on the same matrix
+void tune_adopt(Plan &p) {
+  TuneRecord r;
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tune_db.find(p.tune_key);
+    if (it == g_tune_db.end()) return;
+    r = it->second;
+  }
+  auto in = [](int v, int lo, int hi) { return v >= lo && v <= hi; };
+  int k = 0;
+  for (int f = 0; f < kFamilyCount; ++f)
+    for (int c = 0; c < 2; ++c, ++k) p.stream_policy[f][c] = in(r.v[k], 0, 3) ? r.v[k] : -1;
+  p.adaptive_family[0] = in(r.v[k], 0, 2) ? r.v[k] : -1;
+  ++k;
+  p.adaptive_family[1] = in(r.v[k], 0, 2) ? r.v[k] : -1;
+  ++k;
+  p.flat_npt_choice = (r.v[k] == 4 || r.v[k] == 8) ? r.v[k] : 0;
+  ++k;
+  p.flat_early_choice = r.v[k++] == 1;
+  p.flat_geometry_tuned = r.v[k++] == 1 && p.flat_npt_choice > 0;
+  p.flat_mode_choice[0] = in(r.v[k], 0, 1) ? r.v[k] : -1;
+  ++k;
+  p.flat_mode_choice[1] = in(r.v[k], 0, 1) ? r.v[k] : -1;
+  ++k;
+  p.plus_tuned_min = (r.v[k] == 1024 || r.v[k] == 1536 || r.v[k] == 1920) ? r.v[k] : 0;
+  ++k;
+  if (r.v[k++] == 0) p.hint_state = 0;
+  for (int f = 0; f < 3; ++f, ++k) p.hint_use[f] = in(r.v[k], 0, 1) ? r.v[k] : -1;
+  tune_log("m %d nnz %d: choices adopted from the tune cache (key %016llx)", p.A.m, p.A.nnz, p.tune_key);
+}
+// after a call that did plan work: keep what the plan now knows
+void tune_store(const Plan &p) {
+  if (!p.tune_key) return;
+  const TuneRecord r = tune_snapshot(p);
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  if (g_tune_path.empty()) return;
+  auto it = g_tune_db.find(p.tune_key);
+  if (it != g_tune_db.end() && it->second == r) return;
+  g_tune_db[p.tune_key] = r;
+  if (FILE *f = std::fopen(g_tune_path.c_str(), "a")) { // one line, one write: concurrent processes interleave whole lines
+    std::string line = "spmvacc1 ";
+    char buf[32];
+    std::snprintf(buf, sizeof(buf), "%016llx", p.tune_key);
+    line += buf;
+    for (int i = 0; i < kTuneFields; ++i) line += " " + std::to_string(r.v[i]);
+    line += "\n";
+    std::fwrite(line.data(), 1, line.size(), f);
+    std::fclose(f);
+  }
+}
 
 std::map<PlanKey, std::shared_ptr<Plan>> g_plans; // a running call keeps its plan alive through its own reference
 thread_local std::weak_ptr<Plan> t_last_plan;     // the plan this thread's latest run_spmv used (last_error asks it, and only it)
@@ -689,6 +843,14 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
   if (p->guard_slot >= 0) {
     launch_guard_fill(t_stream, rp, m, const_cast<int *>(p->A.guard));
     if (!hip_ok(hipStreamSynchronize(t_stream), "record the plan guard")) return nullptr; // (a later call may use another stream)
+    if (tune_cache_enabled() && !tun(kT_deterministic)) {
+      int samples[kGuardSamples];
+      if (hipMemcpy(samples, p->A.guard, sizeof(samples), hipMemcpyDeviceToHost) == hipSuccess) {
+        p->tune_key = tune_key_of(dev, m, n, nnz, samples);
+        tune_adopt(*p);
+      }
+      (void)hipGetLastError();
+    }
   }
   g_plans[key] = p;
   return p;
@@ -798,6 +960,13 @@ bool ensure_flat(Plan &p, hipStream_t stream) {
   p.flat_tiles = -1;
   if (!build_flat_plan(p.A, stride, stream, p.flat)) return false;
   p.flat_tiles = p.flat.ntiles;
+  // choices this matrix already has (timed earlier on a plan of another tile size, or loaded from the tune cache)
+  if (p.flat_geometry_tuned) p.flat.early_stream = p.flat_early_choice && stride != kThreads * 16;
+  for (int c = 0; c < 2; ++c) {
+    if (p.flat_mode_choice[c] < 0) continue;
+    p.flat.mode_tuned[c] = true;
+    p.flat.tuned_fixup[c] = p.flat_mode_choice[c] == 1 || !p.flat.can_finish;
+  }
   return true;
 }
 
@@ -938,6 +1107,9 @@ inline double trial_beta() { return t_beta_class ? 1.0 : 0.0; }
 int policy_for(const Plan &p, int fam) {
   const int forced = tun(kT_stream_plain);
   if (forced >= 0) return forced & 3;
+  // deterministic: the rule the timings follow on most matrices -- short rows (the vectors and rowptr are worth more cache than
+  // the matrix) stream non-temporally, everything else with the default policy
+  if (tun(kT_deterministic)) return static_cast<long long>(p.A.nnz) <= 8LL * p.A.m ? kStreamPolicyNt : kStreamPolicyDefault;
   const int c = t_beta_class;
   if (p.stream_policy[fam][c] >= 0) return p.stream_policy[fam][c];
   // not timed for this family in this class yet (adaptive's comparison of the families): the policy another family measured on
@@ -1010,7 +1182,7 @@ struct TuneTimer {
 template <typename Launch> bool autotune_policy(Plan &p, int fam, hipStream_t st, Launch &&launch) {
   const int cls = t_beta_class;
   if (p.stream_policy[fam][cls] >= 0) return true;
-  if (tun(kT_stream_plain) >= 0) return true; // pinned (A/B runs): policy_for follows the tunable, nothing is recorded
+  if (tun(kT_stream_plain) >= 0 || tun(kT_deterministic)) return true; // pinned (A/B runs) / by rule: policy_for decides, nothing is recorded
   // A matrix prepared in one beta class (spmv_acc_prepare: beta = 1) and then CAPTURED into a hipGraph in the other: timing would
   // synchronise inside the capture.  The call runs under the policy the other class measured (policy_for's fallback) and this
   // class is timed by the first call made outside a capture.
@@ -1129,6 +1301,10 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
     F.needs_fixup = forced == 0;
     return true;
   }
+  if (tun(kT_deterministic)) { // by rule: tiles finish their cut rows wherever that is legal (what the timing picks on most matrices)
+    F.needs_fixup = false;
+    return true;
+  }
   const int cls = t_beta_class; // (the fix-up kernel re-reads the old y of every cut row: the two forms rank per beta class)
   if (F.mode_tuned[cls]) {
     F.needs_fixup = F.tuned_fixup[cls];
@@ -1156,6 +1332,7 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
   (void)hipFree(scratch);
   F.tuned_fixup[cls] = F.needs_fixup = !(ok && ms[1] < ms[0]);
   F.mode_tuned[cls] = ok;
+  if (ok) p.flat_mode_choice[cls] = F.tuned_fixup[cls] ? 1 : 0;
   if (ok) tune_log("m %d nnz %d beta class %d flat cut rows: carries + fix-up %.2f us, finished in the tile %.2f us", p.A.m, p.A.nnz, cls, ms[0] * 1e3f, ms[1] * 1e3f);
   return ok;
 }
@@ -1164,7 +1341,7 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
 // per matrix and keep the fastest.  The other tile size gets its own break points / carries; its cut rows are finished in
 // the tile whenever that is legal (no second launch: what wins on short kernels).
 bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
-  if (p.flat_geometry_tuned || tun(kT_col16) > 0 || flat_segment_sum() || t_capturing) return true;
+  if (p.flat_geometry_tuned || tun(kT_col16) > 0 || flat_segment_sum() || t_capturing || tun(kT_deterministic)) return true;
   if (p.A.nnz >= kFlatSmallNnz || p.flat.ntiles <= 1) {
     p.flat_geometry_tuned = true;
     return true;
@@ -1215,9 +1392,10 @@ bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
       alt = FlatPlan(); // ownership moved
       p.flat_tiles = p.flat.ntiles;
     }
-    p.flat.early_stream = best_early;
+    p.flat.early_stream = p.flat_early_choice = best_early;
     p.flat_npt_choice = p.flat.stride / kThreads;
     p.flat_geometry_tuned = true;
+    for (int c = 0; c < 2; ++c) p.flat_mode_choice[c] = p.flat.mode_tuned[c] ? (p.flat.tuned_fixup[c] ? 1 : 0) : -1;
   }
   Plan::free_flat_plan(alt);
   return ok;
@@ -1328,7 +1506,7 @@ template <class Launch> bool autotune_hint(Plan &p, int fam, hipStream_t st, Lau
   }
   if (!ensure_hint(p, st)) return false;
   if (p.hint_state != 1) return true;
-  if (mode > 0) {
+  if (mode > 0 || tun(kT_deterministic)) { // forced / by rule: wherever the census found a hot set worth protecting
     p.A.cold = p.d_cold;
     return true;
   }
@@ -1545,6 +1723,13 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
   const int forced = tun(kT_plus_min_nnz);
   if (forced > 0 || tun(kT_plus_ref_vec)) {
     return ensure_plus(p, h_rowptr, st, forced > 0 ? forced : kPlusMinNnz) && autotune_policy(p, kFamPlus, st, launch);
+  }
+  if (tun(kT_deterministic)) {
+    // by rule, and a pure function of the matrix whatever was called on it before: the balance probe of the row-block shape
+    // decides (hub rows: the reference's 1024, the block size that wins on power-law matrices; else 1536)
+    int vec = 1, rpb = kThreads;
+    pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
+    return probe_rowblock(p, rpb, st) && ensure_plus(p, h_rowptr, st, p.rowblock_ok == 0 ? kPlusMinNnz : 1536);
   }
   if (p.plus_tuned_min > 0) return ensure_plus(p, h_rowptr, st, p.plus_tuned_min) && autotune_policy(p, kFamPlus, st, launch);
   // (inside a capture: the row blocks the plan already holds, whatever block size they were analysed with; none yet -> refused)
@@ -1786,7 +1971,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     break;
   case kAdaptive: {
     if (!fetch_samples(*p, h_rowptr)) return;
-    if (tun(kT_adaptive_timed) && !tun(kT_adaptive_split)) {
+    if (tun(kT_adaptive_timed) && !tun(kT_adaptive_split) && !tun(kT_deterministic)) {
       run_adaptive_timed(st, *p, h_rowptr, alpha, beta, dx, dy);
       break;
     }
@@ -1835,6 +2020,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     set_error(kErrUnknownStrategy, "unknown strategy id");
     break;
   }
+  if (t_plan_work != prepare_clock.work0 && p->tune_key) tune_store(*p); // (plan work happened: keep what was learnt)
   // a launch that failed (bad grid, no code object for this device) leaves y untouched: say so
   const hipError_t launch_err = hipGetLastError();
   if (launch_err != hipSuccess && last_error_code_only() == kOk)

@@ -129,6 +129,9 @@ struct PlanInfo {
 };
 bool query_plan(const int *d_rowptr, int m, PlanInfo *out);
 int cached_plan_count();
+// Persistent per-matrix choices (engine.cpp "tune cache"): path of the text file, null / "" = off; default = environment
+// variable SPMV_ACC_TUNE_CACHE.
+void set_tune_cache(const char *path);
 // Drops every cached plan whose stale flag is up (any thread's) and returns how many; records SPMV_ACC_ERR_BAD_ARGUMENT if any.
 int check_plans();
 

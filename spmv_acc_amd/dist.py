@@ -67,7 +67,7 @@ class RowShardedSpmv:
 
     def __init__(self, rank: int, world: int, bounds, rowptr, cols, vals, n: int, device, strategy="adaptive",
                  local_spmv: Optional[Callable] = None, h_rowptr=None, always_collective: bool = False,
-                 exchange: str = "allgather", pipeline: int = 1):
+                 exchange: str = "allgather", pipeline: int = 1, own_stream: bool = False):
         import torch
 
         self.torch = torch
@@ -94,11 +94,15 @@ class RowShardedSpmv:
         self._pending = None
         self._k = 0
         self._chunks = {}  # pipeline depth -> [(c0, c1, rowptr, cols, vals, nnz, h_rowptr)] over this rank's rows
-        # On the GPU the local SpMV runs on its OWN (non-NULL) stream and is ordered against the exchange with events, both
-        # ways: the exchange of step k is issued after an event recorded behind SpMV k, and SpMV k+2 -- the next writer of
-        # the vector that exchange works on -- is issued after the stream has waited for that exchange.  Nothing relies on the
-        # library's stream and torch's current stream being the same stream.
+        # On the GPU the unpipelined step runs the local SpMV on torch's CURRENT stream -- the stream the exchange is issued
+        # against: the process group orders the exchange behind it by itself, and `work.wait()` of step k-1's exchange is the only
+        # cross-stream dependency a step needs (the two alternating vectors keep SpMV k+1 clear of exchange k).  The engine's
+        # OWN (non-NULL) compute stream, with events both ways -- the exchange of step k issued after an event recorded behind
+        # SpMV k, SpMV k+2 issued after the stream has waited for that exchange -- serves the pipelined step, where the chunks'
+        # kernels must run ahead of the exchanges, and `own_stream=True`.  (Round 2 used it for every step: two extra
+        # cross-stream hand-overs per step, ~20 us of bubbles on a 156 us kernel.)
         self._gpu = torch.device(device).type == "cuda"
+        self.own_stream = bool(own_stream)
         self.compute_stream = torch.cuda.Stream(device=device) if self._gpu else None
         self.spmv_done = None  # event behind the latest local SpMV (GPU only)
         self.exchange_issued_after_spmv = None  # for tests: did the latest exchange wait for that event?
@@ -167,8 +171,15 @@ class RowShardedSpmv:
             cs = self.compute_stream
             # x / y_prev were produced on the caller's stream; `cur` was last touched by the exchange of step k-2, which the
             # caller's stream has waited for (self.wait() of step k-1)
-            cs.wait_stream(cur_stream)
-            if depth == 1:
+            if depth == 1 and not self.own_stream:
+                local(chunks[0])  # on the current stream (the library follows it, spmv_acc_amd._require)
+                self.spmv_done = None
+                self.wait()  # at most one exchange in flight (it worked on the OTHER vector: the SpMV above did not wait for it)
+                self.exchange_issued_after_spmv = True  # (stream order)
+                if not solo:
+                    works = self._issue_exchange(cur, group)
+            elif depth == 1:
+                cs.wait_stream(cur_stream)
                 with torch.cuda.stream(cs):  # the library follows torch's current stream (spmv_acc_amd._require)
                     local(chunks[0])
                     self.spmv_done = cs.record_event()
@@ -178,6 +189,7 @@ class RowShardedSpmv:
                 if not solo:
                     works = self._issue_exchange(cur, group)
             else:
+                cs.wait_stream(cur_stream)
                 self.wait()  # (the pipelined exchange starts during this step: the previous one must have ended)
                 events = []
                 with torch.cuda.stream(cs):

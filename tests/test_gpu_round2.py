@@ -229,7 +229,7 @@ def test_row_sharded_event_ordering_on_one_rank_rccl(torch_dev, oracle):
         bounds = np.array([0, m], dtype=np.int64)
         for exchange in ("allgather", "p2p"):
             eng = RowShardedSpmv(0, 1, bounds, drp, dci, dv, n, torch.device("cuda", 0), strategy="adaptive",
-                                 always_collective=True, exchange=exchange)
+                                 always_collective=True, exchange=exchange, own_stream=True)
             assert eng.compute_stream is not None and eng.compute_stream.cuda_stream != 0  # explicit non-NULL stream
             assert eng.compute_stream.cuda_stream != torch.cuda.current_stream().cuda_stream
             eng.set_y(dy0)
@@ -248,6 +248,18 @@ def test_row_sharded_event_ordering_on_one_rank_rccl(torch_dev, oracle):
                 y = oracle.host_spmv(0.25, 0.5, rowptr, cols, vals, x, y)
             scale_ok = oracle.scaled_error(got, y, 0.25, 0.5, rowptr, cols, vals, x, y0)
             assert scale_ok <= 1e-11, (exchange, scale_ok)
+            # the default (round 3): the local SpMV on the CURRENT stream, ordered with the exchange by stream order alone; held
+            # back the same way, same recurrence
+            eng = RowShardedSpmv(0, 1, bounds, drp, dci, dv, n, torch.device("cuda", 0), strategy="adaptive",
+                                 always_collective=True, exchange=exchange)
+            eng.set_y(dy0)
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(200_000_000)
+                for _ in range(3):
+                    eng.step(0.25, 0.5, dx, overlap=True)
+                got2 = eng.gathered().cpu().numpy()
+            assert oracle.scaled_error(got2, y, 0.25, 0.5, rowptr, cols, vals, x, y0) <= 1e-11, (exchange, "current-stream form")
         spmv_acc_amd.release_plans(drp)
     finally:
         dist.destroy_process_group()

@@ -449,3 +449,72 @@ def test_row_sharded_pipelined_step_on_one_rank_rccl(torch_dev, oracle):
     finally:
         dist.destroy_process_group()
         spmv_acc_amd.load_library().spmv_acc_set_stream(None)
+
+
+# ---- persistent choices and the deterministic switch -------------------------------------------------------------------------
+_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+import spmv_acc_amd
+from spmv_acc_amd import synth
+rp, ci, v = synth.structured_csr_torch(600_000, 600_000, 4_200_000, 0xC7, device="cuda")
+m = n = 600_000
+nnz = int(rp[-1].item())
+gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+x = torch.rand(n, generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+out = {{}}
+for strat in {strategies!r}:
+    ms = spmv_acc_amd.prepare(m, n, nnz, rp, ci, v, x, strategy=strat)
+    y = torch.ones(m, dtype=torch.float64, device="cuda")
+    spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
+    torch.cuda.synchronize()
+    out[strat] = y.cpu().numpy()
+    out[strat + "__prepare_ms"] = np.array(ms)
+    out[strat + "__plan"] = np.array(list((spmv_acc_amd.query_plan(rp, m) or {{}}).values()))
+np.savez({out!r}, **out)
+"""
+
+
+def _run_child(tmp_path, tag, strategies, env_extra):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / f"{tag}.npz")
+    env = dict(os.environ, SPMV_ACC_TUNE_LOG="1", **env_extra)
+    r = subprocess.run([sys.executable, "-c", _CHILD.format(root=root, strategies=strategies, out=out)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(out), r.stderr
+
+
+def test_tune_cache_is_adopted_by_the_next_process(torch_dev, tmp_path):
+    """SPMV_ACC_TUNE_CACHE=<file>: the first process times its choices on the matrix and appends them; a second process meeting
+    the same matrix on the same device adopts them -- no timing line in its tune log, a first call several times cheaper, the same
+    plan, and therefore bitwise the same y."""
+    strategies = ("adaptive", "flat", "adaptive_plus")
+    cache = str(tmp_path / "tune.txt")
+    first, log1 = _run_child(tmp_path, "p1", strategies, {"SPMV_ACC_TUNE_CACHE": cache})
+    assert "stream policy" in log1 and "adopted" not in log1
+    lines = open(cache).read().splitlines()
+    assert lines and all(ln.startswith("spmvacc1 ") and len(ln.split()) == 22 for ln in lines)
+    second, log2 = _run_child(tmp_path, "p2", strategies, {"SPMV_ACC_TUNE_CACHE": cache})
+    assert "adopted from the tune cache" in log2
+    assert "stream policy" not in log2 and "-> family" not in log2 and "flat cut rows" not in log2, log2[-2000:]
+    for s in strategies:
+        assert np.array_equal(first[s], second[s]), s
+        assert np.array_equal(first[s + "__plan"], second[s + "__plan"]), s
+    assert float(second["adaptive__prepare_ms"]) < 0.5 * float(first["adaptive__prepare_ms"]), (first["adaptive__prepare_ms"], second["adaptive__prepare_ms"])
+
+
+def test_deterministic_switch_is_bitwise_stable_across_processes(torch_dev, tmp_path):
+    """SPMV_ACC_DETERMINISTIC=1: nothing is timed (no timing line in the tune log), every choice follows a rule on the matrix'
+    shape, so two processes compute bitwise the same y with every strategy."""
+    strategies = tuple(spmv_acc_amd.STRATEGIES)
+    a, log_a = _run_child(tmp_path, "d1", strategies, {"SPMV_ACC_DETERMINISTIC": "1"})
+    b, log_b = _run_child(tmp_path, "d2", strategies, {"SPMV_ACC_DETERMINISTIC": "1"})
+    for log in (log_a, log_b):
+        assert " us" not in log.replace("census", ""), log[-1500:]  # no timing was taken
+    for s in strategies:
+        assert np.array_equal(a[s], b[s]), s
