@@ -504,7 +504,8 @@ def test_tune_cache_is_adopted_by_the_next_process(torch_dev, tmp_path):
     assert "stream policy" not in log2 and "-> family" not in log2 and "flat cut rows" not in log2, log2[-2000:]
     for s in strategies:
         assert np.array_equal(first[s], second[s]), s
-        assert np.array_equal(first[s + "__plan"], second[s + "__plan"]), s
+        # same timed choices (stream policy, adaptive's family); the second process built only the family that won, the first all three
+        assert first[s + "__plan"][6] == second[s + "__plan"][6] and first[s + "__plan"][8] == second[s + "__plan"][8], s
     assert float(second["adaptive__prepare_ms"]) < 0.5 * float(first["adaptive__prepare_ms"]), (first["adaptive__prepare_ms"], second["adaptive__prepare_ms"])
 
 

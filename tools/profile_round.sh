@@ -46,11 +46,13 @@ def dominant(path):
     for line in open(path):
         m = re.match(r"(\w+) kernel=(.+?) dispatches=(\d+) mean_KB=([\d.]+)", line)
         # the SpMV kernel of the timed loop: most dispatches among the tile kernels
-        if m and any(k in m.group(2) for k in ("rowblock_stream", "flat_tile", "plus_kernel", "vector_row", "wave_row")):
+        if m and any(k in m.group(2) for k in ("rowblock_stream", "flat_tile", "plus_kernel", "vector_tile", "vector_row", "wave_row", "direct_rows")):
             if best is None or int(m.group(3)) > best[1]:
                 best = (m.group(2), int(m.group(3)), float(m.group(4)))
     return best
 f, w = dominant(f"{out}/pmc_FETCH_SIZE.summary.txt"), dominant(f"{out}/pmc_WRITE_SIZE.summary.txt")
+if f is None or w is None:
+    sys.exit(f"profile_round: no SpMV kernel of the library found in {out}/pmc_*.summary.txt (kernel names changed? see dominant())")
 bench = json.loads(open(f"{out}/bench_under_trace.json").read().strip().splitlines()[-1])
 balg = bench["roofline"]["algorithmic_bytes_per_launch"]
 fetch_b, write_b = f[2] * 1024.0, w[2] * 1024.0
