@@ -600,6 +600,24 @@ def main():
         result["plan"] = {k: info[k] for k in ("stream_policy", "adaptive_family", "flat_fixup", "plus_blocks", "flat_tiles")}
     if rank == 0:
         result["copy_ceiling_gbs"] = round(copy_ceiling_gbs(torch, device), 1)
+    if rank == 0 and world == 1:
+        # What the per-launch protocol costs before a single byte of a matrix moves: a 256-row diagonal matrix (one workgroup's
+        # worth of work) under the same two protocols.  The small sweep matrices sit a few microseconds above this floor.
+        tm = 256
+        trp = torch.arange(tm + 1, dtype=torch.int32, device=device)
+        tci = torch.arange(tm, dtype=torch.int32, device=device)
+        tv = torch.ones(tm, dtype=torch.float64, device=device)
+        ty0 = torch.zeros(tm, dtype=torch.float64, device=device)
+        ty = ty0.clone()
+        tx = torch.ones(tm, dtype=torch.float64, device=device)
+        for _ in range(5):
+            spmv_acc_amd.csr_spmv(1.0, 1.0, tm, tm, tm, trp, tci, tv, tx, ty, strategy="line_enhance")
+        torch.cuda.synchronize()
+        f_reset, f_b2b, f_min = two_protocols(torch, "line_enhance", (tm, tm, tm, trp, tci, tv), tx, ty, ty0, 50, 200)
+        result["launch_floor"] = {"workload": "256-row diagonal matrix, line_enhance (one workgroup)",
+                                  "per_launch_reset_us_median": round(f_reset * 1e3, 2), "per_launch_reset_us_min": round(f_min * 1e3, 2),
+                                  "back_to_back_us_mean": round(f_b2b * 1e3, 2)}
+        spmv_acc_amd.release_plans(trp)
     if rank == 0 and world == 1 and args.workload == "hardesty3" and args.scale == 1.0 and not args.no_sensitivity:
         # Same dimensions and row lengths, none of the stand-in's 10 % uniformly random columns (SURVEY.md 8d prescribes
         # them; the real matrix is not available): shows live how much of `roofline.frac` is the gather sector cost.
