@@ -153,6 +153,17 @@ def two_protocols(torch, strat, A, x, y, y0, iters_reset, iters_b2b, alpha=1.0, 
     return float(np.median(per)), float(b2b), float(np.min(per))
 
 
+def nofence_ms(strat, A, x, y, y0, iters, alpha=1.0, beta=1.0):
+    """The per-launch protocol with events created hipEventDisableSystemFence (HIP's documented form for events that only
+    measure time: no cache write-back / invalidation inside the event).  Shown beside the default-event figure, never instead."""
+    import spmv_acc_amd
+
+    m, n, nnz, rp, ci, v = A
+    per = spmv_acc_amd.time_spmv(strat, iters, alpha, beta, m, n, nnz, rp, ci, v, x, y, y0=y0,
+                                 event_flags=spmv_acc_amd.EVENT_DISABLE_SYSTEM_FENCE)
+    return float(np.median(per))
+
+
 def timed_leg(torch, strat, A, x, y0, iters, warm=10, beta=1.0, cols_touched=None):
     """One extra leg: `warm` untimed launches (the first builds the plan), then both protocols (two_protocols).
     us / frac: the reference's per-launch protocol with y reset (what every gate is quoted on); us_back_to_back /
@@ -167,6 +178,7 @@ def timed_leg(torch, strat, A, x, y0, iters, warm=10, beta=1.0, cols_touched=Non
     torch.cuda.synchronize()
     y.copy_(y0)
     reset_ms, b2b_ms, _ = two_protocols(torch, strat, A, x, y, y0, max(20, iters // 3), iters, beta=beta)
+    nf_ms = nofence_ms(strat, A, x, y, y0, 20, beta=beta)
     # (a row shard with global column ids reads only the columns its rows reference, not all n entries of x)
     b = synth.algorithmic_bytes(m, n if cols_touched is None else cols_touched, nnz, beta_nonzero=beta != 0.0)
     info = spmv_acc_amd.query_plan(rp, m) or {}
@@ -174,6 +186,7 @@ def timed_leg(torch, strat, A, x, y0, iters, warm=10, beta=1.0, cols_touched=Non
     return {"us": round(reset_ms * 1e3, 2), "frac": frac(reset_ms),
             "per_launch_reset_ms_median": round(reset_ms, 6), "back_to_back_ms_mean": round(b2b_ms, 6),
             "us_back_to_back": round(b2b_ms * 1e3, 2), "frac_back_to_back": frac(b2b_ms),
+            "us_events_without_system_fence": round(nf_ms * 1e3, 2), "frac_events_without_system_fence": frac(nf_ms),
             "gflops": round(2.0 * nnz / (reset_ms * 1e-3) / 1e9, 1),
             "plan": [info.get(k, -1) for k in ("stream_policy", "adaptive_family", "flat_fixup")]}
 
@@ -496,6 +509,8 @@ def main():
         out_extra["per_launch_reset_ms_median"] = round(ev_ms, 6)
         out_extra["per_launch_reset_ms_min"] = round(float(np.min(ms)), 6)
         out_extra["back_to_back_ms_mean"] = round(b2b_ms, 6)
+        out_extra["per_launch_reset_ms_median_events_without_system_fence"] = round(
+            nofence_ms(strat, (m, n, nnz, W["rp"], W["ci"], W["v"]), x, y, y0, 20, alpha, beta), 6)
     elif args.exchange == "ghost":
         # square workloads only: x partitioned like the rows, x <- alpha * A * x, each rank receiving just the entries its
         # columns reference (BASELINE configs[4]: 4 + 3 doubles per neighbour instead of an allgather of 256 MB slices)
@@ -614,9 +629,11 @@ def main():
             spmv_acc_amd.csr_spmv(1.0, 1.0, tm, tm, tm, trp, tci, tv, tx, ty, strategy="line_enhance")
         torch.cuda.synchronize()
         f_reset, f_b2b, f_min = two_protocols(torch, "line_enhance", (tm, tm, tm, trp, tci, tv), tx, ty, ty0, 50, 200)
+        f_nf = nofence_ms("line_enhance", (tm, tm, tm, trp, tci, tv), tx, ty, ty0, 50)
         result["launch_floor"] = {"workload": "256-row diagonal matrix, line_enhance (one workgroup)",
                                   "per_launch_reset_us_median": round(f_reset * 1e3, 2), "per_launch_reset_us_min": round(f_min * 1e3, 2),
-                                  "back_to_back_us_mean": round(f_b2b * 1e3, 2)}
+                                  "back_to_back_us_mean": round(f_b2b * 1e3, 2),
+                                  "per_launch_reset_us_median_events_without_system_fence": round(f_nf * 1e3, 2)}
         spmv_acc_amd.release_plans(trp)
     if rank == 0 and world == 1 and args.workload == "hardesty3" and args.scale == 1.0 and not args.no_sensitivity:
         # Same dimensions and row lengths, none of the stand-in's 10 % uniformly random columns (SURVEY.md 8d prescribes

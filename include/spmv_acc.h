@@ -279,6 +279,15 @@ int spmv_acc_time_spmv(int strategy, int iters, double alpha, double beta, int m
                        const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
                        const double *dx, double *dy, const double *d_y0, float *ms_out);
 
+/* The same with the events' creation flags chosen by the caller (hipEventCreateWithFlags): 0 = hipEventDefault, what
+ * benchmark/utils/timer_utils.h:16-51 creates and what every gate of this repository is quoted on.  hipEventDisableSystemFence
+ * (0x20000000) takes the system-scope fence -- a cache write-back and invalidation -- out of the event, which HIP documents as the
+ * more accurate form for events that only measure time; on MI355X it is 1.2 us of the ~6.7 us an almost empty launch takes between
+ * default events, and it leaves the L2s warm for the timed launch.  Reported beside the default figure, never instead of it. */
+int spmv_acc_time_spmv_events(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
+                              const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
+                              const double *dx, double *dy, const double *d_y0, float *ms_out, unsigned event_flags);
+
 /* One event pair around all `iters` back-to-back launches (no per-launch markers): *total_ms_out / iters is
  * the average launch duration a solver loop sees. */
 int spmv_acc_time_spmv_total(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,

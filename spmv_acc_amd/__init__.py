@@ -39,7 +39,7 @@ C_ABI_SYMBOLS = (
     "spmv_acc_last_prepare_us", "spmv_acc_sharded_spmv", "spmv_acc_csr_spmv_oop", "spmv_acc_check_plans",
     "spmv_acc_query_plan_beta0", "spmv_acc_shard_create", "spmv_acc_shard_step", "spmv_acc_shard_pipeline",
     "spmv_acc_shard_destroy", "spmv_acc_rccl_comm_init_all", "spmv_acc_rccl_comm_destroy", "spmv_acc_set_tune_cache",
-    "spmv_acc_prepare_beta",
+    "spmv_acc_prepare_beta", "spmv_acc_time_spmv_events",
 )
 
 _lib = None
@@ -100,6 +100,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_last_error_string.restype = ctypes.c_char_p
     lib.spmv_acc_clear_error.restype = None
     lib.spmv_acc_time_spmv.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.spmv_acc_time_spmv_events.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint]
     lib.spmv_acc_version.restype = ctypes.c_char_p
     lib.spmv_acc_set_tunable.argtypes = [ctypes.c_char_p, ci]
     lib.spmv_acc_get_tunable.argtypes = [ctypes.c_char_p]
@@ -303,15 +304,19 @@ def partition_rows(m: int, parts: int, mode: int = 0, h_rowptr=None):
     return out
 
 
+EVENT_DISABLE_SYSTEM_FENCE = 0x20000000  # hipEventDisableSystemFence
+
+
 def time_spmv(strategy, iters: int, alpha: float, beta: float, m: int, n: int, nnz: int, rowptr, colindex, value,
-              x, y, y0=None, h_rowptr=None) -> Sequence[float]:
-    """Per-launch durations (ms) from hipEvents recorded on the library stream around each SpMV."""
+              x, y, y0=None, h_rowptr=None, event_flags: int = 0) -> Sequence[float]:
+    """Per-launch durations (ms) from hipEvents recorded on the library stream around each SpMV; y restored from y0 (device
+    copy) before each launch, outside the event pair.  event_flags: hipEventCreateWithFlags flags (0 = hipEventDefault)."""
     lib = load_library()
     _csr_args(lib, m, n, nnz, rowptr, colindex, value, x, y, y0)
     out = (ctypes.c_float * iters)()
-    rc = lib.spmv_acc_time_spmv(strategy_id(strategy), iters, alpha, beta, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr),
-                                _ptr(colindex), _ptr(value), _ptr(x), _ptr(y), _ptr(y0),
-                                ctypes.cast(out, ctypes.c_void_p))
+    rc = lib.spmv_acc_time_spmv_events(strategy_id(strategy), iters, alpha, beta, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr),
+                                       _ptr(colindex), _ptr(value), _ptr(x), _ptr(y), _ptr(y0),
+                                       ctypes.cast(out, ctypes.c_void_p), event_flags)
     if rc != 0:
         msg = lib.spmv_acc_last_error_string().decode()
         raise SpmvAccError(f"time_spmv failed ({rc}): {msg}")

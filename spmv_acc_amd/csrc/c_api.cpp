@@ -77,6 +77,12 @@ template <typename T> bool stage_one(Stager &st, const T *h, size_t count, T **d
 }
 } // namespace
 
+namespace {
+__global__ void copy_doubles_kernel(double *dst, const double *src, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+} // namespace
+
 // ---- RCCL, resolved at run time (the library links only the HIP runtime) ------------------------------------------------------
 namespace {
 typedef int (*nccl_all_gather_t)(const void *, void *, size_t, int, void *, hipStream_t);
@@ -350,6 +356,13 @@ int spmv_acc_prepare_beta(int strategy, double beta, int m, int n, int nnz, cons
 int spmv_acc_time_spmv(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
                        const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
                        const double *dx, double *dy, const double *d_y0, float *ms_out) {
+  return spmv_acc_time_spmv_events(strategy, iters, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy, d_y0,
+                                   ms_out, 0u);
+}
+
+int spmv_acc_time_spmv_events(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
+                              const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
+                              const double *dx, double *dy, const double *d_y0, float *ms_out, unsigned event_flags) {
   if (iters <= 0 || !ms_out) {
     set_error(kErrBadArgument, "spmv_acc_time_spmv: bad argument");
     return kErrBadArgument;
@@ -357,14 +370,29 @@ int spmv_acc_time_spmv(int strategy, int iters, double alpha, double beta, int m
   hipStream_t st = get_stream();
   std::vector<hipEvent_t> ev(2 * static_cast<size_t>(iters));
   for (auto &e : ev) {
-    if (hipEventCreate(&e) != hipSuccess) {
+    if (hipEventCreateWithFlags(&e, event_flags) != hipSuccess) {
       set_error(kErrHip, "hipEventCreate failed");
       return kErrHip;
     }
   }
   clear_error();
+  // y reset: a copy KERNEL on the same queue as the SpMV (SPMV_ACC_RESET_MEMCPY=1: hipMemcpyAsync, which may run on a DMA engine
+  // and hand over to the compute queue through a signal -- that hand-over then sits between the first event and the kernel)
+  static const bool reset_memcpy = [] {
+    const char *e = std::getenv("SPMV_ACC_RESET_MEMCPY");
+    return e && *e && *e != '0';
+  }();
+  const size_t ybytes = sizeof(double) * static_cast<size_t>(m);
+  const bool kernel_copy = !reset_memcpy && reinterpret_cast<uintptr_t>(dy) % 16 == 0 && reinterpret_cast<uintptr_t>(d_y0) % 16 == 0;
   for (int i = 0; i < iters; ++i) {
-    if (d_y0) (void)hipMemcpyAsync(dy, d_y0, sizeof(double) * static_cast<size_t>(m), hipMemcpyDeviceToDevice, st);
+    if (d_y0) {
+      const size_t body = kernel_copy ? ybytes / 16 * 16 : 0;
+      if (body) launch_stream_copy(st, dy, d_y0, static_cast<long long>(body), false);
+      if (body < ybytes && kernel_copy) // (odd m: the last double)
+        hipLaunchKernelGGL(copy_doubles_kernel, dim3(1), dim3(64), 0, st, dy + body / 8, d_y0 + body / 8, static_cast<int>((ybytes - body) / 8));
+      else if (body < ybytes)
+        (void)hipMemcpyAsync(dy, d_y0, ybytes, hipMemcpyDeviceToDevice, st);
+    }
     (void)hipEventRecord(ev[2 * i], st);
     run_spmv(strategy, 0, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy);
     (void)hipEventRecord(ev[2 * i + 1], st);
