@@ -246,6 +246,16 @@ def extra_legs(torch, device, headline):
                      "line_enhance": timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)}
     progress(f"rmat25: {out['rmat25']['line_enhance']}")
     spmv_acc_amd.release_plans(A[3])
+    # opt-in leg, never the headline of configs[3]: column-slab blocking (tunable col_slabs: the plan holds a re-ordered copy of the
+    # matrix in 8 column ranges and runs 8 consecutive SpMVs, each gathering from an eighth of x).  Same algorithmic bytes.
+    lib = spmv_acc_amd.load_library()
+    lib.spmv_acc_set_tunable(b"col_slabs", 8)
+    try:
+        out["rmat25"]["line_enhance_col_slabs8_opt_in"] = timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)
+        progress(f"rmat25 with 8 column slabs (opt-in): {out['rmat25']['line_enhance_col_slabs8_opt_in']}")
+    finally:
+        lib.spmv_acc_set_tunable(b"col_slabs", 0)
+        spmv_acc_amd.release_plans(A[3])
     del A, x, y0
     torch.cuda.empty_cache()
     rows, total = 32_000_000, 256_000_000

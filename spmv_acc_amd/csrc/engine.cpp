@@ -90,7 +90,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kTunableCount
 };
 #ifdef FLAT_SEGMENT_SUM_REDUCE
 constexpr int kFlatReduceBuilt = 1;
@@ -157,6 +157,11 @@ Tunable g_tunables[] = {
                                // across processes and runs.  Costs the per-matrix optimum (a few per cent on most stand-ins)
     {"tune_protocol", 1, 1},   // how the per-matrix timings are taken: 1 = the reference harness's protocol (y rewritten before each launch, one
                                // event pair per launch, median), 0 = one event pair around back-to-back launches (rounds 1-2)
+    {"col_slabs", 0, 0},       // OPT-IN column-slab blocking (k_slab.hip): S >= 2 = the plan holds a re-ordered COPY of colindex and values,
+                               // A = sum of S column-range slabs, and an SpMV is S consecutive SpMVs of the named strategy, each gathering
+                               // from 1/S of x (power-law columns: the L2s then hold a hot set S times deeper; R-MAT scale 25 7.15 -> 5.5 ms
+                               // with S = 8).  Costs S passes over y; loses on matrices whose gathers already hit.  After editing colindex
+                               // or values in place call spmv_acc_release_plans.  0 = off (the default: plans hold no copy of the matrix)
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -523,6 +528,13 @@ struct Plan {
   int flat_mode_choice[2] = {-1, -1};  // timed cut-row form per beta class: -1 not timed, 0 tiles finish their cut rows, 1 carries + fix-up
   // persistent choices (tune cache): key of this matrix on this device, 0 = none
   unsigned long long tune_key = 0;
+  // opt-in column-slab blocking (tunable col_slabs): the slabs' row pointers (S * (m + 1) ints), the re-ordered colindex / values,
+  // where each slab starts in them, and each slab's non-zero count
+  int slab_count = 0;
+  int *d_slab_rp = nullptr;
+  int *d_slab_ci = nullptr;
+  double *d_slab_v = nullptr;
+  std::vector<long long> slab_off;
   // row-block-plus
   int plus_blocks = -1;
   int plus_vec = 0;
@@ -557,7 +569,9 @@ struct Plan {
     if (digest.base) (void)hipFree(digest.base);
     digest = RowDigest();
   }
+  void free_slabs();
   void free_device() {
+    free_slabs();
     if (d_cold) (void)hipFree(d_cold);
     d_cold = nullptr;
     hint_state = -1;
@@ -729,7 +743,42 @@ void tune_store(const Plan &p) {
   }
 }
 
+// Derived matrices (the slabs of the opt-in column-slab blocking) have plans of their own, keyed by pointers into their parent's
+// arrays.  When the parent dies those plans must go too; a plan can die under g_mu, so the rowptrs are queued here and the entries
+// are erased the next time the cache is touched (before any lookup: a re-used address never meets a dead plan).
+std::mutex g_deferred_mu;
+std::vector<const void *> g_deferred_rp;
+void Plan::free_slabs() {
+  if (d_slab_rp) {
+    std::lock_guard<std::mutex> lk(g_deferred_mu);
+    for (int s = 0; s < slab_count; ++s) g_deferred_rp.push_back(d_slab_rp + static_cast<size_t>(s) * (static_cast<size_t>(A.m) + 1));
+  }
+  if (d_slab_rp) (void)hipFree(d_slab_rp);
+  if (d_slab_ci) (void)hipFree(d_slab_ci);
+  if (d_slab_v) (void)hipFree(d_slab_v);
+  d_slab_rp = d_slab_ci = nullptr;
+  d_slab_v = nullptr;
+  slab_count = 0;
+  slab_off.clear();
+}
+
 std::map<PlanKey, std::shared_ptr<Plan>> g_plans; // a running call keeps its plan alive through its own reference
+void drain_deferred_locked() { // g_mu held
+  std::vector<const void *> dead;
+  {
+    std::lock_guard<std::mutex> lk(g_deferred_mu);
+    dead.swap(g_deferred_rp);
+  }
+  while (!dead.empty()) { // (erasing a plan may queue more)
+    for (auto it = g_plans.begin(); it != g_plans.end();) {
+      if (std::find(dead.begin(), dead.end(), std::get<1>(it->first)) != dead.end()) it = g_plans.erase(it);
+      else ++it;
+    }
+    dead.clear();
+    std::lock_guard<std::mutex> lk(g_deferred_mu);
+    dead.swap(g_deferred_rp);
+  }
+}
 thread_local std::weak_ptr<Plan> t_last_plan;     // the plan this thread's latest run_spmv used (last_error asks it, and only it)
 
 // Is the calling thread inside a stream capture (set by run_spmv)?  Plan work -- allocations, synchronisation, timings -- would
@@ -793,6 +842,7 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
   if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
   const PlanKey key(dev, rp, ci, v, m, n);
   std::lock_guard<std::mutex> lk(g_mu);
+  drain_deferred_locked();
   auto it = g_plans.find(key);
   if (it != g_plans.end() && it->second->is_stale()) {
     if (!plan_work_allowed("rebuilding a stale plan")) return nullptr;
@@ -1887,6 +1937,62 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
 
 } // namespace
 
+namespace {
+thread_local bool t_in_slab = false; // this thread is running one slab of a column-slab SpMV (no nesting)
+
+// Opt-in column-slab blocking: build the S slabs of this matrix (k_slab.hip) once per plan and S.
+bool ensure_slabs(Plan &p, int S, hipStream_t st) {
+  if (p.d_slab_rp && p.slab_count == S) return true;
+  if (!plan_work_allowed("building the column slabs")) return false;
+  ++t_plan_work;
+  p.free_slabs();
+  const CsrDev &A = p.A;
+  const size_t m1 = static_cast<size_t>(A.m) + 1;
+  const int width = (A.n + S - 1) / S > 0 ? (A.n + S - 1) / S : 1;
+  int *cnt = nullptr;
+  long long *d_off = nullptr;
+  void *tmp = nullptr;
+  const size_t tmp_bytes = col16_scan_bytes(A.m);
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&cnt), sizeof(int) * m1 * S), "hipMalloc slab counts") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_slab_rp), sizeof(int) * m1 * S), "hipMalloc slab rowptr") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_slab_ci), sizeof(int) * (static_cast<size_t>(A.nnz) + 4)), "hipMalloc slab colindex") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_slab_v), sizeof(double) * (static_cast<size_t>(A.nnz) + 4)), "hipMalloc slab values") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&d_off), sizeof(long long) * S), "hipMalloc slab offsets") &&
+            hip_ok(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16), "hipMalloc slab scan workspace");
+  std::vector<long long> off(S, 0);
+  if (ok) {
+    launch_slab_count(st, A, width, S, cnt);
+    for (int s = 0; ok && s < S; ++s) // exclusive scan over m + 1 entries: rowptr_s, with rowptr_s[m] = the slab's non-zero count
+      ok = launch_col16_scan(st, A.m, cnt + m1 * s, p.d_slab_rp + m1 * s, tmp, tmp_bytes);
+    if (!ok) set_error(kErrHip, "column slabs: scan failed");
+    long long run = 0;
+    for (int s = 0; ok && s < S; ++s) {
+      int total = 0;
+      ok = hip_ok(hipMemcpyAsync(&total, p.d_slab_rp + m1 * s + A.m, sizeof(int), hipMemcpyDeviceToHost, st), "read slab size") &&
+           hip_ok(hipStreamSynchronize(st), "sync slab size");
+      off[s] = run;
+      run += total;
+    }
+    ok = ok && hip_ok(hipMemcpyAsync(d_off, off.data(), sizeof(long long) * S, hipMemcpyHostToDevice, st), "write slab offsets");
+    if (ok) {
+      launch_slab_scatter(st, A, width, S, p.d_slab_rp, d_off, p.d_slab_ci, p.d_slab_v);
+      ok = hip_ok(hipStreamSynchronize(st), "sync slab scatter");
+    }
+  }
+  if (cnt) (void)hipFree(cnt);
+  if (d_off) (void)hipFree(d_off);
+  if (tmp) (void)hipFree(tmp);
+  if (!ok) {
+    p.free_slabs();
+    return false;
+  }
+  p.slab_count = S;
+  p.slab_off = off;
+  p.slab_off.push_back(A.nnz);
+  return true;
+}
+} // namespace
+
 FlatSegmentSumScope::FlatSegmentSumScope() : prev(t_flat_segment_sum) { t_flat_segment_sum = true; }
 FlatSegmentSumScope::~FlatSegmentSumScope() { t_flat_segment_sum = prev; }
 
@@ -1967,6 +2073,27 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     return;
   }
   if (tun(kT_validate) && !validate_plan(*p, st)) return;
+
+  if (tun(kT_col_slabs) >= 2 && !t_in_slab) {
+    // opt-in column-slab blocking: S consecutive SpMVs of this strategy on the plan's slabs, the first one applying beta (and
+    // reading y_in), the others accumulating into y.  Each slab is an ordinary matrix with a plan of its own.
+    const int S = tun(kT_col_slabs) > 16 ? 16 : tun(kT_col_slabs);
+    if (!ensure_slabs(*p, S, st)) return;
+    const size_t m1 = static_cast<size_t>(m) + 1;
+    launch_guard_check(st, p->A); // (the slabs' kernels check the slabs: the caller's rowptr is checked here)
+    t_in_slab = true;
+    for (int s = 0; s < S && last_error_code_only() == kOk; ++s) {
+      const long long o = p->slab_off[s];
+      if (s > 0 && p->slab_off[s + 1] == o) continue; // an empty slab adds nothing
+      run_spmv(strategy, 0, alpha, s == 0 ? beta : 1.0, m, n, static_cast<int>(p->slab_off[s + 1] - o), nullptr, p->d_slab_rp + m1 * s,
+               p->d_slab_ci + o, p->d_slab_v + o, dx, dy, s == 0 ? dy_in : nullptr);
+    }
+    t_in_slab = false;
+    t_last_plan = p;
+    t_beta_class = beta != 0.0 ? 1 : 0;
+    if (t_plan_work != prepare_clock.work0 && p->tune_key) tune_store(*p);
+    return;
+  }
 
   const long long avg = static_cast<long long>(p->A.nnz) / m;
   switch (strategy) {
@@ -2079,6 +2206,7 @@ void release_plans(const int *d_rowptr) {
       ++it;
     }
   }
+  drain_deferred_locked(); // the plans of matrices derived from the ones just dropped
 }
 
 bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {

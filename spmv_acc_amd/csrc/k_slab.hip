@@ -1,0 +1,94 @@
+// k_slab.hip -- OPT-IN column-slab blocking (tunable col_slabs): A = sum_s A_s, A_s = the non-zeros whose column lies in the
+// s-th of S equal column ranges, y = beta*y + alpha * sum_s A_s x as S consecutive SpMVs of the ordinary kernels.
+//
+// Reference role: none -- the reference streams every row against all of x.  SURVEY.md section 7 names the problem ("R-MAT ... x =
+// 256 MB, random 8 B reads per 64/128 B line ... consider column-window blocking"): on power-law columns ~60 % of the gathers fall
+// on a few MB of x, but every one of the eight 4 MB L2s has to hold that hot set AND absorb the lines the cold gathers bring in.
+// With S slabs a phase gathers from 1/S of x only: the L2s hold a hot set S times deeper (tools/micro/xcd_slab_gather_bench.hip:
+// 67 -> 109 G gathers/s with an eighth of x per L2; tools/col_slab_probe.py: R-MAT scale 25 7.15 -> 5.46 ms with S = 8) at the price
+// of S passes over y and S row-pointer arrays.  The plan then holds a re-ordered COPY of colindex and values, which is why this is
+// opt-in like the 16-bit column stream: after editing colindex or values in place, call spmv_acc_release_plans.
+//
+// Build (once per plan, order inside a row preserved, no atomics): one wavefront per row, 64 non-zeros per step;
+//   count  : per step one ballot per slab, lane s keeps slab s's count            -> cnt[s][row]
+//   scan   : exclusive scan of each slab's counts (rocPRIM, engine.cpp)           -> rowptr_s
+//   scatter: the same walk; a non-zero's place = rowptr_s[row] + non-zeros of slab s before it in the row (ballot + popcount).
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace spmv_acc {
+namespace {
+
+using namespace dev;
+
+__global__ __launch_bounds__(kThreads) void slab_count_kernel(const int *__restrict__ rp, const int *__restrict__ ci, int m, int width,
+                                                              int S, int *__restrict__ cnt) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long waves = static_cast<long long>(gridDim.x) * (kThreads / kWave);
+  for (long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave; row < m; row += waves) {
+    const int j0 = rp[row], j1 = rp[row + 1];
+    int acc = 0;
+    for (int base = j0; base < j1; base += kWave) {
+      const int j = base + lane;
+      const int slab = j < j1 ? ci[j] / width : -1;
+      for (int s = 0; s < S; ++s) {
+        const unsigned long long mask = __ballot(slab == s);
+        if (lane == s) acc += __popcll(mask);
+      }
+    }
+    if (lane < S) cnt[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row] = acc;
+  }
+  // the scan runs over m + 1 entries per slab: the last one is the total
+  if (blockIdx.x == 0 && threadIdx.x < S) cnt[static_cast<size_t>(threadIdx.x) * (static_cast<size_t>(m) + 1) + m] = 0;
+}
+
+// off[s] = first position of slab s in the re-ordered arrays (exclusive sums of the slabs' non-zero counts)
+__global__ __launch_bounds__(kThreads) void slab_scatter_kernel(const int *__restrict__ rp, const int *__restrict__ ci,
+                                                                const double *__restrict__ v, int m, int width, int S,
+                                                                const int *__restrict__ rps, const long long *__restrict__ off,
+                                                                int *__restrict__ ci_out, double *__restrict__ v_out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long waves = static_cast<long long>(gridDim.x) * (kThreads / kWave);
+  for (long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave; row < m; row += waves) {
+    const int j0 = rp[row], j1 = rp[row + 1];
+    long long pos = 0; // lane s: where slab s's next non-zero of this row goes
+    if (lane < S) pos = off[lane] + rps[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row];
+    for (int base = j0; base < j1; base += kWave) {
+      const int j = base + lane;
+      const bool live = j < j1;
+      const int c = live ? ci[j] : 0;
+      const double a = live ? v[j] : 0.0;
+      const int slab = live ? c / width : -1;
+      for (int s = 0; s < S; ++s) {
+        const unsigned long long mask = __ballot(slab == s);
+        const long long at = __shfl(pos, s, kWave);
+        if (slab == s) {
+          const long long dst = at + __popcll(mask & ((1ULL << lane) - 1ULL));
+          ci_out[dst] = c;
+          v_out[dst] = a;
+        }
+        if (lane == s) pos += __popcll(mask);
+      }
+    }
+  }
+}
+
+} // namespace
+
+void launch_slab_count(hipStream_t stream, const CsrDev &A, int width, int S, int *cnt) {
+  if (A.m <= 0) return;
+  long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave);
+  if (blocks > 16384) blocks = 16384; // grid-stride: 64 Ki waves walk the rows
+  hipLaunchKernelGGL(slab_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, width, S, cnt);
+}
+
+void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, const int *rps, const long long *off, int *ci_out,
+                         double *v_out) {
+  if (A.m <= 0) return;
+  long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(slab_scatter_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.v, A.m, width, S,
+                     rps, off, ci_out, v_out);
+}
+
+} // namespace spmv_acc

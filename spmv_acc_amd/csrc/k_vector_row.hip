@@ -248,6 +248,13 @@ __global__ __launch_bounds__(kWave) void guard_fill_kernel(const int *__restrict
   guard[threadIdx.x] = rp[static_cast<int>(static_cast<long long>(threadIdx.x) * m / (kWave - 1))];
 }
 
+// the guard check alone (one wavefront): for call paths whose SpMV kernels run on matrices DERIVED from the caller's (the slabs of
+// the opt-in column-slab blocking), so that a structure edited in place is still noticed
+__global__ __launch_bounds__(kWave) void guard_check_kernel(const int *__restrict__ rp, int m, const int *__restrict__ guard,
+                                                            int *__restrict__ stale) {
+  check_plan_guard(rp, m, guard, stale);
+}
+
 __global__ __launch_bounds__(kThreads) void scale_y_kernel(int m, double beta, double *y, const double *yin) {
   const long long i = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
   if (i < m) y[i] = (beta == 0.0) ? 0.0 : beta * yin[i];
@@ -379,6 +386,10 @@ void launch_validate_csr(hipStream_t stream, const CsrDev &A, int *d_flags) {
 void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard) {
   static_assert(kGuardSamples == kWave, "one lane per sample");
   hipLaunchKernelGGL(guard_fill_kernel, dim3(1), dim3(kWave), 0, stream, rp, m, d_guard);
+}
+
+void launch_guard_check(hipStream_t stream, const CsrDev &A) {
+  if (A.guard && A.stale) hipLaunchKernelGGL(guard_check_kernel, dim3(1), dim3(kWave), 0, stream, A.rp, A.m, A.guard, A.stale);
 }
 
 void launch_scale_y(hipStream_t stream, int m, double beta, double *y, const double *yin) {

@@ -31,6 +31,7 @@ struct CsrDev {
 };
 constexpr int kGuardSamples = 64; // rowptr[k * m / 63], k = 0 .. 63 (includes rowptr[0] and rowptr[m] = nnz)
 void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard);
+void launch_guard_check(hipStream_t stream, const CsrDev &A); // the check alone, for paths whose SpMV kernels run on derived matrices
 
 // Cache policy of the 16-B colindex / value stream loads of the tile kernels.  Which one is fastest depends on the
 // matrix (A/B on MI355X: default-policy loads win by 7-27 % on FEM-like matrices -- part of the matrix then stays
@@ -172,6 +173,12 @@ bool plus_analyze_device_count(hipStream_t stream, const int *rp, int m, int min
                                int vec_size, void *workspace, int *d_total);
 void plus_analyze_device_emit(hipStream_t stream, const int *rp, int m, int min_nnz, const void *workspace, int *d_bp,
                               int *d_fbr);
+
+// ---- opt-in column-slab blocking (k_slab.hip; tunable col_slabs) ---------------------------------------------------------------
+// cnt / rps: S * (m + 1) ints, slab-major; off: S exclusive sums of the slabs' non-zero counts (device, 64-bit)
+void launch_slab_count(hipStream_t stream, const CsrDev &A, int width, int S, int *cnt);
+void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, const int *rps, const long long *off, int *ci_out,
+                         double *v_out);
 
 // dst = src over `bytes` (16-B granules) with the kernels' streaming load shape: the copy ceiling probe
 void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes, bool non_temporal);

@@ -519,3 +519,59 @@ def test_deterministic_switch_is_bitwise_stable_across_processes(torch_dev, tmp_
         assert " us" not in log.replace("census", ""), log[-1500:]  # no timing was taken
     for s in strategies:
         assert np.array_equal(a[s], b[s]), s
+
+
+# ---- opt-in column-slab blocking (tunable col_slabs) --------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,m,n,avg", [("powerlaw", 30000, 30000, 12), ("uniform", 20000, 50000, 7), ("empty_rows", 15000, 15000, 5)])
+def test_col_slabs_opt_in_matches_the_oracle(torch_dev, oracle, hiplib, kind, m, n, avg):
+    """Tunable col_slabs = S (off by default): the plan holds the matrix re-ordered into S column-range slabs and an SpMV is S
+    consecutive SpMVs of the named strategy (first applies beta, the rest accumulate).  Every strategy, S = 2 / 8 / 16 (more slabs
+    than some rows have non-zeros: empty slabs), in place and out of place, beta = 0, against the oracle; the derived plans go away
+    with their parent; an in-place edit of the caller's structure is still noticed."""
+    torch = torch_dev
+    rowptr, cols, vals = synth.random_csr(m, n, avg, seed=33, kind=kind)
+    if kind == "uniform":  # columns confined to the first third of [0, n): most slabs of 8 and 16 are empty
+        cols = (cols % (n // 3)).astype(np.int32)
+        for i in range(m):  # keep the rows sorted (not required by the kernels, tidy for the oracle's error scale)
+            a, b = rowptr[i], rowptr[i + 1]
+            order = np.argsort(cols[a:b], kind="stable")
+            cols[a:b] = cols[a:b][order]
+            vals[a:b] = vals[a:b][order]
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(3)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    try:
+        for S in (2, 8, 16):
+            hiplib.spmv_acc_set_tunable(b"col_slabs", S)
+            for strat in ALL:
+                for alpha, beta in ((1.0, 1.0), (0.5, -2.0), (2.0, 0.0)):
+                    ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+                    y = dy0.clone()
+                    spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y, strategy=strat)
+                    y_in = dy0.clone()
+                    y_out = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+                    spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y_out, strategy=strat, y_in=y_in)
+                    torch.cuda.synchronize()
+                    assert oracle.scaled_error(y.cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL, (S, strat, alpha, beta)
+                    assert torch.equal(y_out, y) and torch.equal(y_in, dy0), (S, strat, "out of place")
+            assert hiplib.spmv_acc_cached_plans() > 1  # the parent + its slabs
+            spmv_acc_amd.release_plans(drp)
+            assert hiplib.spmv_acc_cached_plans() == 0, "slab plans outlived their parent"
+        # the caller rewrites the structure in place (same nnz) without a release: the parent's guard still fires
+        hiplib.spmv_acc_set_tunable(b"col_slabs", 4)
+        y = dy0.clone()
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy="adaptive")
+        torch.cuda.synchronize()
+        lens = np.diff(rowptr)[::-1].copy()
+        drp.copy_(dev(torch, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)))
+        torch.cuda.synchronize()
+        hiplib.spmv_acc_csr_spmv_strategy(spmv_acc_amd.strategy_id("adaptive"), 0, 1.0, 1.0, m, n, nnz, None, drp.data_ptr(),
+                                          dci.data_ptr(), dv.data_ptr(), dx.data_ptr(), y.data_ptr())
+        torch.cuda.synchronize()
+        if not np.array_equal(lens, np.diff(rowptr)):
+            assert hiplib.spmv_acc_last_error() == 2 and b"changed" in hiplib.spmv_acc_last_error_string()
+    finally:
+        hiplib.spmv_acc_clear_error()
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans()
