@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
       if (off + kPlusTile < s1) __syncthreads(); // the next round overwrites the tile
     }
     acc = group_sum_dyn(acc, w);
-    if (live && lane == 0) store_y(y, yin, row, alpha, beta, acc);
+    if (live && lane == 0 && !(r1 == r0 && keeps_y(y, yin, beta))) store_y(y, yin, row, alpha, beta, acc); // (empty row, unchanged y: skipped)
   } else {
     // ---- slice [rec.z, rec.w) of the long row `row_begin` ----
     double s = 0.0;

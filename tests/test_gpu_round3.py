@@ -134,6 +134,7 @@ def test_two_host_threads_two_streams(torch_dev, oracle, hiplib):
     back with a long sleep kernel: the other thread's results are complete while the held stream's y is still untouched -- and every
     result is right.  A third thread that never set a stream sees NULL."""
     torch = torch_dev
+    torch.cuda.empty_cache()
     mats = []
     for seed, m, avg in ((1, 40000, 7), (2, 52000, 12)):
         rowptr, cols, vals = synth.random_csr(m, m, avg, seed=seed, kind="powerlaw")
@@ -155,6 +156,9 @@ def test_two_host_threads_two_streams(torch_dev, oracle, hiplib):
                 for strat in ("adaptive", "flat", "adaptive_plus"):
                     y = A["dy0"].clone()
                     spmv_acc_amd.csr_spmv(1.0, 1.0, A["m"], A["m"], A["nnz"], drp, dci, dv, dx, y, strategy=strat)
+                # every buffer of the contended section exists before it starts: an allocation there may free cached blocks,
+                # and hipFree waits for the whole device -- including the other thread's sleeping stream
+                outs = [torch.empty(A["m"], dtype=torch.float64, device="cuda") for _ in range(30)]
                 streams[i].synchronize()
                 go.wait()
                 if i == 0:
@@ -162,12 +166,11 @@ def test_two_host_threads_two_streams(torch_dev, oracle, hiplib):
                     held.set()
                 else:
                     held.wait()
-                outs = []
                 for it in range(30):
-                    y = A["dy0"].clone()  # (device-side copy on this thread's stream)
+                    y = outs[it]
+                    y.copy_(A["dy0"])  # (device-side copy on this thread's stream)
                     spmv_acc_amd.csr_spmv(1.0, 1.0, A["m"], A["m"], A["nnz"], drp, dci, dv, dx, y,
                                           strategy=("adaptive", "flat", "adaptive_plus")[it % 3])
-                    outs.append(y)
                 seen_streams[i] = hiplib.spmv_acc_get_stream()
                 if i == 1:
                     streams[1].synchronize()  # must not wait for stream 0's sleep
