@@ -625,7 +625,7 @@ def main():
         result["plan"] = {k: info[k] for k in ("stream_policy", "adaptive_family", "flat_fixup", "plus_blocks", "flat_tiles")}
     if rank == 0:
         result["copy_ceiling_gbs"] = round(copy_ceiling_gbs(torch, device), 1)
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_legs:
         # What the per-launch protocol costs before a single byte of a matrix moves: a 256-row diagonal matrix (one workgroup's
         # worth of work) under the same two protocols.  The small sweep matrices sit a few microseconds above this floor.
         tm = 256
