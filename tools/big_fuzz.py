@@ -89,15 +89,28 @@ for case in range(cases):
                 ("flat", {"gather_hint": 1, "hint_budget_kb": 256, "flat_npt": 8, "flat_early": 0}), ("adaptive", {}), ("line_enhance", {}), ("flat", {}), ("adaptive_plus", {}), ("default", {}), ("vector_row", {}),
                 ("line_enhance", {"rowlen": 1}), ("line_enhance", {"rowlen": 0}), ("flat", {"flat_early": 1, "flat_npt": 4}),
                 ("flat", {"flat_early": 1, "flat_npt": 8}), ("flat", {"flat_finish": 1, "flat_npt": 4}), ("flat", {"col16": 1}),
-                ("vector_row", {"vector_tile": 0}), ("light", {"vector_width": 16})]
+                ("vector_row", {"vector_tile": 0}), ("light", {"vector_width": 16}),
+                # round 3: no timing at all, opt-in column slabs, the out-of-place entry ("oop" is this script's switch, not a tunable)
+                ("adaptive", {"deterministic": 1}), ("flat", {"deterministic": 1}), ("adaptive_plus", {"deterministic": 1}),
+                ("line_enhance", {"col_slabs": 4}), ("adaptive", {"col_slabs": 8}), ("flat", {"col_slabs": 3}),
+                ("adaptive", {"oop": 1}), ("flat", {"oop": 1, "flat_finish": 0}), ("adaptive_plus", {"oop": 1}), ("vector_row", {"oop": 1})]
     for strat, knobs in variants:
         lib.spmv_acc_reset_tunables()
+        oop = bool(knobs.get("oop"))
         for k_, v_ in knobs.items():
-            assert lib.spmv_acc_set_tunable(k_.encode(), v_) == 0
+            if k_ != "oop":
+                assert lib.spmv_acc_set_tunable(k_.encode(), v_) == 0
         if knobs:
             spmv_acc_amd.release_plans(rp32[r0:])
         y = y0.clone()
-        spmv_acc_amd.csr_spmv(alpha, beta, r1 - r0, n, int(rp32[r1].item()), rp32[r0:], ci, v, x, y[r0:], strategy=strat)
+        if oop:  # y_out = alpha*A*x + beta*y_in: the old slice is read from a second vector, which must come back untouched
+            y_in = y0.clone()
+            spmv_acc_amd.csr_spmv(alpha, beta, r1 - r0, n, int(rp32[r1].item()), rp32[r0:], ci, v, x, y[r0:], strategy=strat, y_in=y_in[r0:])
+            torch.cuda.synchronize()
+            if not torch.equal(y_in, y0):
+                print(line); print("   FAIL", strat, "out-of-place call wrote y_in"); sys.exit(1)
+        else:
+            spmv_acc_amd.csr_spmv(alpha, beta, r1 - r0, n, int(rp32[r1].item()), rp32[r0:], ci, v, x, y[r0:], strategy=strat)
         torch.cuda.synchronize()
         strat = strat + (" " + str(knobs) if knobs else "")
         if not (torch.equal(y[:r0], y0[:r0]) and torch.equal(y[r1:], y0[r1:])):
