@@ -1959,7 +1959,10 @@ bool ensure_slabs(Plan &p, int S, hipStream_t st) {
             hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_slab_v), sizeof(double) * (static_cast<size_t>(A.nnz) + 4)), "hipMalloc slab values") &&
             hip_ok(hipMalloc(reinterpret_cast<void **>(&d_off), sizeof(long long) * S), "hipMalloc slab offsets") &&
             hip_ok(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16), "hipMalloc slab scan workspace");
+  // (the re-ordered colindex starts as zeros: whatever a consumer reads beyond the slabs' non-zeros is a valid column)
+  ok = ok && hip_ok(hipMemsetAsync(p.d_slab_ci, 0, sizeof(int) * (static_cast<size_t>(A.nnz) + 4), st), "memset slab colindex");
   std::vector<long long> off(S, 0);
+  long long slab_total = 0; // (a row shard handed over without rebasing: fewer than A.nnz, which is then the END offset)
   if (ok) {
     launch_slab_count(st, A, width, S, cnt);
     for (int s = 0; ok && s < S; ++s) // exclusive scan over m + 1 entries: rowptr_s, with rowptr_s[m] = the slab's non-zero count
@@ -1973,6 +1976,7 @@ bool ensure_slabs(Plan &p, int S, hipStream_t st) {
       off[s] = run;
       run += total;
     }
+    slab_total = run;
     ok = ok && hip_ok(hipMemcpyAsync(d_off, off.data(), sizeof(long long) * S, hipMemcpyHostToDevice, st), "write slab offsets");
     if (ok) {
       launch_slab_scatter(st, A, width, S, p.d_slab_rp, d_off, p.d_slab_ci, p.d_slab_v);
@@ -1988,7 +1992,7 @@ bool ensure_slabs(Plan &p, int S, hipStream_t st) {
   }
   p.slab_count = S;
   p.slab_off = off;
-  p.slab_off.push_back(A.nnz);
+  p.slab_off.push_back(slab_total);
   return true;
 }
 } // namespace

@@ -561,6 +561,22 @@ def test_col_slabs_opt_in_matches_the_oracle(torch_dev, oracle, hiplib, kind, m,
             assert hiplib.spmv_acc_cached_plans() > 1  # the parent + its slabs
             spmv_acc_amd.release_plans(drp)
             assert hiplib.spmv_acc_cached_plans() == 0, "slab plans outlived their parent"
+        # a row shard handed over WITHOUT rebasing (rowptr[0] > 0, the nnz argument is then the end offset): the slabs hold the
+        # shard's non-zeros only (an earlier form sized the last slab from the end offset and gathered through uninitialised columns)
+        r0, r1 = m // 5, m - m // 7
+        hiplib.spmv_acc_set_tunable(b"col_slabs", 3)
+        sl = slice(r0, r1)
+        sub_rp = (rowptr[r0:r1 + 1] - rowptr[r0]).astype(np.int32)
+        sub = (sub_rp, cols[rowptr[r0]:rowptr[r1]], vals[rowptr[r0]:rowptr[r1]])
+        for strat in ("flat", "line_enhance", "adaptive_plus"):
+            y = dy0.clone()
+            spmv_acc_amd.csr_spmv(1.0, 1.0, r1 - r0, n, int(rowptr[r1]), drp[r0:], dci, dv, dx, y[r0:], strategy=strat)
+            torch.cuda.synchronize()
+            got = y.cpu().numpy()
+            assert np.array_equal(got[:r0], y0[:r0]) and np.array_equal(got[r1:], y0[r1:]), (strat, "wrote outside the shard")
+            ref = oracle.host_spmv(1.0, 1.0, *sub, x, y0[sl])
+            assert oracle.scaled_error(got[sl], ref, 1.0, 1.0, *sub, x, y0[sl]) <= SCALED_TOL, (strat, "unrebased shard")
+        spmv_acc_amd.release_plans(drp[r0:])
         # the caller rewrites the structure in place (same nnz) without a release: the parent's guard still fires
         hiplib.spmv_acc_set_tunable(b"col_slabs", 4)
         y = dy0.clone()
