@@ -175,6 +175,16 @@ __device__ __forceinline__ void check_plan_guard(const int *__restrict__ rp, int
   }
 }
 
+// Second line of the guard (round 3): every workgroup compares the rowptr entries its plan-resident tables were built from -- a
+// tile's / block's boundary offsets -- with the live rowptr.  The entries are wave-uniform, so the loads are scalar (no vector
+// register, no wait before the kernel's own first wait) and the comparison is one lane's at the end of the workgroup.  The 64
+// samples above catch what shifts offsets globally; this catches an in-place edit BETWEEN the samples that moves a boundary the
+// plan relies on (flat: exactly the edits that would otherwise change a result; row-block-plus: the block's non-zero range; row
+// digest: the block bases -- lengths permuted inside one block of a digest plan remain the documented blind spot).
+__device__ __forceinline__ void raise_stale(int *__restrict__ stale) {
+  if (stale != nullptr) __hip_atomic_store(stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // y update with the documented semantics y = alpha*A*x + beta*y (api/spmv.h:14).  beta == 0 does
 // not read y (BLAS convention; for finite y it equals the reference's alpha*s + 0*y).
 // yin: where the OLD y is read.  The reference's entries update y in place (yin == y, what every in-place entry passes); the
