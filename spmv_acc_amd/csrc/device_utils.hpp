@@ -175,15 +175,13 @@ __device__ __forceinline__ void check_plan_guard(const int *__restrict__ rp, int
   }
 }
 
-// Second line of the guard (round 3): every workgroup compares the rowptr entries its plan-resident tables were built from -- a
-// tile's / block's boundary offsets -- with the live rowptr.  The entries are wave-uniform, so the loads are scalar (no vector
-// register, no wait before the kernel's own first wait) and the comparison is one lane's at the end of the workgroup.  The 64
-// samples above catch what shifts offsets globally; this catches an in-place edit BETWEEN the samples that moves a boundary the
-// plan relies on (flat: exactly the edits that would otherwise change a result; row-block-plus: the block's non-zero range; row
-// digest: the block bases -- lengths permuted inside one block of a digest plan remain the documented blind spot).
-__device__ __forceinline__ void raise_stale(int *__restrict__ stale) {
-  if (stale != nullptr) __hip_atomic_store(stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+// (Round 3 tried a second line of this guard: every workgroup comparing the boundary offsets ITS plan tables were built from -- flat's
+// tile digest, the row-block analysis' block ranges, the row digest's bases -- with the live rowptr, which would close the window
+// between the 64 samples (for flat exactly).  Two scalar loads per workgroup + one comparison cost 2-3 % on the stream-bound
+// stand-ins in all three kernels -- the scalar loads pull the kernels' first lgkmcnt wait forward; as a comparison in flat's row loop,
+// where the values are in registers anyway, 0.5-1.5 % -- in-process A/B of two builds, tools/ab_two_libs.py,
+// profiles/r03_second_line_guard_ab.txt.  Not kept: the matrices it slows sit within 2 % of the 0.70 gate, and the window it closes
+// needs an in-place edit that preserves all 64 samples.)
 
 // y update with the documented semantics y = alpha*A*x + beta*y (api/spmv.h:14).  beta == 0 does
 // not read y (BLAS convention; for finite y it equals the reference's alpha*s + 0*y).

@@ -117,7 +117,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
   const int first = rec.x;
   const int end_excl = rec.y;
   const int nrows = end_excl - first;
-
   // lanes per row for this tile: as many as the tile's row count leaves room for (wave-uniform); one with the segmented scan
   int w = 1;
   while (!SEGSUM && w < 64 && nrows * (w * 2) <= kThreads) w <<= 1;
@@ -256,11 +255,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
     }
     const int lo = (a > t0 ? a : t0) - t0;
     const int hi = (b < t1 ? b : t1) - t0;
-    // guard, second line (device_utils.hpp): the lane group that owns the tile's LAST row holds that row's live extents -- the two
-    // offsets the tile's digest was built from.  No extra load, no extra register; if they differ, the rows this tile was built
-    // around have moved (and with them what the tile may assume about cut rows).  (Not in the stream-first instances, which small grids
-    // may time in: they sit at 98 of the 100 scalar registers that keep 8 waves per SIMD, and keeping `stale` alive costs the eighth.)
-    if (!EARLY && live && lane == 0 && base + vec_id == nrows - 1 && (a != rec.z || b != rec.w)) raise_stale(stale);
     double s;
     if (SEGSUM) {
       s = hi > lo ? lds[hi - 1] : 0.0; // the scanned value at the row's last product in the tile

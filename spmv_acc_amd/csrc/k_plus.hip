@@ -91,8 +91,6 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
     const int nrows = rec.y - row_begin;
     const int s0 = rec.z;
     const int s1 = rec.w;
-    // guard, second line (device_utils.hpp): the block's non-zero range against the live rowptr (scalar loads)
-    const int live_s0 = rp[row_begin], live_s1 = rp[rec.y];
     const int a0 = s0 & ~3;
     int w = 64; // lanes per row: as many as the block's row count leaves room for
     while (w > 1 && nrows * w > kThreads) w >>= 1;
@@ -116,12 +114,10 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
     }
     acc = group_sum_dyn(acc, w);
     if (live && lane == 0 && !(r1 == r0 && keeps_y(y, yin, beta))) store_y(y, yin, row, alpha, beta, acc); // (empty row, unchanged y: skipped)
-    if (threadIdx.x == 0 && (live_s0 != s0 || live_s1 != s1)) raise_stale(stale);
   } else {
     // ---- slice [rec.z, rec.w) of the long row `row_begin` ----
     double s = 0.0;
     const int j0 = rec.z, j1 = rec.w;
-    const int live_r0 = rp[row_begin], live_r1 = rp[row_begin + 1]; // (guard, second line: the slice must lie inside its row)
     {
       // 4 consecutive non-zeros per lane per step (one 16-B colindex load, two 16-B value loads), all steps of the slice
       // issued back to back; the slice start is aligned down to a multiple of 4 and the (at most 3 + 3) foreign elements
@@ -162,7 +158,6 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
 #pragma unroll
       for (int i = 0; i < kWaves; ++i) total += row_acc[i];
       partial[g] = total;
-      if (j0 < live_r0 || j1 > live_r1) raise_stale(stale);
     }
   }
 }

@@ -82,11 +82,6 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
     s0 = b0 & 0x7fffffff;
     s1 = base[b + 1] & 0x7fffffff;
     from_lens = b0 >= 0;
-    // guard, second line (device_utils.hpp): the digest's block bases against the live rowptr (two scalar loads per block -- the
-    // digest exists to keep the 4 B/row of rowptr out of the traffic, this is 8 B per block)
-    if (rp[row_base] != s0 || rp[row_end] != s1) {
-      if (threadIdx.x == 0) raise_stale(stale);
-    }
   } else {
     s0 = rp[row_base];
     s1 = rp[row_end];
