@@ -189,10 +189,12 @@ __device__ __forceinline__ void check_plan_guard(const int *__restrict__ rp, int
 // out-of-place entry (spmv_acc_csr_spmv_oop: y_out = alpha*A*x + beta*y_in) passes another vector, which saves an iteration
 // that keeps both vectors (and the row-sharded step, whose old slice and new slice live in different buffers) a copy of y per
 // SpMV.  Neither pointer is __restrict__ in the kernels: they may be the same vector.
-// An EMPTY row under beta == 1 updated in place keeps its value (y + alpha * 0): the tile kernels neither read nor write it
-// (keeps_y).  That is 16 B per empty row -- most of the traffic of a hypersparse matrix, and of the slabs of the opt-in column-slab
-// blocking, whose S passes over y otherwise cost as much as the matrix.  (The one observable difference: a y of -0.0 stays -0.0
-// where alpha * 0 + y would have made it +0.0.)
+// An EMPTY row under beta == 1 updated in place keeps its value (y + alpha * 0): the row-block-plus kernel neither reads nor
+// writes it (keeps_y).  That is 16 B per empty row -- a large share of the traffic of the slabs of the opt-in column-slab blocking on
+// power-law matrices (which that kernel runs), whose S passes over y otherwise cost as much as the matrix.  (The one observable
+// difference: a y of -0.0 stays -0.0 where alpha * 0 + y would have made it +0.0.)  NOT in the row-block and flat kernels: the test
+// sits in their row loop and cost 1.3-3 % on every stream-bound stand-in (in-process A/B of two builds, tools/ab_two_libs.py,
+// profiles/r03_keeps_y_ab.txt); in the row-block-plus kernel it measures nothing (+-0.3 %).
 __device__ __forceinline__ bool keeps_y(const double *y, const double *yin, double beta) { return beta == 1.0 && yin == y; }
 
 __device__ __forceinline__ void store_y(double *y, const double *yin, int row, double alpha, double beta, double s) {

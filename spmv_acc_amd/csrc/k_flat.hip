@@ -132,8 +132,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
   }
   const bool early_y = beta != 0.0;
   double y_old0 = 0.0;
-  const bool keep = keeps_y(y, yin, beta); // empty rows whose y would not change are neither read nor written (device_utils.hpp)
-  if (early_y && live0 && lane == 0 && !(keep && a0 == b0)) y_old0 = yin[first + vec_id]; // read for cut rows too (<= 2 per tile): harmless
+  if (early_y && live0 && lane == 0) y_old0 = yin[first + vec_id]; // read for cut rows too (<= 2 per tile): harmless
 
   // Finish mode (reach > 0): the tile's last row, when it starts here and runs at most `reach` non-zeros past the tile, is
   // completed by this tile's first wave.  Its overhang [t1, row end) is requested NOW, next to the stream loads -- the row's
@@ -265,8 +264,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
     if (live && lane == 0) {
       if (a >= t0 && b <= t1) {
         // complete row (possibly empty): final value
-        if (keep && a == b) {
-        } else if (base == 0 && early_y) y[r] = alpha * s + beta * y_old0;
+        if (base == 0 && early_y) y[r] = alpha * s + beta * y_old0;
         else store_y(y, yin, r, alpha, beta, s);
       } else if (a < t0) {
         // row started in an earlier tile.  Its owner (the tile it starts in) finishes a short overhang itself; only a

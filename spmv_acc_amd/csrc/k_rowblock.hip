@@ -98,9 +98,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
     r1 = rp[row + 1];
   }
   // the old y is needed only at the very end: ask for it now so its latency hides behind the whole tile
-  // (an empty row whose y would not change is neither read nor written: device_utils.hpp keeps_y)
-  const bool empty_row = (LENS && from_lens) ? len == 0 : r1 == r0;
-  const bool writer = live && lane == 0 && !(empty_row && keeps_y(y, yin, beta));
+  const bool writer = live && lane == 0;
   double y_old = 0.0;
   const bool early_y = (flags & 2) && beta != 0.0;
   if (early_y && writer) y_old = yin[row]; // (non-temporal y loads / stores were A/B-tested in round 2: no effect on any stand-in)

@@ -14,7 +14,21 @@ from spmv_acc_amd import synth
 
 strat, names = sys.argv[1], sys.argv[2].split(",")
 knobs = [kv.split("=") for kv in (sys.argv[3].split(",") if len(sys.argv) > 3 and sys.argv[3] else [])]
-libs = {"shipped": spmv_acc_amd.load_library(), "exp": spmv_acc_amd.load_library(os.path.join(ROOT, "spmv_acc_amd", "lib_exp", "libspmv_acc.so"))}
+def raw(path):  # only the entries this script calls, so that an OLDER build of the library (fewer symbols) can stand on either side
+    lib = ctypes.CDLL(path)
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    lib.spmv_acc_csr_spmv_strategy.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+    lib.spmv_acc_csr_spmv_strategy.restype = None
+    lib.spmv_acc_time_spmv.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.spmv_acc_time_spmv_total.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+    lib.spmv_acc_set_tunable.argtypes = [ctypes.c_char_p, ci]
+    lib.spmv_acc_release_plans.argtypes = [vp]
+    lib.spmv_acc_release_plans.restype = None
+    return lib
+
+
+spmv_acc_amd.load_library()  # (torch's HIP runtime first, see spmv_acc_amd.load_library)
+libs = {"shipped": raw(spmv_acc_amd.LIB_PATH), "exp": raw(os.environ.get("AB_EXP_LIB") or os.path.join(ROOT, "spmv_acc_amd", "lib_exp", "libspmv_acc.so"))}
 sid = spmv_acc_amd.strategy_id(strat)
 for name in names:
     m, n, nnz, rp, ci, v = synth.sweep_standin_torch(name)
@@ -32,7 +46,7 @@ for name in names:
                 lib.spmv_acc_csr_spmv_strategy(sid, 0, 1.0, 1.0, *args)
             torch.cuda.synchronize()
             out = (ctypes.c_float * 30)()
-            assert lib.spmv_acc_time_spmv_events(sid, 30, 1.0, 1.0, *args, y0.data_ptr(), ctypes.cast(out, ctypes.c_void_p), 0) == 0
+            assert lib.spmv_acc_time_spmv(sid, 30, 1.0, 1.0, *args, y0.data_ptr(), ctypes.cast(out, ctypes.c_void_p)) == 0
             res[key]["reset"].append(float(np.median(list(out))) * 1e3)
             tot = ctypes.c_float(0)
             assert lib.spmv_acc_time_spmv_total(sid, iters, 1.0, 1.0, *args, ctypes.addressof(tot)) == 0
