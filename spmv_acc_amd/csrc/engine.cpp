@@ -90,7 +90,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kTunableCount
 };
 #ifdef FLAT_SEGMENT_SUM_REDUCE
 constexpr int kFlatReduceBuilt = 1;
@@ -162,6 +162,11 @@ Tunable g_tunables[] = {
                                // from 1/S of x (power-law columns: the L2s then hold a hot set S times deeper; R-MAT scale 25 7.15 -> 5.5 ms
                                // with S = 8).  Costs S passes over y; loses on matrices whose gathers already hit.  After editing colindex
                                // or values in place call spmv_acc_release_plans.  0 = off (the default: plans hold no copy of the matrix)
+    {"flat_rowblock", -1, -1}, // flat on SMALL grids (below 24 Mi non-zeros) whose fixed row blocks are balanced: -1 = time the flat tile kernel
+                               // against the row-block kernel once per matrix and run the faster (a flat tile needs one more dependent hop --
+                               // tile digest -> row extents -- than a row block, which a grid of two or three workgroups per CU cannot
+                               // hide: 7-11 % per launch on the small sweep stand-ins); 0 = always the flat tile kernel; 1 = always the
+                               // row blocks where balanced.  Large grids always run the tile kernel
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -524,6 +529,7 @@ struct Plan {
   Col16 col16;                  // opt-in 16-bit column encoding (tunable col16), built on first use
   int flat_npt_choice = 0;      // timed tile size (non-zeros per lane), 0 = not timed
   bool flat_geometry_tuned = false;
+  int flat_rowblock_choice = -1;       // small grids: -1 not timed, 0 flat's own tile kernel, 1 the row-block kernel (tunable flat_rowblock)
   bool flat_early_choice = false;      // timed staging order (kept here as well: a FlatPlan is rebuilt when the tile size changes)
   int flat_mode_choice[2] = {-1, -1};  // timed cut-row form per beta class: -1 not timed, 0 tiles finish their cut rows, 1 carries + fix-up
   // persistent choices (tune cache): key of this matrix on this device, 0 = none
@@ -609,10 +615,10 @@ struct Plan {
 // the same matrix on the same device adopts them and only runs the structural passes.  Opt-in; the last line for a key wins;
 // a choice the current build cannot honour (a cut-row form that is not legal on this matrix) falls back to the safe one.
 struct TuneRecord {
-  int v[20]; // stream_policy[4][2], adaptive_family[2], flat_npt, flat_early, flat_geometry_tuned, flat_mode[2], plus_min, hint_state0, hint_use[4] (first 3)
+  int v[21]; // stream_policy[4][2], adaptive_family[2], flat_npt, flat_early, flat_geometry_tuned, flat_mode[2], plus_min, hint_state0, hint_use[3], flat_rowblock
   bool operator==(const TuneRecord &o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
 };
-constexpr int kTuneFields = 20;
+constexpr int kTuneFields = 21;
 std::mutex g_tune_mu;
 std::string g_tune_path;
 bool g_tune_path_set = false, g_tune_loaded = false;
@@ -630,7 +636,7 @@ void tune_load_locked() {
     unsigned long long key;
     while (std::fscanf(f, "%31s %llx", tag, &key) == 2) {
       TuneRecord r;
-      bool ok = std::strcmp(tag, "spmvacc1") == 0;
+      bool ok = std::strcmp(tag, "spmvacc2") == 0;
       for (int i = 0; i < kTuneFields; ++i) ok = (std::fscanf(f, "%d", &r.v[i]) == 1) && ok;
       if (ok) g_tune_db[key] = r;
     }
@@ -648,7 +654,7 @@ unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *sample
     const unsigned char *c = static_cast<const unsigned char *>(p);
     for (size_t i = 0; i < bytes; ++i) h = (h ^ c[i]) * 1099511628211ULL;
   };
-  static const char kVersion[] = "spmv_acc_amd 0.3 tune v1";
+  static const char kVersion[] = "spmv_acc_amd 0.3 tune v2";
   mix(kVersion, sizeof(kVersion));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
@@ -680,6 +686,7 @@ TuneRecord tune_snapshot(const Plan &p) {
   r.v[k++] = p.plus_tuned_min;
   r.v[k++] = p.hint_state == 0 ? 0 : -1; // only "the census found nothing to protect" is worth keeping: the bits themselves are rebuilt
   for (int f = 0; f < 3; ++f) r.v[k++] = p.hint_use[f];
+  r.v[k++] = p.flat_rowblock_choice;
   return r;
 }
 } // namespace
@@ -720,6 +727,7 @@ void tune_adopt(Plan &p) {
   ++k;
   if (r.v[k++] == 0) p.hint_state = 0;
   for (int f = 0; f < 3; ++f, ++k) p.hint_use[f] = in(r.v[k], 0, 1) ? r.v[k] : -1;
+  p.flat_rowblock_choice = in(r.v[k], 0, 1) ? r.v[k] : -1;
   tune_log("m %d nnz %d: choices adopted from the tune cache (key %016llx)", p.A.m, p.A.nnz, p.tune_key);
 }
 // after a call that did plan work: keep what the plan now knows
@@ -732,7 +740,7 @@ void tune_store(const Plan &p) {
   if (it != g_tune_db.end() && it->second == r) return;
   g_tune_db[p.tune_key] = r;
   if (FILE *f = std::fopen(g_tune_path.c_str(), "a")) { // one line, one write: concurrent processes interleave whole lines
-    std::string line = "spmvacc1 ";
+    std::string line = "spmvacc2 ";
     char buf[32];
     std::snprintf(buf, sizeof(buf), "%016llx", p.tune_key);
     line += buf;
@@ -1625,6 +1633,7 @@ template <class Launch> bool autotune_hint(Plan &p, int fam, hipStream_t st, Lau
 
 bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y,
                   bool allow_uneven_switch);
+bool probe_rowblock(Plan &p, int rpb, hipStream_t st);
 
 // A flat tile is one workgroup and walks its rows 256 at a time.  Where a tile owns tens of thousands of rows (hypersparse
 // matrices: 50 M rows with 6000 non-zeros put all of them into ONE tile, 96 ms) the rows, not the non-zeros, need cutting: such
@@ -1648,6 +1657,40 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
   if (!autotune_flat_mode(p, st, x)) return false;
   if (!autotune_flat_geometry(p, st, x)) return false;
   if (!autotune_hint(p, kFamFlat, st, [&](double *ys) { launch_flat_with(st, p, policy_for(p, kFamFlat), 1.0, trial_beta(), x, ys); })) return false;
+  // Small grids: the tile kernel's extra dependent hop (tile digest -> row extents) is not hidden by other workgroups.  Where the
+  // fixed row blocks are balanced (nothing for non-zero-cut tiles to repair) the two kernels are timed once and the faster runs.
+  const int rb_mode = tun(kT_flat_rowblock);
+  if (rb_mode != 0 && p.A.nnz < kFlatSmallNnz && !flat_segment_sum() && tun(kT_col16) <= 0 && !tun(kT_rescue_flat) && !t_coarse_tuning) {
+    if (rb_mode > 0) {
+      int vec = 1, rpb = kThreads;
+      pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
+      if (t_capturing ? (p.rowblock_ok == 1 && p.rowblock_rpb == rpb) : (probe_rowblock(p, rpb, st) && p.rowblock_ok == 1))
+        return run_rowblock(st, p, nullptr, alpha, beta, x, y, false);
+    } else if (p.flat_rowblock_choice < 0 && !t_capturing && !tun(kT_deterministic)) {
+      int vec = 1, rpb = kThreads;
+      pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
+      if (!probe_rowblock(p, rpb, st)) return false;
+      p.flat_rowblock_choice = 0;
+      if (p.rowblock_ok == 1) {
+        ++t_plan_work;
+        double *scratch = nullptr;
+        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y")) return false;
+        TuneTimer timer;
+        timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
+        bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
+        float ms_flat = 0.f, ms_rb = 0.f;
+        ok = ok && run_rowblock(st, p, nullptr, 1.0, trial_beta(), x, scratch, false); // (builds and tunes the row-block side)
+        ok = ok && timer.time(st, [&] { launch_flat_with(st, p, policy_for(p, kFamFlat), 1.0, trial_beta(), x, scratch); }, &ms_flat);
+        ok = ok && timer.time(st, [&] { (void)run_rowblock(st, p, nullptr, 1.0, trial_beta(), x, scratch, false); }, &ms_rb);
+        (void)hipFree(scratch);
+        if (!ok) return false;
+        p.flat_rowblock_choice = ms_rb < 0.97f * ms_flat ? 1 : 0;
+        tune_log("m %d nnz %d flat on a small grid: tile kernel %.2f us, row blocks %.2f us -> %s", p.A.m, p.A.nnz, ms_flat * 1e3f, ms_rb * 1e3f,
+                 p.flat_rowblock_choice ? "row blocks" : "tile kernel");
+      }
+    }
+    if (rb_mode < 0 && p.flat_rowblock_choice == 1) return run_rowblock(st, p, nullptr, alpha, beta, x, y, false);
+  }
   launch_flat_with(st, p, policy_for(p, kFamFlat), alpha, beta, x, y);
   return true;
 }

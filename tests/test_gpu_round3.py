@@ -501,7 +501,7 @@ def test_tune_cache_is_adopted_by_the_next_process(torch_dev, tmp_path):
     first, log1 = _run_child(tmp_path, "p1", strategies, {"SPMV_ACC_TUNE_CACHE": cache})
     assert "stream policy" in log1 and "adopted" not in log1
     lines = open(cache).read().splitlines()
-    assert lines and all(ln.startswith("spmvacc1 ") and len(ln.split()) == 22 for ln in lines)
+    assert lines and all(ln.startswith("spmvacc2 ") and len(ln.split()) == 23 for ln in lines)
     second, log2 = _run_child(tmp_path, "p2", strategies, {"SPMV_ACC_TUNE_CACHE": cache})
     assert "adopted from the tune cache" in log2
     assert "stream policy" not in log2 and "-> family" not in log2 and "flat cut rows" not in log2, log2[-2000:]
