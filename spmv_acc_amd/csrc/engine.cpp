@@ -1660,7 +1660,10 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
   // Small grids: the tile kernel's extra dependent hop (tile digest -> row extents) is not hidden by other workgroups.  Where the
   // fixed row blocks are balanced (nothing for non-zero-cut tiles to repair) the two kernels are timed once and the faster runs.
   const int rb_mode = tun(kT_flat_rowblock);
-  if (rb_mode != 0 && p.A.nnz < kFlatSmallNnz && !flat_segment_sum() && tun(kT_col16) <= 0 && !tun(kT_rescue_flat) && !t_coarse_tuning) {
+  // (a caller that pins any of the tile kernel's own choices -- cut-row form, tile size, staging order -- is asking for that kernel)
+  const bool tile_pinned = tun(kT_flat_finish) >= 0 || tun(kT_flat_npt) >= 0 || tun(kT_flat_early) >= 0;
+  if (rb_mode != 0 && (rb_mode > 0 || !tile_pinned) && p.A.nnz < kFlatSmallNnz && !flat_segment_sum() && tun(kT_col16) <= 0 &&
+      !tun(kT_rescue_flat) && !t_coarse_tuning) {
     if (rb_mode > 0) {
       int vec = 1, rpb = kThreads;
       pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);

@@ -292,7 +292,8 @@ def test_opt_in_col16_encoding_matches_plain_flat(torch_dev, oracle, hiplib):
             for mode in (0, 1):
                 for finish in (0, 1):
                     hiplib.spmv_acc_reset_tunables()
-                    for k, val in (("col16", mode), ("flat_npt", 8), ("flat_finish", finish), ("flat_early", 0), ("stream_plain", 1)):
+                    for k, val in (("col16", mode), ("flat_npt", 8), ("flat_finish", finish), ("flat_early", 0), ("stream_plain", 1),
+                                   ("flat_rowblock", 0)):  # (round 3: small balanced grids may otherwise run the row-block kernel)
                         assert hiplib.spmv_acc_set_tunable(k.encode(), val) == 0
                     dy = dev(torch, y0)
                     spmv_acc_amd.csr_spmv(0.5, -2.0, m, n, nnz, drp, dci, dv, dx, dy, strategy="flat")
