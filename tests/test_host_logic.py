@@ -247,3 +247,36 @@ def test_cmake_accepts_the_reference_cache_variables(tmp_path):
     assert out.returncode != 0 and "unsupported kernel strategy" in out.stderr
     out = subprocess.run(["cmake", "-S", ROOT, "-B", str(tmp_path / "bad2"), "-DWF_REDUCE=tree"] + common[:-2], capture_output=True, text=True)
     assert out.returncode != 0 and "unsupported wavefront reduction strategy" in out.stderr
+
+
+def test_round3_switches_and_entry_points_without_a_gpu(hiplib, tmp_path):
+    """Host-side behaviour of the round-3 surface that needs no device: SPMV_ACC_DETERMINISTIC seeds the tunable; the tune-cache
+    setter accepts a path / None; the library stream is per host thread; the shard handle API refuses bad arguments before it
+    looks for RCCL or a device; the all-plans stale check is a no-op on an empty cache."""
+    import ctypes
+    import threading
+
+    code = "import spmv_acc_amd as s; l = s.load_library(); print(l.spmv_acc_get_tunable(b'deterministic'), l.spmv_acc_get_tunable(b'col_slabs'))"
+    for env_val, want in (("1", "1"), ("0", "0")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, SPMV_ACC_DETERMINISTIC=env_val, PYTHONPATH=ROOT))
+        assert r.returncode == 0 and r.stdout.split() == [want, "0"], (r.stdout, r.stderr[-500:])
+    spmv_acc_amd.set_tune_cache(str(tmp_path / "tune.txt"))
+    spmv_acc_amd.set_tune_cache(None)
+    assert hiplib.spmv_acc_check_plans() == 0 and hiplib.spmv_acc_cached_plans() == 0
+    # stream: set here, invisible to another thread, restored
+    hiplib.spmv_acc_set_stream(ctypes.c_void_p(0x1234))
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(hiplib.spmv_acc_get_stream()))
+    t.start()
+    t.join()
+    assert hiplib.spmv_acc_get_stream() == 0x1234 and seen == [None]
+    hiplib.spmv_acc_set_stream(None)
+    shard = ctypes.c_void_p()
+    dummy = ctypes.c_void_p(0x10)
+    assert hiplib.spmv_acc_shard_create(ctypes.byref(shard), None, 1, 10, 10, 10, 5, dummy, dummy, dummy, 1) == 2  # no communicator
+    assert hiplib.spmv_acc_shard_create(ctypes.byref(shard), dummy, 1, 10, 9, 10, 5, dummy, dummy, dummy, 1) == 2  # pad < rows
+    assert hiplib.spmv_acc_shard_create(None, dummy, 1, 10, 10, 10, 5, dummy, dummy, dummy, 1) == 2
+    assert hiplib.spmv_acc_shard_step(None, 1.0, 0.0, dummy, None, dummy) == 2 and hiplib.spmv_acc_shard_destroy(None) == 0
+    assert hiplib.spmv_acc_shard_pipeline(None) == 0
+    hiplib.spmv_acc_clear_error()
