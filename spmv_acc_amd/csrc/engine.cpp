@@ -90,7 +90,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kTunableCount
 };
 #ifdef FLAT_SEGMENT_SUM_REDUCE
 constexpr int kFlatReduceBuilt = 1;
@@ -167,6 +167,9 @@ Tunable g_tunables[] = {
                                // tile digest -> row extents -- than a row block, which a grid of two or three workgroups per CU cannot
                                // hide: 7-11 % per launch on the small sweep stand-ins); 0 = always the flat tile kernel; 1 = always the
                                // row blocks where balanced.  Large grids always run the tile kernel
+    {"legacy_kernels", 1, 1},  // KERNEL_STRATEGY LIGHT / BLOCK_ROW_ORDINARY: 1 = their own kernels (k_legacy.hip: rows handed out by an atomic
+                               // counter; one workgroup per row -- what the names mean in the reference), 0 = the round-1/2 stand-ins (the
+                               // vector-row tile kernel; one wavefront per row), which are faster on most matrices
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -536,6 +539,7 @@ struct Plan {
   unsigned long long tune_key = 0;
   // opt-in column-slab blocking (tunable col_slabs): the slabs' row pointers (S * (m + 1) ints), the re-ordered colindex / values,
   // where each slab starts in them, and each slab's non-zero count
+  unsigned *d_light_counter = nullptr; // LIGHT's row counter (k_legacy.hip)
   int slab_count = 0;
   int *d_slab_rp = nullptr;
   int *d_slab_ci = nullptr;
@@ -578,6 +582,8 @@ struct Plan {
   void free_slabs();
   void free_device() {
     free_slabs();
+    if (d_light_counter) (void)hipFree(d_light_counter);
+    d_light_counter = nullptr;
     if (d_cold) (void)hipFree(d_cold);
     d_cold = nullptr;
     hint_state = -1;
@@ -2146,7 +2152,30 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   }
 
   const long long avg = static_cast<long long>(p->A.nnz) / m;
+  // a resident grid for the two persistent-style legacy kernels: CUs x 8 workgroups of 4 waves
+  auto resident_blocks = [&]() {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || cus <= 0) cus = 256;
+    (void)hipGetLastError();
+    return cus * 8;
+  };
+  if (strategy == kLight && tun(kT_legacy_kernels)) {
+    // LightSpMV (hip-light/light_spmv.cpp:16-41): lanes per row from the average row length (its thresholds: vector_row.cpp's
+    // table), rows handed out by the plan's counter
+    if (!p->d_light_counter) {
+      if (!plan_work_allowed("LIGHT's row counter")) return;
+      ++t_plan_work;
+      if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p->d_light_counter), sizeof(unsigned)), "hipMalloc light counter")) return;
+    }
+    launch_light(st, p->A, classic_vec(avg), resident_blocks(), p->d_light_counter, alpha, beta, dx, dy);
+    strategy = -1; // handled
+  } else if (strategy == kBlockRowOrdinary && tun(kT_legacy_kernels)) {
+    launch_block_row(st, p->A, resident_blocks(), alpha, beta, dx, dy); // hip-block-row-ordinary/spmv_hip_acc_imp.cpp:16-75
+    strategy = -1;
+  }
   switch (strategy) {
+  case -1:
+    break;
   case kLight:
   case kVectorRow:
   {

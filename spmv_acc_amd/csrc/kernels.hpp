@@ -62,6 +62,12 @@ void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int 
                         int target_products, int xcd_chunk, int stream_policy, double alpha, double beta, const double *x,
                         double *y, bool reverse = false);
 
+// genuine LIGHT (rows handed out by an atomic counter, w lanes per row) and BLOCK_ROW_ORDINARY (one workgroup per row) -- k_legacy.hip.
+// counter: one plan-resident unsigned, zeroed by a memset in front of every launch.  grid_blocks: a resident grid (CUs x 8).
+void launch_light(hipStream_t stream, const CsrDev &A, int w, int grid_blocks, unsigned *counter, double alpha, double beta, const double *x,
+                  double *y);
+void launch_block_row(hipStream_t stream, const CsrDev &A, int grid_blocks, double alpha, double beta, const double *x, double *y);
+
 // wavefront-per-row for long rows: 4 consecutive non-zeros per lane per step (16-B loads), two steps in flight.
 void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y);
 

@@ -594,3 +594,64 @@ def test_col_slabs_opt_in_matches_the_oracle(torch_dev, oracle, hiplib, kind, m,
         hiplib.spmv_acc_clear_error()
         hiplib.spmv_acc_reset_tunables()
         spmv_acc_amd.release_plans()
+
+
+# ---- genuine LIGHT and BLOCK_ROW_ORDINARY kernels (the last two KERNEL_STRATEGY names that were aliases) -----------------------------
+def test_light_and_block_row_run_their_own_kernels(torch_dev, oracle, hiplib):
+    """KERNEL_STRATEGY=LIGHT hands rows out through an atomic counter (LightSpMV, hip-light/spmv_hip_acc_imp.inl:36-76), BLOCK_ROW_ORDINARY
+    gives every row a whole workgroup (hip-block-row-ordinary/spmv_hip_acc_imp.cpp:16-66).  Both against the oracle on matrices that
+    exercise their corners -- every lane width of LIGHT (average row length 1 .. 200), rows far longer than a workgroup's step, empty
+    rows, a row count that is not a multiple of the fetch size, fewer rows than the resident grid -- with general alpha / beta, out of
+    place, inside a hipGraph (LIGHT's counter is zeroed by a memset node), and bitwise reproducible although LIGHT's row-to-wave
+    assignment changes from launch to launch.  `legacy_kernels = 0` brings the round-2 stand-ins back."""
+    torch = torch_dev
+    cases = []
+    for avg, m in ((1, 50_001), (3, 40_000), (7, 30_011), (14, 20_000), (30, 9_000), (60, 5_000), (200, 1_500)):
+        cases.append((f"avg {avg}", synth.random_csr(m, m, avg, seed=avg, kind="powerlaw" if avg > 3 else "uniform")))
+    cases.append(("empty rows", synth.random_csr(20_000, 20_000, 6, seed=4, kind="empty_rows")))
+    cases.append(("spikes", synth.random_csr(3_000, 40_000, 9, seed=5, kind="spikes")))
+    cases.append(("tiny", synth.random_csr(37, 50, 4, seed=6, kind="uniform")))
+    rng = np.random.default_rng(2)
+    side = torch.cuda.Stream()
+    try:
+        for tag, (rowptr, cols, vals) in cases:
+            m, n, nnz = rowptr.size - 1, int(cols.max()) + 1 if cols.size else 1, int(rowptr[-1])
+            x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+            drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+            for strat in ("light", "block_row_ordinary"):
+                for alpha, beta in ((1.0, 1.0), (0.5, -2.0), (2.0, 0.0)):
+                    ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+                    y = dy0.clone()
+                    spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y, strategy=strat)
+                    y2 = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+                    spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y2, strategy=strat, y_in=dy0)
+                    torch.cuda.synchronize()
+                    assert oracle.scaled_error(y.cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL, (tag, strat, alpha, beta)
+                    assert torch.equal(y, y2), (tag, strat, "out of place / run-to-run")  # same sums whichever wave took which rows
+                # captured and replayed (LIGHT: memset node + kernel node)
+                with torch.cuda.stream(side):
+                    static_y = dy0.clone()
+                    spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, static_y, strategy=strat)
+                side.synchronize()
+                eager = static_y.clone()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, static_y, strategy=strat)
+                for _ in range(2):
+                    static_y.copy_(dy0)
+                    g.replay()
+                    torch.cuda.synchronize()
+                    assert torch.equal(static_y, eager), (tag, strat, "graph replay")
+            # the stand-ins are still there
+            hiplib.spmv_acc_set_tunable(b"legacy_kernels", 0)
+            y = dy0.clone()
+            spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy="light")
+            torch.cuda.synchronize()
+            ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+            assert oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, tag
+            hiplib.spmv_acc_reset_tunables()
+            spmv_acc_amd.release_plans(drp)
+    finally:
+        hiplib.spmv_acc_set_stream(None)
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans()
