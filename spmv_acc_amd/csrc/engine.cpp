@@ -2165,7 +2165,10 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     if (!p->d_light_counter) {
       if (!plan_work_allowed("LIGHT's row counter")) return;
       ++t_plan_work;
-      if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p->d_light_counter), sizeof(unsigned)), "hipMalloc light counter")) return;
+      if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&p->d_light_counter), 2 * sizeof(unsigned)), "hipMalloc light counter") ||
+          !hip_ok(hipMemsetAsync(p->d_light_counter, 0, 2 * sizeof(unsigned), st), "memset light counter") ||
+          !hip_ok(hipStreamSynchronize(st), "sync light counter"))
+        return;
     }
     launch_light(st, p->A, classic_vec(avg), resident_blocks(), p->d_light_counter, alpha, beta, dx, dy);
     strategy = -1; // handled

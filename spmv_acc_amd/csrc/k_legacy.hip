@@ -10,8 +10,10 @@
 //   * hip-block-row-ordinary/spmv_hip_acc_imp.cpp:16-66: one 256-thread block per row, a fixed grid of 64 blocks striding over the
 //     rows, a 256-entry LDS tree per row with commented-out barriers between its levels (SURVEY.md A.3 lists it among the latent races).
 // What is kept: the work distribution that defines each strategy -- rows handed out by an atomic counter; a whole workgroup per row.
-// What is different (MI355X-first): the counter lives in the plan and is zeroed by a memset node in front of the launch (no
-// malloc / free per call, capturable); a fetch takes a batch of 8 * (64 / w) rows so that a lane group keeps 8 rows' loads in flight
+// What is different (MI355X-first): the counter lives in the plan and the kernel leaves it at zero itself -- the last wavefront
+// to finish resets it (a second counter tells which one is last) -- so a call is ONE launch with no malloc / memset / free around it
+// and replays from a hipGraph (a memset node in front of the kernel was the first form: under torch's graph capture the replayed
+// kernel found the counter unreset and did nothing); a fetch takes a batch of 8 * (64 / w) rows so that a lane group keeps 8 rows' loads in flight
 // and the counter sees 1/8 of the atomics; the grid is sized from the device (CUs x resident waves), not a constant 256 x 256;
 // general alpha / beta and the out-of-place old y like every other kernel.  Block-per-row: 16-B stream loads, 4 non-zeros per lane per
 // step, DPP wave sums and ONE barrier per row (4 partials through LDS) instead of an 8-level tree.
@@ -28,7 +30,8 @@ using namespace dev;
 
 constexpr int kLightRowsPerGroup = 8; // rows a lane group takes from one fetch (their loads are issued together)
 
-// w lanes per row (wave-uniform, power of two <= 64).  counter: rows handed out so far.
+// w lanes per row (wave-uniform, power of two <= 64).  counter[0]: rows handed out so far; counter[1]: wavefronts that have finished.
+// Both are zero when a launch starts and when it ends.
 __global__ __launch_bounds__(kThreads) void light_kernel(int m, int w, double alpha, double beta, unsigned *__restrict__ counter,
                                                          const int *__restrict__ rp, const int *__restrict__ ci,
                                                          const double *__restrict__ v, const double *__restrict__ x, double *y,
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(kThreads) void light_kernel(int m, int w, double al
     unsigned fetched = 0;
     if (lane_in_wave == 0) fetched = atomicAdd(counter, static_cast<unsigned>(batch));
     fetched = __shfl(fetched, 0, kWave);
-    if (fetched >= static_cast<unsigned>(m)) break; // every wavefront reaches this: the counter only grows
+    if (fetched >= static_cast<unsigned>(m)) break; // every wavefront reaches this: counter[0] only grows while any wavefront runs
     const int base = static_cast<int>(fetched);
     // rows base + group + k * groups, k = 0 .. 7: neighbouring groups read neighbouring rowptr entries
     int j0[kLightRowsPerGroup], j1[kLightRowsPerGroup];
@@ -70,6 +73,14 @@ __global__ __launch_bounds__(kThreads) void light_kernel(int m, int w, double al
       const double sum = group_sum_dyn(s[k], w); // every lane takes part (DPP needs a full exec mask)
       const long long row = static_cast<long long>(base) + group + k * groups;
       if (row < m && lane == 0) store_y(y, yin, static_cast<int>(row), alpha, beta, sum);
+    }
+  }
+  // the last wavefront out puts both counters back to zero for the next launch (every other wavefront has made its last fetch)
+  if (lane_in_wave == 0) {
+    const unsigned waves = gridDim.x * (kThreads / kWave);
+    if (atomicAdd(counter + 1, 1u) == waves - 1) {
+      counter[0] = 0;
+      counter[1] = 0;
     }
   }
 }
@@ -120,7 +131,6 @@ __global__ __launch_bounds__(kThreads) void block_row_kernel(int m, int nnz, dou
 void launch_light(hipStream_t stream, const CsrDev &A, int w, int grid_blocks, unsigned *counter, double alpha, double beta, const double *x,
                   double *y) {
   if (A.m <= 0) return;
-  (void)hipMemsetAsync(counter, 0, sizeof(unsigned), stream); // (a memset node under capture; the reference: hipMalloc + hipMemset + hipFree per call)
   hipLaunchKernelGGL(light_kernel, dim3(grid_blocks), dim3(kThreads), 0, stream, A.m, w, alpha, beta, counter, A.rp, A.ci, A.v, x, y,
                      A.yin ? A.yin : y, A.guard, A.stale);
 }

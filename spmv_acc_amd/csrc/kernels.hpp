@@ -63,7 +63,7 @@ void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int 
                         double *y, bool reverse = false);
 
 // genuine LIGHT (rows handed out by an atomic counter, w lanes per row) and BLOCK_ROW_ORDINARY (one workgroup per row) -- k_legacy.hip.
-// counter: one plan-resident unsigned, zeroed by a memset in front of every launch.  grid_blocks: a resident grid (CUs x 8).
+// counter: two plan-resident unsigneds, zero between launches (the kernel's last wavefront resets them).  grid_blocks: a resident grid (CUs x 8).
 void launch_light(hipStream_t stream, const CsrDev &A, int w, int grid_blocks, unsigned *counter, double alpha, double beta, const double *x,
                   double *y);
 void launch_block_row(hipStream_t stream, const CsrDev &A, int grid_blocks, double alpha, double beta, const double *x, double *y);

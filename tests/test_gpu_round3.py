@@ -602,7 +602,7 @@ def test_light_and_block_row_run_their_own_kernels(torch_dev, oracle, hiplib):
     gives every row a whole workgroup (hip-block-row-ordinary/spmv_hip_acc_imp.cpp:16-66).  Both against the oracle on matrices that
     exercise their corners -- every lane width of LIGHT (average row length 1 .. 200), rows far longer than a workgroup's step, empty
     rows, a row count that is not a multiple of the fetch size, fewer rows than the resident grid -- with general alpha / beta, out of
-    place, inside a hipGraph (LIGHT's counter is zeroed by a memset node), and bitwise reproducible although LIGHT's row-to-wave
+    place, inside a hipGraph (LIGHT's counter is left at zero by the kernel's last wavefront: one node), and bitwise reproducible although LIGHT's row-to-wave
     assignment changes from launch to launch.  `legacy_kernels = 0` brings the round-2 stand-ins back."""
     torch = torch_dev
     cases = []
@@ -628,7 +628,7 @@ def test_light_and_block_row_run_their_own_kernels(torch_dev, oracle, hiplib):
                     torch.cuda.synchronize()
                     assert oracle.scaled_error(y.cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL, (tag, strat, alpha, beta)
                     assert torch.equal(y, y2), (tag, strat, "out of place / run-to-run")  # same sums whichever wave took which rows
-                # captured and replayed (LIGHT: memset node + kernel node)
+                # captured and replayed
                 with torch.cuda.stream(side):
                     static_y = dy0.clone()
                     spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, static_y, strategy=strat)
