@@ -210,6 +210,14 @@ int spmv_acc_prepare_beta(int strategy, double beta, int m, int n, int nnz, cons
  *     rule on the matrix' shape -- y is then bitwise equal across processes and runs (the kernels never use atomics). */
 void spmv_acc_set_tune_cache(const char *path);
 
+/* ---- values changed in place, with the opt-in column slabs in use (new) ---------------------------------------------------------
+ * Every plan survives in-place edits of `value` (the reference keeps nothing between calls) -- except the one opt-in mode whose plan
+ * holds a re-ordered COPY of the matrix (tunable col_slabs).  After changing values in place, call this instead of dropping the plan:
+ * one scatter pass re-copies the values into the slabs (enqueued on the calling thread's library stream, ordered before later
+ * SpMVs on it); the slabs' structure, plans and timed choices stay.  Returns the number of plans refreshed (0: the matrix has no
+ * slabs, nothing to do).  A changed STRUCTURE (rowptr / colindex) still needs spmv_acc_release_plans. */
+int spmv_acc_refresh_values(const int *d_rowptr);
+
 /* Host microseconds the calling thread's most recent SpMV call spent preparing its matrix (structural passes + per-matrix
  * timings of the FIRST call on a matrix); 0 when the plan already existed.
  * replaces: BenchmarkTime::pre of the reference's harness (benchmark/utils/benchmark_time.cpp:23-43,

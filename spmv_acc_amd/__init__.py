@@ -39,7 +39,7 @@ C_ABI_SYMBOLS = (
     "spmv_acc_last_prepare_us", "spmv_acc_sharded_spmv", "spmv_acc_csr_spmv_oop", "spmv_acc_check_plans",
     "spmv_acc_query_plan_beta0", "spmv_acc_shard_create", "spmv_acc_shard_step", "spmv_acc_shard_pipeline",
     "spmv_acc_shard_destroy", "spmv_acc_rccl_comm_init_all", "spmv_acc_rccl_comm_destroy", "spmv_acc_set_tune_cache",
-    "spmv_acc_prepare_beta", "spmv_acc_time_spmv_events",
+    "spmv_acc_prepare_beta", "spmv_acc_time_spmv_events", "spmv_acc_refresh_values",
 )
 
 _lib = None
@@ -121,6 +121,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_rccl_comm_destroy.argtypes = [vp]
     lib.spmv_acc_set_tune_cache.argtypes = [ctypes.c_char_p]
     lib.spmv_acc_set_tune_cache.restype = None
+    lib.spmv_acc_refresh_values.argtypes = [vp]
     lib.spmv_acc_prepare_beta.argtypes = [ci, cd, ci, ci, ci, vp, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     if path is None:
         _lib = lib
@@ -351,6 +352,12 @@ def release_plans(rowptr=None) -> None:
 def set_tune_cache(path: Optional[str]) -> None:
     """Persist the per-matrix timed choices in ``path`` (None: off); see include/spmv_acc.h."""
     load_library().spmv_acc_set_tune_cache(path.encode() if path else None)
+
+
+def refresh_values(rowptr) -> int:
+    """After changing ``value`` in place while the opt-in column slabs (tunable col_slabs) are in use: re-copy the values into the
+    plan's slabs.  Returns the number of plans refreshed."""
+    return int(load_library().spmv_acc_refresh_values(_ptr(rowptr)))
 
 
 def check_plans() -> int:

@@ -318,6 +318,7 @@ const char *spmv_acc_last_error_string(void) { return last_error_string(); }
 void spmv_acc_clear_error(void) { clear_error(); }
 
 void spmv_acc_set_tune_cache(const char *path) { set_tune_cache(path); }
+int spmv_acc_refresh_values(const int *d_rowptr) { return refresh_values(d_rowptr); }
 
 int spmv_acc_prepare(int strategy, int m, int n, int nnz, const int *h_rowptr, const int *d_rowptr, const int *d_colindex,
                      const double *d_value, const double *dx, float *ms_out) {

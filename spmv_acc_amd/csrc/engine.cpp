@@ -160,8 +160,9 @@ Tunable g_tunables[] = {
     {"col_slabs", 0, 0},       // OPT-IN column-slab blocking (k_slab.hip): S >= 2 = the plan holds a re-ordered COPY of colindex and values,
                                // A = sum of S column-range slabs, and an SpMV is S consecutive SpMVs of the named strategy, each gathering
                                // from 1/S of x (power-law columns: the L2s then hold a hot set S times deeper; R-MAT scale 25 7.15 -> 5.5 ms
-                               // with S = 8).  Costs S passes over y; loses on matrices whose gathers already hit.  After editing colindex
-                               // or values in place call spmv_acc_release_plans.  0 = off (the default: plans hold no copy of the matrix)
+                               // with S = 8).  Costs S passes over y; loses on matrices whose gathers already hit.  After editing values
+                               // in place call spmv_acc_refresh_values, after editing colindex spmv_acc_release_plans.  0 = off (the
+                               // default: plans hold no copy of the matrix)
     {"flat_rowblock", -1, -1}, // flat on SMALL grids (below 24 Mi non-zeros) whose fixed row blocks are balanced: -1 = time the flat tile kernel
                                // against the row-block kernel once per matrix and run the faster (a flat tile needs one more dependent hop --
                                // tile digest -> row extents -- than a row block, which a grid of two or three workgroups per CU cannot
@@ -541,6 +542,8 @@ struct Plan {
   // where each slab starts in them, and each slab's non-zero count
   unsigned *d_light_counter = nullptr; // LIGHT's row counter (k_legacy.hip)
   int slab_count = 0;
+  int slab_width = 0;
+  long long *d_slab_off = nullptr; // the slabs' start positions, on the device (kept for spmv_acc_refresh_values)
   int *d_slab_rp = nullptr;
   int *d_slab_ci = nullptr;
   double *d_slab_v = nullptr;
@@ -770,6 +773,8 @@ void Plan::free_slabs() {
   if (d_slab_rp) (void)hipFree(d_slab_rp);
   if (d_slab_ci) (void)hipFree(d_slab_ci);
   if (d_slab_v) (void)hipFree(d_slab_v);
+  if (d_slab_off) (void)hipFree(d_slab_off);
+  d_slab_off = nullptr;
   d_slab_rp = d_slab_ci = nullptr;
   d_slab_v = nullptr;
   slab_count = 0;
@@ -2036,18 +2041,38 @@ bool ensure_slabs(Plan &p, int S, hipStream_t st) {
     }
   }
   if (cnt) (void)hipFree(cnt);
-  if (d_off) (void)hipFree(d_off);
   if (tmp) (void)hipFree(tmp);
   if (!ok) {
+    if (d_off) (void)hipFree(d_off);
     p.free_slabs();
     return false;
   }
+  p.d_slab_off = d_off;
+  p.slab_width = width;
   p.slab_count = S;
   p.slab_off = off;
   p.slab_off.push_back(slab_total);
   return true;
 }
 } // namespace
+
+// The one plan-resident copy of VALUES is the column slabs' (opt-in).  A caller that changes values in place -- which every other
+// plan survives -- refreshes it with this: one scatter pass over the matrix, the slabs' structure (and their plans) stay.
+int refresh_values(const int *d_rowptr) {
+  std::vector<std::shared_ptr<Plan>> todo;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &kv : g_plans)
+      if (std::get<1>(kv.first) == d_rowptr && kv.second->d_slab_rp) todo.push_back(kv.second);
+  }
+  hipStream_t st = t_stream;
+  for (auto &p : todo) {
+    std::lock_guard<std::mutex> plan_lock(p->mu);
+    if (!p->d_slab_rp) continue;
+    launch_slab_scatter(st, p->A, p->slab_width, p->slab_count, p->d_slab_rp, p->d_slab_off, p->d_slab_ci, p->d_slab_v, /*values_only=*/true);
+  }
+  return static_cast<int>(todo.size());
+}
 
 FlatSegmentSumScope::FlatSegmentSumScope() : prev(t_flat_segment_sum) { t_flat_segment_sum = true; }
 FlatSegmentSumScope::~FlatSegmentSumScope() { t_flat_segment_sum = prev; }

@@ -132,6 +132,9 @@ int cached_plan_count();
 // Persistent per-matrix choices (engine.cpp "tune cache"): path of the text file, null / "" = off; default = environment
 // variable SPMV_ACC_TUNE_CACHE.
 void set_tune_cache(const char *path);
+// Re-copy the caller's VALUES into the plan-resident column slabs of this matrix (tunable col_slabs; no other plan data holds values).
+// Enqueued on the calling thread's library stream; returns the number of plans refreshed.
+int refresh_values(const int *d_rowptr);
 // Drops every cached plan whose stale flag is up (any thread's) and returns how many; records SPMV_ACC_ERR_BAD_ARGUMENT if any.
 int check_plans();
 

@@ -7,7 +7,8 @@
 // With S slabs a phase gathers from 1/S of x only: the L2s hold a hot set S times deeper (tools/micro/xcd_slab_gather_bench.hip:
 // 67 -> 109 G gathers/s with an eighth of x per L2; tools/col_slab_probe.py: R-MAT scale 25 7.15 -> 5.46 ms with S = 8) at the price
 // of S passes over y and S row-pointer arrays.  The plan then holds a re-ordered COPY of colindex and values, which is why this is
-// opt-in like the 16-bit column stream: after editing colindex or values in place, call spmv_acc_release_plans.
+// opt-in like the 16-bit column stream: after editing VALUES in place call spmv_acc_refresh_values (one scatter pass, the slabs'
+// structure and plans stay), after editing the structure spmv_acc_release_plans.
 //
 // Build (once per plan, order inside a row preserved, no atomics): one wavefront per row, 64 non-zeros per step;
 //   count  : per step one ballot per slab, lane s keeps slab s's count            -> cnt[s][row]
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(kThreads) void slab_count_kernel(const int *__restr
 __global__ __launch_bounds__(kThreads) void slab_scatter_kernel(const int *__restrict__ rp, const int *__restrict__ ci,
                                                                 const double *__restrict__ v, int m, int width, int S,
                                                                 const int *__restrict__ rps, const long long *__restrict__ off,
-                                                                int *__restrict__ ci_out, double *__restrict__ v_out) {
+                                                                int *__restrict__ ci_out, double *__restrict__ v_out, int values_only) {
   const int lane = threadIdx.x & (kWave - 1);
   const long long waves = static_cast<long long>(gridDim.x) * (kThreads / kWave);
   for (long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave; row < m; row += waves) {
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(kThreads) void slab_scatter_kernel(const int *__res
         const long long at = __shfl(pos, s, kWave);
         if (slab == s) {
           const long long dst = at + __popcll(mask & ((1ULL << lane) - 1ULL));
-          ci_out[dst] = c;
+          if (!values_only) ci_out[dst] = c; // (values_only: the caller changed values in place and asked for a refresh)
           v_out[dst] = a;
         }
         if (lane == s) pos += __popcll(mask);
@@ -83,12 +84,12 @@ void launch_slab_count(hipStream_t stream, const CsrDev &A, int width, int S, in
 }
 
 void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, const int *rps, const long long *off, int *ci_out,
-                         double *v_out) {
+                         double *v_out, bool values_only) {
   if (A.m <= 0) return;
   long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave);
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(slab_scatter_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.v, A.m, width, S,
-                     rps, off, ci_out, v_out);
+                     rps, off, ci_out, v_out, values_only ? 1 : 0);
 }
 
 } // namespace spmv_acc

@@ -184,7 +184,7 @@ void plus_analyze_device_emit(hipStream_t stream, const int *rp, int m, int min_
 // cnt / rps: S * (m + 1) ints, slab-major; off: S exclusive sums of the slabs' non-zero counts (device, 64-bit)
 void launch_slab_count(hipStream_t stream, const CsrDev &A, int width, int S, int *cnt);
 void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, const int *rps, const long long *off, int *ci_out,
-                         double *v_out);
+                         double *v_out, bool values_only = false);
 
 // dst = src over `bytes` (16-B granules) with the kernels' streaming load shape: the copy ceiling probe
 void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes, bool non_temporal);

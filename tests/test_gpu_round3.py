@@ -577,6 +577,25 @@ def test_col_slabs_opt_in_matches_the_oracle(torch_dev, oracle, hiplib, kind, m,
             ref = oracle.host_spmv(1.0, 1.0, *sub, x, y0[sl])
             assert oracle.scaled_error(got[sl], ref, 1.0, 1.0, *sub, x, y0[sl]) <= SCALED_TOL, (strat, "unrebased shard")
         spmv_acc_amd.release_plans(drp[r0:])
+        # values changed in place: the slabs hold a copy -- spmv_acc_refresh_values re-copies them (structure and plans stay)
+        hiplib.spmv_acc_set_tunable(b"col_slabs", 4)
+        y = dy0.clone()
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy="adaptive")
+        torch.cuda.synchronize()
+        plans = hiplib.spmv_acc_cached_plans()
+        vals2 = vals * -0.75 + 0.125
+        dv.copy_(dev(torch, vals2))
+        assert spmv_acc_amd.refresh_values(drp) == 1
+        y = dy0.clone()
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy="adaptive")
+        torch.cuda.synchronize()
+        ref2 = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals2, x, y0)
+        assert oracle.scaled_error(y.cpu().numpy(), ref2, 1.0, 1.0, rowptr, cols, vals2, x, y0) <= SCALED_TOL
+        assert hiplib.spmv_acc_cached_plans() == plans and hiplib.spmv_acc_last_error() == 0
+        dv.copy_(dev(torch, vals))
+        assert spmv_acc_amd.refresh_values(drp) == 1
+        spmv_acc_amd.release_plans(drp)
+        assert spmv_acc_amd.refresh_values(drp) == 0  # nothing to refresh
         # the caller rewrites the structure in place (same nnz) without a release: the parent's guard still fires
         hiplib.spmv_acc_set_tunable(b"col_slabs", 4)
         y = dy0.clone()
