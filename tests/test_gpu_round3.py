@@ -674,3 +674,32 @@ def test_light_and_block_row_run_their_own_kernels(torch_dev, oracle, hiplib):
         hiplib.spmv_acc_set_stream(None)
         hiplib.spmv_acc_reset_tunables()
         spmv_acc_amd.release_plans()
+
+
+# ---- bench.py --gpus N on the GPU box: the self-launch and the N > 1 code path, two gloo ranks sharing the card ---------------------
+def test_bench_gpus_2_launches_itself_and_runs_the_sharded_step(torch_dev):
+    """`python bench.py --gpus 2` with no WORLD_SIZE -- what the driver runs when it has more than one GPU -- on this one-GPU box:
+    SPMV_ACC_BENCH_BACKEND=gloo lets the two ranks share the card (RCCL needs a GPU per rank).  The parent launches the ranks as
+    child processes, rank 0's ONE JSON line comes back with n_gpus 2, weak scaling (value counts both ranks' non-zeros), the
+    spmv_only / spmv+exchange split and the exchange form; exit status 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SPMV_ACC_BENCH_CHILD")}
+    env["SPMV_ACC_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--scale", "0.1", "--no-legs"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 10
+    assert "x2" in d["config"]["parallelism"] and "gloo" in d["config"]["parallelism"]
+    assert d["exchange"] in ("allgather", "p2p") and d["spmv_plus_exchange_ms_per_step"] > 0 and d["spmv_only_gflops_per_gpu"] > 0
+    assert d["allgather_bytes_per_rank_per_step"] == 8 * d["config"]["rows_per_gpu"]  # one peer's slice
+    # value = both ranks' non-zeros over the max-over-ranks wall time
+    assert abs(d["value"] - 2.0 * 2 * d["config"]["nnz_per_gpu"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e9) / d["value"] < 0.02
+    assert "launching 2 ranks" in r.stderr
