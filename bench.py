@@ -270,7 +270,7 @@ def extra_legs(torch, device, headline):
     return out
 
 
-def sharded_leg(torch, dist, args, W, x, y0, alpha, beta, rank, world, device, backend, force_dist, steps, warmup):
+def sharded_leg(torch, dist, args, W, x, y0, alpha, beta, rank, world, device, backend, force_dist, steps, warmup, bounds=None):
     """N > 1: one RowShardedSpmv over this rank's shard -- local SpMV on the engine's own stream, ONE exchange of the y slices
     per step (RCCL allgather or the point-to-point fan-out, whichever the timing on this communicator prefers).  Returns the
     max-over-ranks wall time of `steps` steps (barrier + synchronize on both sides) and the SpMV-only launch time."""
@@ -280,7 +280,8 @@ def sharded_leg(torch, dist, args, W, x, y0, alpha, beta, rank, world, device, b
     m, n, nnz = W["m"], W["n"], W["nnz"]
     strat = W["strategy"]
     extra = {}
-    bounds = np.arange(world + 1, dtype=np.int64) * m  # every rank owns m rows of the (world*m) x n matrix
+    if bounds is None:
+        bounds = np.arange(world + 1, dtype=np.int64) * m  # every rank owns m rows of the (world*m) x n matrix
     eng = RowShardedSpmv(rank, world, bounds, W["rp"], W["ci"], W["v"], n, device, strategy=strat,
                          always_collective=force_dist,
                          exchange="allgather" if args.exchange == "auto" else args.exchange)
@@ -581,6 +582,33 @@ def main():
             out_extra["banded"] = bextra
             spmv_acc_amd.release_plans(brp)
             del brp, bci, bv, bx, by0, BW
+            torch.cuda.empty_cache()
+            # STRONG scaling beside the weak-scaling value ("strong scaling on a problem that fits one GPU and weak
+            # scaling"): the ONE Hardesty3-sized matrix (same seed on every rank) cut into `world` nnz-balanced row ranges, equal
+            # padded shards, x replicated, allgather(y) per step.  gflops_total counts the matrix once.
+            from spmv_acc_amd.dist import local_csr_slice, shard_bounds
+
+            gm, gn, gnnz, grp, gci, gv = synth.hardesty3_like_torch(device=device, seed=0xC2, scale=args.scale)
+            h_rp = grp.cpu().numpy()
+            sb = shard_bounds(gm, world, mode=1, h_rowptr=h_rp)
+            r0, r1 = int(sb[rank]), int(sb[rank + 1])
+            lrp, lci, lv = local_csr_slice(grp, gci, gv, r0, r1)
+            lrp = lrp.contiguous()
+            SW = dict(m=r1 - r0, n=gn, nnz=int(h_rp[r1] - h_rp[r0]), rp=lrp, ci=lci, v=lv, strategy=strat)
+            gen_s = torch.Generator(device=device)
+            gen_s.manual_seed(99)
+            sy0 = torch.rand(r1 - r0, generator=gen_s, device=device, dtype=torch.float64)
+            ssteps = min(args.steps, 100)
+            swall, sev, sextra = sharded_leg(torch, dist, args, SW, x, sy0, alpha, beta, rank, world, device, backend, force_dist, ssteps,
+                                             min(args.warmup, 5), bounds=sb)
+            sextra.pop("spmv_plus_exchange_gflops_total", None)  # (that key assumes equal non-zeros per rank: weak scaling)
+            sextra.update({"workload": "the ONE Hardesty3-sized matrix in `world` nnz-balanced row ranges (strong scaling)",
+                           "rows_this_rank": r1 - r0, "nnz_this_rank": SW["nnz"], "steps": ssteps,
+                           "gflops_total": round(2.0 * gnnz * ssteps / swall / 1e9, 3),
+                           "ms_per_step": round(swall / ssteps * 1e3, 6)})
+            out_extra["strong_scaling"] = sextra
+            spmv_acc_amd.release_plans(lrp)
+            del grp, gci, gv, lrp, lci, lv, SW
             torch.cuda.empty_cache()
 
     ms_per_step = wall / args.steps * 1e3
