@@ -1635,8 +1635,8 @@ template <class Launch> bool autotune_hint(Plan &p, int fam, hipStream_t st, Lau
     p.A.cold = nullptr;
     if (!ok) return false;
     p.hint_use[fam] = ms[1] < 0.98f * ms[0] ? 1 : 0;
-    tune_log("m %d nnz %d family %d gather hints: plain %.2f us, hinted %.2f us -> %s", p.A.m, p.A.nnz, fam, ms[0] * 1e3f, ms[1] * 1e3f,
-             p.hint_use[fam] ? "hinted" : "plain");
+    tune_log("m %d nnz %d family %d beta class %d gather hints: plain %.2f us, hinted %.2f us -> %s (kept for both classes)", p.A.m, p.A.nnz, fam,
+             t_beta_class, ms[0] * 1e3f, ms[1] * 1e3f, p.hint_use[fam] ? "hinted" : "plain");
   }
   p.A.cold = p.hint_use[fam] == 1 ? p.d_cold : nullptr;
   return true;
@@ -1901,7 +1901,7 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
     if (!ok) break;
     float ms = 0.f;
     ok = timer.time(st, [&] { launch(policy_for(p, kFamPlus), scratch); }, &ms);
-    if (ok) tune_log("m %d nnz %d row-block-plus: MIN_NNZ_PER_BLOCK %d -> %.2f us", p.A.m, p.A.nnz, candidates[c], ms * 1e3f);
+    if (ok) tune_log("m %d nnz %d beta class %d row-block-plus: MIN_NNZ_PER_BLOCK %d -> %.2f us (kept for both classes)", p.A.m, p.A.nnz, t_beta_class, candidates[c], ms * 1e3f);
     if (ok && ms < best) {
       best = ms;
       best_min = candidates[c];
