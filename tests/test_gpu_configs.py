@@ -213,6 +213,48 @@ def test_configs3_rmat25_line_enhance_full_size(torch_dev, oracle):
         torch.cuda.empty_cache()
 
 
+def test_configs3_rmat25_out_of_place_and_column_slabs_full_size(torch_dev, oracle, hiplib):
+    """Round 3 at configs[3]'s full size: the out-of-place entry is bitwise the in-place one (line_enhance, i.e. the row-block-plus
+    kernel with long rows sliced over blocks and folded by its second kernel); the opt-in column slabs (col_slabs = 8: eight
+    consecutive SpMVs over the plan's re-ordered copy, the first applying beta) agree with the independent device evaluation on
+    every row and with the CPU oracle on a row prefix; values edited in place are picked up by spmv_acc_refresh_values."""
+    torch = torch_dev
+    A = synth.rmat_torch(25, device="cuda", seed=0xC4)
+    m, n, nnz, rp, ci, v = A
+    x, y0 = _vectors(torch, m, n, 0xC4C5)
+    try:
+        inplace = _spmv(torch, A, "line_enhance", 0.5, -2.0, x, y0)
+        y_in, y_out = y0.clone(), torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+        spmv_acc_amd.csr_spmv(0.5, -2.0, m, n, nnz, rp, ci, v, x, y_out, strategy="line_enhance", y_in=y_in)
+        torch.cuda.synchronize()
+        assert torch.equal(y_out, inplace) and torch.equal(y_in, y0)
+        del y_in, y_out, inplace
+        ax, mag = _host_checked_reference(torch, A, x, "line_enhance")
+        spmv_acc_amd.release_plans(rp)
+        hiplib.spmv_acc_set_tunable(b"col_slabs", 8)
+        _say("R-MAT 25 with 8 column slabs")
+        y = _spmv(torch, A, "line_enhance", 1.0, 1.0, x, y0)
+        ref = ax + y0
+        scale = (mag + y0.abs()).clamp_min(1e-300)
+        assert ((y - ref).abs() / scale).max().item() <= SCALED_TOL, "column slabs vs device reference"
+        assert _verify_y_failures(torch, y, ref) == 0
+        y = _spmv(torch, A, "line_enhance", 0.5, 0.0, x, torch.full((m,), float("nan"), dtype=torch.float64, device="cuda"))
+        assert ((y - 0.5 * ax).abs() / (0.5 * mag).clamp_min(1e-300)).max().item() <= SCALED_TOL, "column slabs, beta = 0"
+        _prefix_vs_oracle(torch, oracle, A, ("line_enhance",), x, y0)
+        # values edited in place (scaled by -2): one refresh pass, same plans
+        plans = hiplib.spmv_acc_cached_plans()
+        v.mul_(-2.0)
+        assert spmv_acc_amd.refresh_values(rp) == 1
+        y = _spmv(torch, A, "line_enhance", 1.0, 1.0, x, y0)
+        assert ((y - (y0 - 2.0 * ax)).abs() / (2.0 * mag + y0.abs()).clamp_min(1e-300)).max().item() <= SCALED_TOL, "after refresh_values"
+        assert hiplib.spmv_acc_cached_plans() == plans
+    finally:
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans(rp)
+        del A
+        torch.cuda.empty_cache()
+
+
 def test_configs4_banded_shard_full_size(torch_dev, oracle):
     """BASELINE configs[4]: rank 3's shard (32 M rows, 256 M non-zeros, global column ids into a 256 M-entry x) of the
     256 M-row banded matrix.  Closed form for x = 1, the generic full-size checks, and the first rows against the oracle."""
