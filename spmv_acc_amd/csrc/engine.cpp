@@ -544,7 +544,12 @@ struct Plan {
   int slab_count = 0;
   int slab_width = 0;
   long long *d_slab_off = nullptr; // the slabs' start positions, on the device (kept for spmv_acc_refresh_values)
-  int *d_slab_rp = nullptr;
+  // per slab, COMPACT: the rows that have non-zeros in the slab (ascending ids), their row pointers (ms + 1), how many there are;
+  // one scratch vector for a slab's compact result
+  std::vector<int *> slab_rowid, slab_crp;
+  std::vector<int> slab_rows;
+  double *d_slab_ys = nullptr;
+  int *d_slab_rp = nullptr;        // the slabs' DENSE row pointers (S * (m + 1)): where the scatter (and a values refresh) puts a non-zero
   int *d_slab_ci = nullptr;
   double *d_slab_v = nullptr;
   std::vector<long long> slab_off;
@@ -766,10 +771,20 @@ void tune_store(const Plan &p) {
 std::mutex g_deferred_mu;
 std::vector<const void *> g_deferred_rp;
 void Plan::free_slabs() {
-  if (d_slab_rp) {
+  if (!slab_crp.empty()) {
     std::lock_guard<std::mutex> lk(g_deferred_mu);
-    for (int s = 0; s < slab_count; ++s) g_deferred_rp.push_back(d_slab_rp + static_cast<size_t>(s) * (static_cast<size_t>(A.m) + 1));
+    for (int *crp : slab_crp)
+      if (crp) g_deferred_rp.push_back(crp); // (the slabs' plans are keyed by their compact row pointers)
   }
+  for (int *q : slab_rowid)
+    if (q) (void)hipFree(q);
+  for (int *q : slab_crp)
+    if (q) (void)hipFree(q);
+  slab_rowid.clear();
+  slab_crp.clear();
+  slab_rows.clear();
+  if (d_slab_ys) (void)hipFree(d_slab_ys);
+  d_slab_ys = nullptr;
   if (d_slab_rp) (void)hipFree(d_slab_rp);
   if (d_slab_ci) (void)hipFree(d_slab_ci);
   if (d_slab_v) (void)hipFree(d_slab_v);
@@ -2039,6 +2054,28 @@ bool ensure_slabs(Plan &p, int S, hipStream_t st) {
       launch_slab_scatter(st, A, width, S, p.d_slab_rp, d_off, p.d_slab_ci, p.d_slab_v);
       ok = hip_ok(hipStreamSynchronize(st), "sync slab scatter");
     }
+    // compact every slab to its non-empty rows (cnt is free now: its first two (m + 1)-blocks serve as flags and positions)
+    p.slab_rowid.assign(S, nullptr);
+    p.slab_crp.assign(S, nullptr);
+    p.slab_rows.assign(S, 0);
+    int *flags = cnt, *pos = S >= 2 ? cnt + m1 : nullptr;
+    int max_rows = 0;
+    for (int s = 0; ok && s < S && pos; ++s) {
+      const int *rps = p.d_slab_rp + m1 * s;
+      launch_slab_flags(st, rps, A.m, flags);
+      int ms = 0;
+      ok = launch_col16_scan(st, A.m, flags, pos, tmp, tmp_bytes) &&
+           hip_ok(hipMemcpyAsync(&ms, pos + A.m, sizeof(int), hipMemcpyDeviceToHost, st), "read slab rows") &&
+           hip_ok(hipStreamSynchronize(st), "sync slab rows") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&p.slab_rowid[s]), sizeof(int) * (static_cast<size_t>(ms) + 1)), "hipMalloc slab row ids") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&p.slab_crp[s]), sizeof(int) * (static_cast<size_t>(ms) + 1)), "hipMalloc slab compact rowptr");
+      if (!ok) break;
+      launch_slab_compact(st, rps, pos, A.m, p.slab_rowid[s], p.slab_crp[s]);
+      ok = hip_ok(hipStreamSynchronize(st), "sync slab compaction"); // (flags / pos are reused by the next slab)
+      p.slab_rows[s] = ms;
+      max_rows = ms > max_rows ? ms : max_rows;
+    }
+    ok = ok && hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_slab_ys), sizeof(double) * (static_cast<size_t>(max_rows) + 1)), "hipMalloc slab result");
   }
   if (cnt) (void)hipFree(cnt);
   if (tmp) (void)hipFree(tmp);
@@ -2160,14 +2197,18 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     // reading y_in), the others accumulating into y.  Each slab is an ordinary matrix with a plan of its own.
     const int S = tun(kT_col_slabs) > 16 ? 16 : tun(kT_col_slabs);
     if (!ensure_slabs(*p, S, st)) return;
-    const size_t m1 = static_cast<size_t>(m) + 1;
     launch_guard_check(st, p->A); // (the slabs' kernels check the slabs: the caller's rowptr is checked here)
+    // y = beta * y_in first (nothing to do for beta == 1 in place), then every slab: y_s = alpha * A_s x over the slab's non-empty
+    // rows (an ordinary SpMV of a smaller matrix, beta = 0) and y[rowid] += y_s
+    if (beta != 1.0 || p->A.yin) launch_scale_y(st, m, beta, dy, p->A.yin);
     t_in_slab = true;
     for (int s = 0; s < S && last_error_code_only() == kOk; ++s) {
       const long long o = p->slab_off[s];
-      if (s > 0 && p->slab_off[s + 1] == o) continue; // an empty slab adds nothing
-      run_spmv(strategy, 0, alpha, s == 0 ? beta : 1.0, m, n, static_cast<int>(p->slab_off[s + 1] - o), nullptr, p->d_slab_rp + m1 * s,
-               p->d_slab_ci + o, p->d_slab_v + o, dx, dy, s == 0 ? dy_in : nullptr);
+      const int ms = p->slab_rows[s];
+      if (ms == 0) continue; // an empty slab adds nothing
+      run_spmv(strategy, 0, alpha, 0.0, ms, n, static_cast<int>(p->slab_off[s + 1] - o), nullptr, p->slab_crp[s], p->d_slab_ci + o,
+               p->d_slab_v + o, dx, p->d_slab_ys, nullptr);
+      if (last_error_code_only() == kOk) launch_slab_merge(st, ms, p->slab_rowid[s], p->d_slab_ys, dy);
     }
     t_in_slab = false;
     t_last_plan = p;

@@ -5,8 +5,10 @@
 // 256 MB, random 8 B reads per 64/128 B line ... consider column-window blocking"): on power-law columns ~60 % of the gathers fall
 // on a few MB of x, but every one of the eight 4 MB L2s has to hold that hot set AND absorb the lines the cold gathers bring in.
 // With S slabs a phase gathers from 1/S of x only: the L2s hold a hot set S times deeper (tools/micro/xcd_slab_gather_bench.hip:
-// 67 -> 109 G gathers/s with an eighth of x per L2; tools/col_slab_probe.py: R-MAT scale 25 7.15 -> 5.46 ms with S = 8) at the price
-// of S passes over y and S row-pointer arrays.  The plan then holds a re-ordered COPY of colindex and values, which is why this is
+// 67 -> 109 G gathers/s with an eighth of x per L2; tools/col_slab_probe.py: R-MAT scale 25 7.15 -> 5.46 ms with S = 8 DENSE slabs,
+// i.e. S passes over y and S full row-pointer arrays).  The slabs are kept COMPACT -- only the rows that have non-zeros in a slab,
+// with a row-id list (tools/col_slab_compact_probe.py: 45 M non-empty (row, slab) pairs of 268 M on R-MAT 25) -- so a phase is an
+// ordinary SpMV of a smaller matrix into a compact y_s plus a merge y[rowid] += y_s.  The plan then holds a re-ordered COPY of colindex and values, which is why this is
 // opt-in like the 16-bit column stream: after editing VALUES in place call spmv_acc_refresh_values (one scatter pass, the slabs'
 // structure and plans stay), after editing the structure spmv_acc_release_plans.
 //
@@ -74,7 +76,52 @@ __global__ __launch_bounds__(kThreads) void slab_scatter_kernel(const int *__res
   }
 }
 
+// A slab keeps only the rows that HAVE non-zeros in it (power-law matrices: R-MAT 25 in 8 slabs has 45 M non-empty (row, slab)
+// pairs out of 268 M): flags -> exclusive scan (engine.cpp) -> row-id list + the row pointers of those rows.
+// rps: the slab's DENSE row pointers (m + 1); flags / pos: m + 1 ints.
+__global__ __launch_bounds__(kThreads) void slab_flags_kernel(const int *__restrict__ rps, int m, int *__restrict__ flags) {
+  const long long r = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
+  if (r < m) flags[r] = rps[r + 1] > rps[r] ? 1 : 0;
+  else if (r == m) flags[r] = 0;
+}
+__global__ __launch_bounds__(kThreads) void slab_compact_kernel(const int *__restrict__ rps, const int *__restrict__ pos, int m,
+                                                                int *__restrict__ rowid, int *__restrict__ crp) {
+  const long long r = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
+  if (r < m) {
+    if (rps[r + 1] > rps[r]) {
+      const int i = pos[r];
+      rowid[i] = static_cast<int>(r);
+      crp[i] = rps[r];
+    }
+  } else if (r == m) {
+    crp[pos[m]] = rps[m]; // the slab's non-zero count closes the compact row pointers
+  }
+}
+// y[rowid[i]] += ys[i]: a slab's compact result into the full vector (rows ascending: the stores are as coalesced as the rows are dense)
+__global__ __launch_bounds__(kThreads) void slab_merge_kernel(int ms, const int *__restrict__ rowid, const double *__restrict__ ys,
+                                                              double *__restrict__ y) {
+  const long long i = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i < ms) {
+    const int r = rowid[i];
+    y[r] += ys[i];
+  }
+}
+
 } // namespace
+
+void launch_slab_flags(hipStream_t stream, const int *rps, int m, int *flags) {
+  const long long blocks = (static_cast<long long>(m) + 1 + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(slab_flags_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, rps, m, flags);
+}
+void launch_slab_compact(hipStream_t stream, const int *rps, const int *pos, int m, int *rowid, int *crp) {
+  const long long blocks = (static_cast<long long>(m) + 1 + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(slab_compact_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, rps, pos, m, rowid, crp);
+}
+void launch_slab_merge(hipStream_t stream, int ms, const int *rowid, const double *ys, double *y) {
+  if (ms <= 0) return;
+  const long long blocks = (static_cast<long long>(ms) + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(slab_merge_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, ms, rowid, ys, y);
+}
 
 void launch_slab_count(hipStream_t stream, const CsrDev &A, int width, int S, int *cnt) {
   if (A.m <= 0) return;

@@ -185,6 +185,11 @@ void plus_analyze_device_emit(hipStream_t stream, const int *rp, int m, int min_
 void launch_slab_count(hipStream_t stream, const CsrDev &A, int width, int S, int *cnt);
 void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, const int *rps, const long long *off, int *ci_out,
                          double *v_out, bool values_only = false);
+// compaction of one slab to its non-empty rows (flags -> caller's exclusive scan -> row ids + their row pointers) and the merge of a
+// slab's compact result into y
+void launch_slab_flags(hipStream_t stream, const int *rps, int m, int *flags);
+void launch_slab_compact(hipStream_t stream, const int *rps, const int *pos, int m, int *rowid, int *crp);
+void launch_slab_merge(hipStream_t stream, int ms, const int *rowid, const double *ys, double *y);
 
 // dst = src over `bytes` (16-B granules) with the kernels' streaming load shape: the copy ceiling probe
 void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes, bool non_temporal);
