@@ -159,8 +159,8 @@ Tunable g_tunables[] = {
                                // event pair per launch, median), 0 = one event pair around back-to-back launches (rounds 1-2)
     {"col_slabs", 0, 0},       // OPT-IN column-slab blocking (k_slab.hip): S >= 2 = the plan holds a re-ordered COPY of colindex and values,
                                // A = sum of S column-range slabs, and an SpMV is S consecutive SpMVs of the named strategy, each gathering
-                               // from 1/S of x (power-law columns: the L2s then hold a hot set S times deeper; R-MAT scale 25 7.15 -> 5.5 ms
-                               // with S = 8).  Costs S passes over y; loses on matrices whose gathers already hit.  After editing values
+                               // from 1/S of x (power-law columns: the L2s then hold a hot set S times deeper; R-MAT scale 25 7.2 -> 4.4 ms
+                               // with S = 8; a slab keeps only the rows that have non-zeros in it).  Costs S passes over y; loses on matrices whose gathers already hit.  After editing values
                                // in place call spmv_acc_refresh_values, after editing colindex spmv_acc_release_plans.  0 = off (the
                                // default: plans hold no copy of the matrix)
     {"flat_rowblock", -1, -1}, // flat on SMALL grids (below 24 Mi non-zeros) whose fixed row blocks are balanced: -1 = time the flat tile kernel
