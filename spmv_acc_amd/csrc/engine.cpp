@@ -103,7 +103,10 @@ Tunable g_tunables[] = {
     {"xcd_chunk_tiles", 16, 16}, // same order for the flat / row-block-plus grids (A/B after the cache-policy autotune,
                                // 9 stand-ins: 0 .. -4 % time on every one, none slower)
     {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
-    {"rowblock_target", 1900, 1900}, // products a row block should bring to its 2048-product tile
+    {"rowblock_target", 1500, 1500}, // products a row block should bring to its 2048-product tile.  Round 1 measured 1900 best (fullest tile); with
+                               // round 2-3's kernels (zigzag, per-matrix cache policy) and the per-launch protocol 1500 is 1-2 % faster on ten of
+                               // eleven sweep stand-ins and 2.8 % on the banded shard, +0.8 % on TSOPF (tools/param_sweep_reset.py, fresh plans on
+                               // the same arrays, profiles/r03_rowblock_target.txt); 1600 / 1400 / 1300 / 1700 / 2040 are not better
     {"stream_plain", -1, -1},  // stream-load cache policy: -1 = timed once per matrix; 0 nt, 1 default, 2 index default, 3 value default
     {"copy_nt", 1, 1},         // copy-ceiling probe: non-temporal loads/stores (0 = default cache policy)
     {"stage_fast", 1, 1},      // tile staging: wave-skip + branch-free form (0: per-lane predicated loads)

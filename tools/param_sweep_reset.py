@@ -12,7 +12,14 @@ from spmv_acc_amd import synth
 lib = spmv_acc_amd.load_library()
 strat, names, variants = sys.argv[1], sys.argv[2].split(","), sys.argv[3].split(";")
 for name in names:
-    m, n, nnz, rp, ci, v = synth.sweep_standin_torch(name)
+    if name == "banded":  # BASELINE configs[4]: rank 3's 32 M-row shard
+        rows, total = 32_000_000, 256_000_000
+        rp, ci, v = synth.banded_torch(rows, first_row=3 * rows, total_rows=total, device="cuda")
+        m, n, nnz = rows, total, int(rp[-1].item())
+    elif name.startswith("rmat"):
+        m, n, nnz, rp, ci, v = synth.rmat_torch(int(name[4:]), device="cuda", seed=0xC4)
+    else:
+        m, n, nnz, rp, ci, v = synth.sweep_standin_torch(name)
     x = torch.rand(n, device="cuda", dtype=torch.float64)
     y0 = torch.rand(m, device="cuda", dtype=torch.float64)
     y = y0.clone()
