@@ -649,13 +649,22 @@ void tune_load_locked() {
   if (g_tune_loaded || g_tune_path.empty()) return;
   g_tune_loaded = true;
   if (FILE *f = std::fopen(g_tune_path.c_str(), "r")) {
-    char tag[32];
-    unsigned long long key;
-    while (std::fscanf(f, "%31s %llx", tag, &key) == 2) {
+    // line by line: a line cut short (a writer killed mid-write) or written by another version is skipped by itself
+    char line[1024];
+    while (std::fgets(line, sizeof(line), f)) {
+      char tag[32];
+      unsigned long long key = 0;
+      int used = 0;
+      if (std::sscanf(line, "%31s %llx%n", tag, &key, &used) != 2 || std::strcmp(tag, "spmvacc2") != 0) continue;
       TuneRecord r;
-      bool ok = std::strcmp(tag, "spmvacc2") == 0;
-      for (int i = 0; i < kTuneFields; ++i) ok = (std::fscanf(f, "%d", &r.v[i]) == 1) && ok;
-      if (ok) g_tune_db[key] = r;
+      bool ok = true;
+      const char *at = line + used;
+      for (int i = 0; i < kTuneFields && ok; ++i) {
+        int step = 0;
+        ok = std::sscanf(at, "%d%n", &r.v[i], &step) == 1;
+        at += step;
+      }
+      if (ok && std::strchr(at, '\n')) g_tune_db[key] = r;
     }
     std::fclose(f);
   }

@@ -209,6 +209,12 @@ int spmv_acc_shard_pipeline(spmv_acc_shard_t S) { return S ? static_cast<int>(S-
 int spmv_acc_shard_step(spmv_acc_shard_t S, double alpha, double beta, const double *dx, const double *dy_in_local, double *dy_full) {
   if (!S || !dy_full) return fail(kErrBadArgument, "spmv_acc_shard_step: bad argument");
   const Rccl &R = rccl();
+  // a shard belongs to the device that was current when it was made (its chunk arrays, events and second stream live there); a host
+  // thread that drives several shards has to hipSetDevice before each step, and forgetting it would launch on the wrong card
+  int current = -1;
+  if (hipGetDevice(&current) != hipSuccess || current != S->device)
+    return fail(kErrBadArgument, "spmv_acc_shard_step: the shard was created on device " + std::to_string(S->device) +
+                                     ", the calling thread's current device is " + std::to_string(current));
   hipStream_t st = get_stream();
   double *own = dy_full + static_cast<size_t>(S->rank) * S->m_pad;
   clear_error();
