@@ -90,7 +90,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kTunableCount
 };
 #ifdef FLAT_SEGMENT_SUM_REDUCE
 constexpr int kFlatReduceBuilt = 1;
@@ -174,6 +174,9 @@ Tunable g_tunables[] = {
     {"legacy_kernels", 1, 1},  // KERNEL_STRATEGY LIGHT / BLOCK_ROW_ORDINARY: 1 = their own kernels (k_legacy.hip: rows handed out by an atomic
                                // counter; one workgroup per row -- what the names mean in the reference), 0 = the round-1/2 stand-ins (the
                                // vector-row tile kernel; one wavefront per row), which are faster on most matrices
+    {"guard_full", 0, 0},      // OPT-IN: 1 = every SpMV re-reads ALL of rowptr and compares a 64-bit digest with the plan's (k_guard.hip) -- an
+                               // in-place edit of the structure is then always noticed, not only where it touches one of the 64 samples of the
+                               // guard the kernels carry.  4 * (m + 1) bytes and two small launches more per call
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -544,6 +547,14 @@ struct Plan {
   // opt-in column-slab blocking (tunable col_slabs): the slabs' row pointers (S * (m + 1) ints), the re-ordered colindex / values,
   // where each slab starts in them, and each slab's non-zero count
   unsigned *d_light_counter = nullptr; // LIGHT's row counter (k_legacy.hip)
+  // opt-in full row-pointer check (tunable guard_full, k_guard.hip): digest of rowptr[0 .. m] at plan-build time and the
+  // arrays the per-call partial digests go to -- kDigestSlots of them, used in turn, so that calls on this plan that are in
+  // flight on DIFFERENT streams at the same time do not share one
+  static constexpr int kDigestSlots = 8;
+  bool have_rp_digest = false;
+  unsigned long long rp_digest = 0;
+  unsigned long long *d_digest_acc = nullptr;
+  unsigned digest_turn = 0;
   int slab_count = 0;
   int slab_width = 0;
   long long *d_slab_off = nullptr; // the slabs' start positions, on the device (kept for spmv_acc_refresh_values)
@@ -595,6 +606,8 @@ struct Plan {
     free_slabs();
     if (d_light_counter) (void)hipFree(d_light_counter);
     d_light_counter = nullptr;
+    if (d_digest_acc) (void)hipFree(d_digest_acc);
+    d_digest_acc = nullptr;
     if (d_cold) (void)hipFree(d_cold);
     d_cold = nullptr;
     hint_state = -1;
@@ -1766,6 +1779,32 @@ bool validate_plan(Plan &p, hipStream_t st) {
   return true;
 }
 
+// Opt-in (tunable guard_full): the digest of the whole rowptr, taken once per plan; then one digest + verdict pair per call, on the
+// call's stream AHEAD of its SpMV kernels (the flag is up by the time the caller has synchronised and asks spmv_acc_last_error).
+bool launch_full_guard(Plan &p, hipStream_t st) {
+  if (!p.A.guard || !p.A.stale) return true; // (the plan runs unguarded: no slot was free)
+  if (!p.have_rp_digest) {
+    if (!plan_work_allowed("the full row-pointer digest (guard_full)")) return false;
+    ++t_plan_work;
+    // kDigestSlots sets of partial sums + one word for the build-time digest
+    const size_t words = static_cast<size_t>(Plan::kDigestSlots) * kDigestMaxParts + 1;
+    if (!p.d_digest_acc && !hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_digest_acc), sizeof(unsigned long long) * words), "hipMalloc digest"))
+      return false;
+    unsigned long long *out = p.d_digest_acc + words - 1;
+    launch_rowptr_digest(st, p.A.rp, p.A.m, p.d_digest_acc);
+    launch_rowptr_verdict(st, p.d_digest_acc, p.A.m, 0, nullptr, out);
+    unsigned long long h = 0;
+    if (!hip_ok(hipMemcpyAsync(&h, out, sizeof(h), hipMemcpyDeviceToHost, st), "read digest") || !hip_ok(hipStreamSynchronize(st), "sync digest"))
+      return false;
+    p.rp_digest = h;
+    p.have_rp_digest = true;
+  }
+  unsigned long long *part = p.d_digest_acc + static_cast<size_t>(p.digest_turn++ % Plan::kDigestSlots) * kDigestMaxParts;
+  launch_rowptr_digest(st, p.A.rp, p.A.m, part);
+  launch_rowptr_verdict(st, part, p.A.m, p.rp_digest, p.A.stale, nullptr);
+  return true;
+}
+
 // Once per matrix: would any fixed row block have to stream more than kRowblockMaxRounds tiles?
 // (power-law matrices: R-MAT hub rows put millions of non-zeros into one workgroup.)
 bool probe_rowblock(Plan &p, int rpb, hipStream_t st) {
@@ -2203,6 +2242,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     return;
   }
   if (tun(kT_validate) && !validate_plan(*p, st)) return;
+  if (tun(kT_guard_full) && !t_in_slab && !launch_full_guard(*p, st)) return; // (a slab is a derived matrix: its parent was checked)
 
   if (tun(kT_col_slabs) >= 2 && !t_in_slab) {
     // opt-in column-slab blocking: S consecutive SpMVs of this strategy on the plan's slabs, the first one applying beta (and

@@ -32,6 +32,13 @@ struct CsrDev {
 constexpr int kGuardSamples = 64; // rowptr[k * m / 63], k = 0 .. 63 (includes rowptr[0] and rowptr[m] = nnz)
 void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard);
 void launch_guard_check(hipStream_t stream, const CsrDev &A); // the check alone, for paths whose SpMV kernels run on derived matrices
+// opt-in full check (k_guard.hip, tunable guard_full): one partial digest of rowptr[0 .. m] per workgroup into part[0 .. parts);
+// then ONE workgroup adds them up and either writes the digest to digest_out (plan build) or compares it with `expected` and raises `stale`
+constexpr int kDigestMaxParts = 1024;
+int rowptr_digest_parts(int m);
+void launch_rowptr_digest(hipStream_t stream, const int *rp, int m, unsigned long long *part);
+void launch_rowptr_verdict(hipStream_t stream, const unsigned long long *part, int m, unsigned long long expected, int *stale,
+                           unsigned long long *digest_out);
 
 // Cache policy of the 16-B colindex / value stream loads of the tile kernels.  Which one is fastest depends on the
 // matrix (A/B on MI355X: default-policy loads win by 7-27 % on FEM-like matrices -- part of the matrix then stays

@@ -324,6 +324,107 @@ def test_stale_plan_is_reported_to_the_thread_that_used_it(torch_dev, hiplib):
         spmv_acc_amd.release_plans()
 
 
+@pytest.mark.parametrize("strat", ["flat", "line_enhance", "adaptive_plus"])
+def test_guard_full_notices_an_edit_between_the_samples(torch_dev, oracle, hiplib, strat):
+    """The guard every kernel carries compares 64 strided rowptr samples: moving one non-zero from a row to its neighbour at an
+    index that is NOT a sample goes unnoticed (documented window).  Tunable guard_full = 1 re-reads all of rowptr on every call:
+    the same edit raises the stale-plan error on the call that met it, the plan is rebuilt, and the next call is right."""
+    torch = torch_dev
+    m, n = 50000, 50000
+    rowptr, cols, vals = synth.random_csr(m, n, 9, seed=77, kind="uniform")
+    nnz = int(rowptr[-1])
+    samples = {int(k * m // 63) for k in range(64)}
+    i = next(r for r in range(m // 3, m) if r not in samples and rowptr[r] - rowptr[r - 1] >= 2)
+    edited = rowptr.copy()
+    edited[i] -= 1  # row i takes over the last non-zero of row i-1: same nnz, same 64 samples
+    assert all(edited[int(k * m // 63)] == rowptr[int(k * m // 63)] for k in range(64))
+    x = np.random.default_rng(2).standard_normal(n)
+    y0 = np.zeros(m)
+    drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+    sid = spmv_acc_amd.strategy_id(strat)
+
+    def call(y):
+        hiplib.spmv_acc_csr_spmv_strategy(sid, 0, 1.0, 0.0, m, n, nnz, None, drp.data_ptr(), dci.data_ptr(), dv.data_ptr(),
+                                          dx.data_ptr(), y.data_ptr())
+        torch.cuda.synchronize()
+        return hiplib.spmv_acc_last_error()
+
+    try:
+        for full in (0, 1):
+            drp.copy_(dev(torch, rowptr))
+            torch.cuda.synchronize()
+            spmv_acc_amd.release_plans()
+            hiplib.spmv_acc_clear_error()
+            hiplib.spmv_acc_set_tunable(b"guard_full", full)
+            y = torch.zeros(m, dtype=torch.float64, device="cuda")
+            assert call(y) == 0
+            ref = oracle.host_spmv(1.0, 0.0, rowptr, cols, vals, x, y0)
+            assert oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 0.0, rowptr, cols, vals, x, y0) <= SCALED_TOL
+            assert call(y) == 0  # an unchanged matrix passes the full check too
+            drp.copy_(dev(torch, edited))  # in place, not announced
+            torch.cuda.synchronize()
+            err = call(y)
+            if full == 0:
+                assert err == 0  # the window: nothing noticed (y may or may not be right, depending on what the plan holds)
+                continue
+            assert err == 2 and b"changed" in hiplib.spmv_acc_last_error_string()
+            hiplib.spmv_acc_clear_error()
+            assert call(y) == 0  # fresh plan for the edited structure
+            ref = oracle.host_spmv(1.0, 0.0, edited, cols, vals, x, y0)
+            assert oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 0.0, edited, cols, vals, x, y0) <= SCALED_TOL
+    finally:
+        hiplib.spmv_acc_set_tunable(b"guard_full", 0)
+        hiplib.spmv_acc_clear_error()
+        spmv_acc_amd.release_plans()
+
+
+def test_guard_full_replays_from_a_graph(torch_dev, oracle, hiplib):
+    """The per-call digest + verdict pair is two ordinary launches: a captured SpMV with guard_full = 1 replays (the accumulator is
+    left at zero by the verdict kernel), and an in-place edit between replays is noticed by the replay that meets it."""
+    torch = torch_dev
+    m, n = 30000, 30000
+    rowptr, cols, vals = synth.random_csr(m, n, 7, seed=78, kind="uniform")
+    nnz = int(rowptr[-1])
+    x = np.random.default_rng(3).standard_normal(n)
+    y0 = np.zeros(m)
+    drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
+    y = torch.zeros(m, dtype=torch.float64, device="cuda")
+    samples = {int(k * m // 63) for k in range(64)}
+    i = next(r for r in range(m // 2, m) if r not in samples and rowptr[r] - rowptr[r - 1] >= 2)
+    edited = rowptr.copy()
+    edited[i] -= 1
+    stream = torch.cuda.Stream()
+    try:
+        hiplib.spmv_acc_set_tunable(b"guard_full", 1)
+        hiplib.spmv_acc_clear_error()
+        with torch.cuda.stream(stream):
+            hiplib.spmv_acc_set_stream(stream.cuda_stream)
+            spmv_acc_amd.csr_spmv(1.0, 0.0, m, n, nnz, drp, dci, dv, dx, y, strategy="line_enhance")  # plan + digest outside the capture
+            stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                hiplib.spmv_acc_csr_spmv_strategy(spmv_acc_amd.strategy_id("line_enhance"), 0, 1.0, 0.0, m, n, nnz, None, drp.data_ptr(),
+                                                  dci.data_ptr(), dv.data_ptr(), dx.data_ptr(), y.data_ptr())
+            assert hiplib.spmv_acc_last_error() == 0, hiplib.spmv_acc_last_error_string()
+        ref = oracle.host_spmv(1.0, 0.0, rowptr, cols, vals, x, y0)
+        for _ in range(3):
+            y.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert hiplib.spmv_acc_last_error() == 0
+            assert oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 0.0, rowptr, cols, vals, x, y0) <= SCALED_TOL
+        drp.copy_(dev(torch, edited))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert hiplib.spmv_acc_last_error() == 2 and b"changed" in hiplib.spmv_acc_last_error_string()
+    finally:
+        hiplib.spmv_acc_set_stream(None)
+        hiplib.spmv_acc_set_tunable(b"guard_full", 0)
+        hiplib.spmv_acc_clear_error()
+        spmv_acc_amd.release_plans()
+
+
 def test_adaptive_family_is_kept_per_beta_class(torch_dev, hiplib):
     """adaptive times the kernel families in the caller's beta class and keeps one choice per class (the ranking flips where rows
     hold one or two non-zeros); spmv_acc_prepare (beta = 1) leaves the beta == 0 class untimed until a beta == 0 call arrives."""
