@@ -93,7 +93,10 @@ for case in range(cases):
                 # round 3: no timing at all, opt-in column slabs, the out-of-place entry ("oop" is this script's switch, not a tunable)
                 ("adaptive", {"deterministic": 1}), ("flat", {"deterministic": 1}), ("adaptive_plus", {"deterministic": 1}),
                 ("line_enhance", {"col_slabs": 4}), ("adaptive", {"col_slabs": 8}), ("flat", {"col_slabs": 3}),
-                ("adaptive", {"oop": 1}), ("flat", {"oop": 1, "flat_finish": 0}), ("adaptive_plus", {"oop": 1}), ("vector_row", {"oop": 1})]
+                ("adaptive", {"oop": 1}), ("flat", {"oop": 1, "flat_finish": 0}), ("adaptive_plus", {"oop": 1}), ("vector_row", {"oop": 1}),
+                # later in round 3: the full row-pointer check, LIGHT / BLOCK_ROW_ORDINARY with their own kernels, flat's small-grid switch pinned both ways
+                ("adaptive", {"guard_full": 1}), ("light", {}), ("block_row_ordinary", {}), ("light", {"oop": 1}),
+                ("flat", {"flat_rowblock": 1}), ("flat", {"flat_rowblock": 0}), ("line_enhance", {"rowblock_target": 1900})]
     for strat, knobs in variants:
         lib.spmv_acc_reset_tunables()
         oop = bool(knobs.get("oop"))
