@@ -244,8 +244,20 @@ def extra_legs(torch, device, headline):
     x, y0 = vectors(A[0], A[1])
     out["rmat25"] = {"workload": "R-MAT scale 25, edge factor 16 (BASELINE configs[3])", "rows": A[0], "nnz": A[2],
                      "line_enhance": timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)}
-    progress(f"rmat25: {out['rmat25']['line_enhance']}")
+    info = spmv_acc_amd.query_plan(A[3], A[0]) or {}
+    out["rmat25"]["path"] = ("column-slab passes over run lists, no copy of the matrix (k_segment.hip; timed against the row-block-plus "
+                             "kernel at plan time)" if info.get("slab_passes") else "row-block-plus kernel")
+    progress(f"rmat25: {out['rmat25']['line_enhance']} ({out['rmat25']['path']})")
     spmv_acc_amd.release_plans(A[3])
+    # the same strategy with the slab passes switched off: the one-kernel path of rounds 1-2 (gather hints), for comparison
+    lib = spmv_acc_amd.load_library()
+    lib.spmv_acc_set_tunable(b"slab_segments", 0)
+    try:
+        out["rmat25"]["line_enhance_without_slab_passes"] = timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)
+        progress(f"rmat25 without the slab passes: {out['rmat25']['line_enhance_without_slab_passes']}")
+    finally:
+        lib.spmv_acc_set_tunable(b"slab_segments", -1)
+        spmv_acc_amd.release_plans(A[3])
     # opt-in leg, never the headline of configs[3]: column-slab blocking (tunable col_slabs: the plan holds a re-ordered copy of the
     # matrix in 8 column ranges and runs 8 consecutive SpMVs, each gathering from an eighth of x).  Same algorithmic bytes.
     lib = spmv_acc_amd.load_library()

@@ -255,6 +255,11 @@ int spmv_acc_query_plan(const int *d_rowptr, int m, int *out);
 /* adaptive's timed kernel family for the beta == 0 class alone (out[8] above reports the beta != 0 class when it has been
  * timed): the families are timed per class because the ranking changes with the y read; -2 = no such plan */
 int spmv_acc_query_plan_beta0(const int *d_rowptr, int m);
+/* number of column slabs whose run lists the plan holds and its SpMVs pass over (tunable slab_segments, k_segment.hip: column-slab
+ * blocking without a copy of the matrix -- chosen by a plan-time timing on matrices whose column census finds a hot set, or forced);
+ * 0 = the plan runs the named strategy's own kernel; -2 = no such plan.  No reference counterpart: the reference has one path per
+ * strategy (strategy_picker.cpp:19-65). */
+int spmv_acc_query_plan_slab_passes(const int *d_rowptr, int m);
 
 void spmv_acc_set_stream(void *hip_stream); /* hipStream_t; NULL = the NULL stream (reference behaviour).  The stream belongs to the
                                              * CALLING HOST THREAD, like HIP's current device: N threads driving N GPUs each set

@@ -90,7 +90,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kT_slab_segments, kTunableCount
 };
 #ifdef FLAT_SEGMENT_SUM_REDUCE
 constexpr int kFlatReduceBuilt = 1;
@@ -177,6 +177,12 @@ Tunable g_tunables[] = {
     {"guard_full", 0, 0},      // OPT-IN: 1 = every SpMV re-reads ALL of rowptr and compares a 64-bit digest with the plan's (k_guard.hip) -- an
                                // in-place edit of the structure is then always noticed, not only where it touches one of the 64 samples of the
                                // guard the kernels carry.  4 * (m + 1) bytes and two small launches more per call
+    {"slab_segments", -1, -1}, // column-slab blocking WITHOUT a copy of the matrix (k_segment.hip): where every row's columns ascend, the plan keeps
+                               // per column slab the list of (row, first non-zero, length) runs -- structure only -- and an SpMV is S passes
+                               // over those runs, each gathering from 1/S of x.  -1 = on matrices whose column census finds a hot set (the
+                               // matrices that get gather hints: power-law columns, x far beyond the L2s) 8 slabs are built and timed once
+                               // against the row-block-plus kernel, the faster stays (R-MAT scale 25: 7.3 -> 5.3 ms); 0 = off; S >= 2 = always,
+                               // whatever the strategy (rows that are not ordered: the ordinary path)
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -602,8 +608,32 @@ struct Plan {
     digest = RowDigest();
   }
   void free_slabs();
+  // column-slab blocking without a copy (tunable slab_segments, k_segment.hip): -1 not looked at, 0 the rows are not slab-ordered
+  // (ordinary path), 1 built for seg_slabs slabs
+  int seg_state = -1, seg_slabs = 0;
+  int seg_choice = -1; // automatic mode: -1 not timed, 0 the row-block-plus kernel stays, 1 the slab passes
+  // per slab: one entry per run (or piece of a long run): its row, its first non-zero, its place in the pass's virtual non-zero
+  // order (entries + 1 prefix sums of the lengths); and the first entry of every workgroup (blocks + 1)
+  std::vector<int *> seg_row, seg_begin, seg_vptr, seg_blk;
+  std::vector<int> seg_entries, seg_blocks, seg_pieces; // seg_pieces[s] != 0: the slab holds runs cut into pieces (merge kernel needed)
+  double *d_seg_ys = nullptr; // one partial sum per entry of the longest list
+  void free_segments() {
+    for (auto *list : {&seg_row, &seg_begin, &seg_vptr, &seg_blk}) {
+      for (int *q : *list)
+        if (q) (void)hipFree(q);
+      list->clear();
+    }
+    seg_entries.clear();
+    seg_blocks.clear();
+    seg_pieces.clear();
+    if (d_seg_ys) (void)hipFree(d_seg_ys);
+    d_seg_ys = nullptr;
+    seg_state = -1;
+    seg_slabs = 0;
+  }
   void free_device() {
     free_slabs();
+    free_segments();
     if (d_light_counter) (void)hipFree(d_light_counter);
     d_light_counter = nullptr;
     if (d_digest_acc) (void)hipFree(d_digest_acc);
@@ -645,10 +675,10 @@ struct Plan {
 // the same matrix on the same device adopts them and only runs the structural passes.  Opt-in; the last line for a key wins;
 // a choice the current build cannot honour (a cut-row form that is not legal on this matrix) falls back to the safe one.
 struct TuneRecord {
-  int v[21]; // stream_policy[4][2], adaptive_family[2], flat_npt, flat_early, flat_geometry_tuned, flat_mode[2], plus_min, hint_state0, hint_use[3], flat_rowblock
+  int v[22]; // stream_policy[4][2], adaptive_family[2], flat_npt, flat_early, flat_geometry_tuned, flat_mode[2], plus_min, hint_state0, hint_use[3], flat_rowblock, seg_choice
   bool operator==(const TuneRecord &o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
 };
-constexpr int kTuneFields = 21;
+constexpr int kTuneFields = 22;
 std::mutex g_tune_mu;
 std::string g_tune_path;
 bool g_tune_path_set = false, g_tune_loaded = false;
@@ -668,7 +698,7 @@ void tune_load_locked() {
       char tag[32];
       unsigned long long key = 0;
       int used = 0;
-      if (std::sscanf(line, "%31s %llx%n", tag, &key, &used) != 2 || std::strcmp(tag, "spmvacc2") != 0) continue;
+      if (std::sscanf(line, "%31s %llx%n", tag, &key, &used) != 2 || std::strcmp(tag, "spmvacc3") != 0) continue;
       TuneRecord r;
       bool ok = true;
       const char *at = line + used;
@@ -693,7 +723,7 @@ unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *sample
     const unsigned char *c = static_cast<const unsigned char *>(p);
     for (size_t i = 0; i < bytes; ++i) h = (h ^ c[i]) * 1099511628211ULL;
   };
-  static const char kVersion[] = "spmv_acc_amd 0.3 tune v2";
+  static const char kVersion[] = "spmv_acc_amd 0.3 tune v3";
   mix(kVersion, sizeof(kVersion));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
@@ -726,6 +756,7 @@ TuneRecord tune_snapshot(const Plan &p) {
   r.v[k++] = p.hint_state == 0 ? 0 : -1; // only "the census found nothing to protect" is worth keeping: the bits themselves are rebuilt
   for (int f = 0; f < 3; ++f) r.v[k++] = p.hint_use[f];
   r.v[k++] = p.flat_rowblock_choice;
+  r.v[k++] = p.seg_choice;
   return r;
 }
 } // namespace
@@ -767,6 +798,8 @@ void tune_adopt(Plan &p) {
   if (r.v[k++] == 0) p.hint_state = 0;
   for (int f = 0; f < 3; ++f, ++k) p.hint_use[f] = in(r.v[k], 0, 1) ? r.v[k] : -1;
   p.flat_rowblock_choice = in(r.v[k], 0, 1) ? r.v[k] : -1;
+  ++k;
+  p.seg_choice = in(r.v[k], 0, 1) ? r.v[k] : -1;
   tune_log("m %d nnz %d: choices adopted from the tune cache (key %016llx)", p.A.m, p.A.nnz, p.tune_key);
 }
 // after a call that did plan work: keep what the plan now knows
@@ -779,7 +812,7 @@ void tune_store(const Plan &p) {
   if (it != g_tune_db.end() && it->second == r) return;
   g_tune_db[p.tune_key] = r;
   if (FILE *f = std::fopen(g_tune_path.c_str(), "a")) { // one line, one write: concurrent processes interleave whole lines
-    std::string line = "spmvacc2 ";
+    std::string line = "spmvacc3 ";
     char buf[32];
     std::snprintf(buf, sizeof(buf), "%016llx", p.tune_key);
     line += buf;
@@ -1979,16 +2012,70 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
   return ensure_plus(p, h_rowptr, st, best_min);
 }
 
+thread_local bool t_in_slab = false; // this thread is running one slab of a column-slab SpMV (no nesting)
+bool ensure_segments(Plan &p, int S, hipStream_t st);
+// the S passes over the plan's run lists (k_segment.hip); p.seg_state == 1
+void run_segments(hipStream_t st, Plan &p, double alpha, double beta, const double *x, double *y) {
+  launch_guard_check(st, p.A); // (the passes read run lists, not rowptr: the caller's rowptr is checked here)
+  if (beta != 1.0 || p.A.yin) launch_scale_y(st, p.A.m, beta, y, p.A.yin);
+  for (int s = 0; s < p.seg_slabs; ++s) {
+    if (p.seg_entries[s] == 0) continue;
+    launch_segment_tiles(st, p.seg_blocks[s], alpha, p.seg_blk[s], p.seg_row[s], p.seg_begin[s], p.seg_vptr[s], p.A.ci, p.A.v, x, p.d_seg_ys, y);
+    if (p.seg_pieces[s]) launch_segment_merge(st, p.seg_entries[s], p.seg_row[s], p.d_seg_ys, y);
+  }
+}
+// automatic mode: slabs of about 32 MB of x (R-MAT scale 25, x = 256 MB, S = 4 / 8 / 12 / 16: 5.92 / 5.31 / 5.59 / 6.08 ms, 7.27 without;
+// scale 24, x = 128 MB, S = 4 / 8: 2.37 / 2.59 ms, 3.21 without)
+int seg_auto_slabs(int n) {
+  const long long s = (static_cast<long long>(n) * 8 + (16LL << 20)) / (32LL << 20);
+  return s < 2 ? 2 : (s > 16 ? 16 : static_cast<int>(s));
+}
+
 bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y) {
   p.A.cold = nullptr; // (the prepare timings run without hints)
   if (!run_plus_prepare(p, h_rowptr, st, x)) return false;
-  if (!autotune_hint(p, kFamPlus, st, [&](double *ys) {
-        launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk_tiles), policy_for(p, kFamPlus),
-                    p.d_ppartial, 1.0, trial_beta(), x, ys, next_reverse(p));
-      }))
-    return false;
-  launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk_tiles),
-              policy_for(p, kFamPlus), p.d_ppartial, alpha, beta, x, y, next_reverse(p));
+  auto launch_here = [&](double a, double b, double *yy) {
+    launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk_tiles), policy_for(p, kFamPlus),
+                p.d_ppartial, a, b, x, yy, next_reverse(p));
+  };
+  if (!autotune_hint(p, kFamPlus, st, [&](double *ys) { launch_here(1.0, trial_beta(), ys); })) return false;
+  // Where the column census found a hot set (power-law columns, x far beyond the L2s) this kernel is bound by gathers that miss:
+  // the slab passes over run lists (k_segment.hip) are built once and timed against it, the faster stays.
+  if (tun(kT_slab_segments) < 0 && p.hint_state == 1 && !t_in_slab) {
+    if (p.seg_choice < 0 && !t_capturing && !tun(kT_deterministic) && !t_coarse_tuning) {
+      if (!ensure_segments(p, seg_auto_slabs(p.A.n), st)) return false;
+      p.seg_choice = 0;
+      if (p.seg_state == 1) {
+        ++t_plan_work;
+        double *scratch = nullptr;
+        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y")) return false;
+        TuneTimer timer;
+        timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
+        bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
+        float ms[2] = {0.f, 0.f};
+        const double *keep_yin = p.A.yin;
+        p.A.yin = nullptr; // (the trial runs update the scratch vector in place)
+        ok = ok && timer.time(st, [&] { launch_here(1.0, trial_beta(), scratch); }, &ms[0]) &&
+             timer.time(st, [&] { run_segments(st, p, 1.0, trial_beta(), x, scratch); }, &ms[1]);
+        p.A.yin = keep_yin;
+        (void)hipFree(scratch);
+        if (!ok) return false;
+        p.seg_choice = ms[1] < 0.95f * ms[0] ? 1 : 0;
+        tune_log("m %d nnz %d beta class %d: row-block-plus %.2f us, %d column-slab passes over run lists %.2f us -> %s", p.A.m, p.A.nnz,
+                 t_beta_class, ms[0] * 1e3f, seg_auto_slabs(p.A.n), ms[1] * 1e3f, p.seg_choice ? "slab passes" : "row-block-plus");
+      }
+      if (p.seg_choice == 0) p.free_segments(); // (the lists of a matrix that does not use them: 12 B per run back)
+    }
+    if (p.seg_choice == 1) {
+      // (a plan that adopted the choice from the tune cache builds its lists here; inside a capture only lists that exist are used)
+      if (p.seg_state != 1 && !t_capturing && !ensure_segments(p, seg_auto_slabs(p.A.n), st)) return false;
+      if (p.seg_state == 1) {
+        run_segments(st, p, alpha, beta, x, y);
+        return true;
+      }
+    }
+  }
+  launch_here(alpha, beta, y);
   return true;
 }
 
@@ -2061,7 +2148,6 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
 } // namespace
 
 namespace {
-thread_local bool t_in_slab = false; // this thread is running one slab of a column-slab SpMV (no nesting)
 
 // Opt-in column-slab blocking: build the S slabs of this matrix (k_slab.hip) once per plan and S.
 bool ensure_slabs(Plan &p, int S, hipStream_t st) {
@@ -2140,6 +2226,103 @@ bool ensure_slabs(Plan &p, int S, hipStream_t st) {
   p.slab_count = S;
   p.slab_off = off;
   p.slab_off.push_back(slab_total);
+  return true;
+}
+
+// Column-slab blocking without a copy (tunable slab_segments): the per-slab run lists of k_segment.hip.  Structure only; built once.
+bool ensure_segments(Plan &p, int S, hipStream_t st) {
+  if (p.seg_state >= 0 && (p.seg_state == 0 || p.seg_slabs == S)) return true;
+  if (!plan_work_allowed("building the column-slab run lists")) return false;
+  ++t_plan_work;
+  p.free_segments();
+  const CsrDev &A = p.A;
+  const size_t m1 = static_cast<size_t>(A.m) + 1;
+  const int width = (A.n + S - 1) / S > 0 ? (A.n + S - 1) / S : 1;
+  int *cnt = nullptr, *beg = nullptr, *pieces = nullptr, *pos = nullptr, *flag = nullptr;
+  void *tmp = nullptr;
+  const size_t tmp_bytes = col16_scan_bytes(A.m);
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&cnt), sizeof(int) * m1 * S), "hipMalloc run counts") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&beg), sizeof(int) * m1 * S), "hipMalloc run starts") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&pieces), sizeof(int) * m1), "hipMalloc run pieces") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&pos), sizeof(int) * m1), "hipMalloc run positions") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&flag), sizeof(int)), "hipMalloc order flag") &&
+            hip_ok(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16), "hipMalloc scan workspace") &&
+            hip_ok(hipMemsetAsync(flag, 0, sizeof(int), st), "memset order flag");
+  int unordered = 0;
+  if (ok) {
+    launch_segment_count(st, A, width, S, cnt, beg, flag);
+    ok = hip_ok(hipMemcpyAsync(&unordered, flag, sizeof(int), hipMemcpyDeviceToHost, st), "read order flag") &&
+         hip_ok(hipStreamSynchronize(st), "sync run counts");
+  }
+  if (ok && unordered) {
+    p.seg_state = 0; // some row's columns do not ascend across a slab boundary: its slab parts are not runs
+    tune_log("m %d nnz %d: slab_segments: rows are not ordered by column slab, ordinary path", A.m, A.nnz);
+  } else if (ok) {
+    for (auto *list : {&p.seg_row, &p.seg_begin, &p.seg_vptr, &p.seg_blk}) list->assign(S, nullptr);
+    p.seg_entries.assign(S, 0);
+    p.seg_blocks.assign(S, 0);
+    p.seg_pieces.assign(S, 0);
+    int max_entries = 0;
+    for (int s = 0; ok && s < S; ++s) {
+      const int *cnt_s = cnt + m1 * s;
+      int entries = 0;
+      launch_segment_pieces(st, cnt_s, A.m, kSegPiece, pieces);
+      ok = launch_col16_scan(st, A.m, pieces, pos, tmp, tmp_bytes) &&
+           hip_ok(hipMemcpyAsync(&entries, pos + A.m, sizeof(int), hipMemcpyDeviceToHost, st), "read run count") &&
+           hip_ok(hipStreamSynchronize(st), "sync run count");
+      if (!ok || entries == 0) continue;
+      // entries: row, first non-zero, length -> vptr; cost -> cptr -> the workgroups' first entries
+      const size_t e1 = static_cast<size_t>(entries) + 1;
+      int *len = nullptr, *cost = nullptr, *cptr = nullptr;
+      void *tmp_e = nullptr;
+      const size_t tmp_e_bytes = col16_scan_bytes(entries);
+      long long total_cost = 0;
+      int last[2] = {0, 0};
+      ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p.seg_row[s]), sizeof(int) * e1), "hipMalloc run rows") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&p.seg_begin[s]), sizeof(int) * e1), "hipMalloc run starts") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&p.seg_vptr[s]), sizeof(int) * e1), "hipMalloc run prefix") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&len), sizeof(int) * e1), "hipMalloc run lengths") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&cost), sizeof(int) * e1), "hipMalloc run costs") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&cptr), sizeof(int) * e1), "hipMalloc run cost prefix") &&
+           hip_ok(hipMalloc(&tmp_e, tmp_e_bytes > 0 ? tmp_e_bytes : 16), "hipMalloc scan workspace");
+      if (ok) {
+        ok = hip_ok(hipMemsetAsync(flag, 0, sizeof(int), st), "memset piece flag");
+        launch_segment_compact(st, cnt_s, beg + m1 * s, pos, A.m, kSegPiece, p.seg_row[s], p.seg_begin[s], len, flag);
+        launch_segment_cost(st, entries, len, cost);
+        ok = ok && launch_col16_scan(st, entries, len, p.seg_vptr[s], tmp_e, tmp_e_bytes) && launch_col16_scan(st, entries, cost, cptr, tmp_e, tmp_e_bytes) &&
+             hip_ok(hipMemcpyAsync(&p.seg_pieces[s], flag, sizeof(int), hipMemcpyDeviceToHost, st), "read piece flag") &&
+             hip_ok(hipMemcpyAsync(&last[0], cptr + entries, sizeof(int), hipMemcpyDeviceToHost, st), "read pass cost") &&
+             hip_ok(hipMemcpyAsync(&last[1], p.seg_vptr[s] + entries, sizeof(int), hipMemcpyDeviceToHost, st), "read pass size") &&
+             hip_ok(hipStreamSynchronize(st), "sync run scans");
+        total_cost = last[0];
+      }
+      if (ok) {
+        const int nblocks = segment_block_count(total_cost);
+        ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p.seg_blk[s]), sizeof(int) * (static_cast<size_t>(nblocks) + 1)), "hipMalloc pass workgroups");
+        if (ok) {
+          launch_segment_blocks(st, entries, nblocks, cptr, p.seg_blk[s]);
+          ok = hip_ok(hipStreamSynchronize(st), "sync pass workgroups"); // (pieces / pos / cptr are reused or freed next)
+          p.seg_blocks[s] = nblocks;
+        }
+      }
+      for (void *q : {static_cast<void *>(len), static_cast<void *>(cost), static_cast<void *>(cptr), tmp_e})
+        if (q) (void)hipFree(q);
+      p.seg_entries[s] = entries;
+      max_entries = entries > max_entries ? entries : max_entries;
+      tune_log("m %d nnz %d: slab_segments: slab %d of %d: %d non-zeros in %d runs, %d workgroups", A.m, A.nnz, s, S, last[1], entries, p.seg_blocks[s]);
+    }
+    ok = ok && hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_seg_ys), sizeof(double) * (static_cast<size_t>(max_entries) + 1)), "hipMalloc run sums");
+    if (ok) {
+      p.seg_state = 1;
+      p.seg_slabs = S;
+    }
+  }
+  for (void *q : {static_cast<void *>(cnt), static_cast<void *>(beg), static_cast<void *>(pieces), static_cast<void *>(pos), static_cast<void *>(flag), tmp})
+    if (q) (void)hipFree(q);
+  if (!ok) {
+    p.free_segments();
+    return false;
+  }
   return true;
 }
 } // namespace
@@ -2243,6 +2426,18 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   }
   if (tun(kT_validate) && !validate_plan(*p, st)) return;
   if (tun(kT_guard_full) && !t_in_slab && !launch_full_guard(*p, st)) return; // (a slab is a derived matrix: its parent was checked)
+
+  if (tun(kT_slab_segments) >= 2 && !t_in_slab) {
+    // column-slab blocking without a copy: S passes over the plan's run lists (k_segment.hip), whatever the strategy name
+    const int S = tun(kT_slab_segments) > 16 ? 16 : tun(kT_slab_segments);
+    if (!ensure_segments(*p, S, st)) return;
+    if (p->seg_state == 1) {
+      run_segments(st, *p, alpha, beta, dx, dy);
+      if (t_plan_work != prepare_clock.work0 && p->tune_key) tune_store(*p);
+      return;
+    }
+    // (rows not ordered by column slab: the ordinary path below)
+  }
 
   if (tun(kT_col_slabs) >= 2 && !t_in_slab) {
     // opt-in column-slab blocking: S consecutive SpMVs of this strategy on the plan's slabs, the first one applying beta (and
@@ -2431,6 +2626,7 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->flat_fixup = p.flat_tiles > 0 ? (p.flat.needs_fixup ? 1 : 0) : -1;
       out->adaptive_family = afam;
       out->adaptive_family_beta0 = p.adaptive_family[0];
+      out->slab_passes = p.seg_state == 1 && (tun(kT_slab_segments) >= 2 || (tun(kT_slab_segments) < 0 && p.seg_choice == 1)) ? p.seg_slabs : 0;
       return true;
     }
   }

@@ -126,6 +126,7 @@ struct PlanInfo {
   int adaptive_family = -1; // adaptive's timed choice: 0 fixed row blocks, 1 row-block-plus, 2 flat, -1 not timed (the beta != 0
                             // class if it has been timed, else the beta == 0 class)
   int adaptive_family_beta0 = -1; // ... of the beta == 0 class alone
+  int slab_passes = 0;            // column slabs whose run lists the plan holds and uses (k_segment.hip), 0 = none
 };
 bool query_plan(const int *d_rowptr, int m, PlanInfo *out);
 int cached_plan_count();

@@ -32,6 +32,18 @@ struct CsrDev {
 constexpr int kGuardSamples = 64; // rowptr[k * m / 63], k = 0 .. 63 (includes rowptr[0] and rowptr[m] = nnz)
 void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard);
 void launch_guard_check(hipStream_t stream, const CsrDev &A); // the check alone, for paths whose SpMV kernels run on derived matrices
+// column-slab blocking without a copy (k_segment.hip, tunable slab_segments): cnt S x (m + 1), beg S x (m + 1); *not_monotone pre-zeroed
+void launch_segment_count(hipStream_t stream, const CsrDev &A, int width, int S, int *cnt, int *beg, int *not_monotone);
+void launch_segment_pieces(hipStream_t stream, const int *cnt_s, int m, int piece_max, int *pieces);
+void launch_segment_compact(hipStream_t stream, const int *cnt_s, const int *beg_s, const int *pos, int m, int piece_max, int *seg_row,
+                            int *seg_begin, int *seg_len, int *has_pieces); // *has_pieces pre-zeroed: set when some run was cut
+constexpr int kSegPiece = 512; // longer runs are cut into pieces (entries of their own)
+void launch_segment_cost(hipStream_t stream, int entries, int *seg_len, int *cost); // both entries + 1 long; closes them with a zero
+int segment_block_count(long long total_cost);
+void launch_segment_blocks(hipStream_t stream, int entries, int nblocks, const int *cptr, int *blk_first); // blk_first: nblocks + 1
+void launch_segment_tiles(hipStream_t stream, int nblocks, double alpha, const int *blk_first, const int *seg_row, const int *seg_begin,
+                          const int *vptr, const int *ci, const double *v, const double *x, double *ys, double *y);
+void launch_segment_merge(hipStream_t stream, int entries, const int *seg_row, const double *ys, double *y);
 // opt-in full check (k_guard.hip, tunable guard_full): one partial digest of rowptr[0 .. m] per workgroup into part[0 .. parts);
 // then ONE workgroup adds them up and either writes the digest to digest_out (plan build) or compares it with `expected` and raises `stale`
 constexpr int kDigestMaxParts = 1024;

@@ -602,7 +602,7 @@ def test_tune_cache_is_adopted_by_the_next_process(torch_dev, tmp_path):
     first, log1 = _run_child(tmp_path, "p1", strategies, {"SPMV_ACC_TUNE_CACHE": cache})
     assert "stream policy" in log1 and "adopted" not in log1
     lines = open(cache).read().splitlines()
-    assert lines and all(ln.startswith("spmvacc2 ") and len(ln.split()) == 23 for ln in lines)
+    assert lines and all(ln.startswith("spmvacc3 ") and len(ln.split()) == 24 for ln in lines)
     # a damaged file costs at most the damaged lines: one cut short by a killed writer, one from another version, one of noise
     with open(cache, "w") as f:
         f.write(lines[0][: len(lines[0]) // 2] + "\n" + "spmvacc1 00ff 1 2 3\n" + "\x00\x01 not a record\n\n" + "\n".join(lines) + "\n")
@@ -714,6 +714,163 @@ def test_col_slabs_opt_in_matches_the_oracle(torch_dev, oracle, hiplib, kind, m,
         if not np.array_equal(lens, np.diff(rowptr)):
             assert hiplib.spmv_acc_last_error() == 2 and b"changed" in hiplib.spmv_acc_last_error_string()
     finally:
+        hiplib.spmv_acc_clear_error()
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans()
+
+
+# ---- column-slab blocking without a copy (tunable slab_segments, k_segment.hip) ------------------------------------------------
+def _sorted_rows(rowptr, cols, vals):
+    cols, vals = cols.copy(), vals.copy()
+    for i in range(len(rowptr) - 1):
+        a, b = rowptr[i], rowptr[i + 1]
+        order = np.argsort(cols[a:b], kind="stable")
+        cols[a:b] = cols[a:b][order]
+        vals[a:b] = vals[a:b][order]
+    return cols, vals
+
+
+@pytest.mark.parametrize("kind,m,n,avg", [("powerlaw", 30000, 30000, 12), ("uniform", 20000, 50000, 7), ("empty_rows", 15000, 15000, 5),
+                                          ("longrows", 2500, 60000, 30)])
+def test_slab_segments_match_the_oracle(torch_dev, oracle, hiplib, kind, m, n, avg):
+    """Tunable slab_segments = S: where every row's columns ascend the plan keeps per column slab the list of (row, first non-zero,
+    length) runs -- no copy of the matrix -- and an SpMV is S passes over those runs.  S = 2 / 8 / 16, general alpha / beta, in place
+    and out of place, runs far longer than a piece (cut into pieces whose sums the merge kernel adds in order), empty rows, empty
+    slabs, an un-rebased row shard; VALUES edited in place are seen by the next call without any refresh; COLUMNS edited in place (the
+    runs are then filed under the wrong slabs) still give the right sums; rows that are not ordered take the ordinary path."""
+    torch = torch_dev
+    if kind == "longrows":
+        rowptr, cols, vals = synth.random_csr(m, n, avg, seed=9, kind="uniform")
+        rng = np.random.default_rng(5)
+        lens = np.diff(rowptr).astype(np.int64)
+        lens[[3, m // 2, m - 1]] = (20001, 5000, 1300)
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        cols = rng.integers(0, n, int(rowptr[-1])).astype(np.int32)
+        vals = rng.standard_normal(int(rowptr[-1]))
+    else:
+        rowptr, cols, vals = synth.random_csr(m, n, avg, seed=33, kind=kind)
+        if kind == "uniform":
+            cols = (cols % (n // 3)).astype(np.int32)  # most slabs of 8 and 16 are empty
+    cols, vals = _sorted_rows(rowptr, cols, vals)
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(3)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    try:
+        for S in (2, 8, 16):
+            hiplib.spmv_acc_set_tunable(b"slab_segments", S)
+            for strat in ("adaptive", "flat"):  # (the passes replace whatever kernel the name would run)
+                for alpha, beta in ((1.0, 1.0), (0.5, -2.0), (2.0, 0.0)):
+                    ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+                    y = dy0.clone()
+                    spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y, strategy=strat)
+                    y_in = dy0.clone()
+                    y_out = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+                    spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y_out, strategy=strat, y_in=y_in)
+                    torch.cuda.synchronize()
+                    assert oracle.scaled_error(y.cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL, (S, strat, alpha, beta)
+                    assert torch.equal(y_out, y) and torch.equal(y_in, dy0), (S, strat, "out of place")
+            assert hiplib.spmv_acc_cached_plans() == 1  # no derived matrices, no derived plans
+            spmv_acc_amd.release_plans(drp)
+        hiplib.spmv_acc_set_tunable(b"slab_segments", 4)
+        # a row shard handed over without rebasing (rowptr[0] > 0; the nnz argument is then the end offset)
+        r0, r1 = m // 5, m - m // 7
+        sl = slice(r0, r1)
+        sub_rp = (rowptr[r0:r1 + 1] - rowptr[r0]).astype(np.int32)
+        sub = (sub_rp, cols[rowptr[r0]:rowptr[r1]], vals[rowptr[r0]:rowptr[r1]])
+        y = dy0.clone()
+        spmv_acc_amd.csr_spmv(1.0, 1.0, r1 - r0, n, int(rowptr[r1]), drp[r0:], dci, dv, dx, y[r0:], strategy="line_enhance")
+        torch.cuda.synchronize()
+        got = y.cpu().numpy()
+        assert np.array_equal(got[:r0], y0[:r0]) and np.array_equal(got[r1:], y0[r1:]), "wrote outside the shard"
+        ref = oracle.host_spmv(1.0, 1.0, *sub, x, y0[sl])
+        assert oracle.scaled_error(got[sl], ref, 1.0, 1.0, *sub, x, y0[sl]) <= SCALED_TOL, "unrebased shard"
+        spmv_acc_amd.release_plans(drp[r0:])
+        # values edited in place: nothing to refresh, the plan holds no values
+        y = dy0.clone()
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy="adaptive")
+        torch.cuda.synchronize()
+        vals2 = vals * -0.75 + 0.125
+        dv.copy_(dev(torch, vals2))
+        y = dy0.clone()
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy="adaptive")
+        torch.cuda.synchronize()
+        ref2 = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals2, x, y0)
+        assert oracle.scaled_error(y.cpu().numpy(), ref2, 1.0, 1.0, rowptr, cols, vals2, x, y0) <= SCALED_TOL
+        # columns edited in place, rows no longer ordered: the lists (built for the old columns) still cut every row into the same
+        # runs, so the sums are over the same non-zeros -- only the locality the slabs were for is gone
+        cols3 = ((cols.astype(np.int64) * 7919 + 13) % n).astype(np.int32)
+        dci.copy_(dev(torch, cols3))
+        y = dy0.clone()
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy="adaptive")
+        torch.cuda.synchronize()
+        ref3 = oracle.host_spmv(1.0, 1.0, rowptr, cols3, vals2, x, y0)
+        assert oracle.scaled_error(y.cpu().numpy(), ref3, 1.0, 1.0, rowptr, cols3, vals2, x, y0) <= SCALED_TOL
+        assert hiplib.spmv_acc_last_error() == 0 and hiplib.spmv_acc_cached_plans() == 1
+        # a FRESH plan on the unordered columns: no lists, the ordinary path
+        spmv_acc_amd.release_plans(drp)
+        y = dy0.clone()
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy="adaptive")
+        torch.cuda.synchronize()
+        assert oracle.scaled_error(y.cpu().numpy(), ref3, 1.0, 1.0, rowptr, cols3, vals2, x, y0) <= SCALED_TOL
+        # the structure rewritten in place without a release: the guard check ahead of the passes fires
+        lens = np.diff(rowptr)[::-1].copy()
+        if not np.array_equal(lens, np.diff(rowptr)):
+            dci.copy_(dev(torch, cols))
+            spmv_acc_amd.release_plans(drp)
+            y = dy0.clone()
+            spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy="adaptive")
+            torch.cuda.synchronize()
+            drp.copy_(dev(torch, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)))
+            torch.cuda.synchronize()
+            hiplib.spmv_acc_csr_spmv_strategy(spmv_acc_amd.strategy_id("adaptive"), 0, 1.0, 1.0, m, n, nnz, None, drp.data_ptr(),
+                                              dci.data_ptr(), dv.data_ptr(), dx.data_ptr(), y.data_ptr())
+            torch.cuda.synchronize()
+            assert hiplib.spmv_acc_last_error() == 2 and b"changed" in hiplib.spmv_acc_last_error_string()
+    finally:
+        hiplib.spmv_acc_clear_error()
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans()
+
+
+def test_slab_segments_replay_from_a_graph_and_are_bitwise_stable(torch_dev, oracle, hiplib):
+    """The passes are ordinary launches over plan-resident lists: captured after one warm-up call they replay, and two runs give the
+    same bits (whole runs add straight into y, the pieces of a long run are added in entry order by one thread: no atomics)."""
+    torch = torch_dev
+    m = n = 40000
+    rowptr, cols, vals = synth.random_csr(m, n, 10, seed=12, kind="powerlaw")
+    cols, vals = _sorted_rows(rowptr, cols, vals)
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(6)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    y = dy0.clone()
+    stream = torch.cuda.Stream()
+    try:
+        hiplib.spmv_acc_set_tunable(b"slab_segments", 8)
+        sid = spmv_acc_amd.strategy_id("line_enhance")
+        with torch.cuda.stream(stream):
+            hiplib.spmv_acc_set_stream(stream.cuda_stream)
+            spmv_acc_amd.csr_spmv(0.5, -2.0, m, n, nnz, drp, dci, dv, dx, y, strategy="line_enhance")
+            stream.synchronize()
+            first = y.clone()
+            y.copy_(dy0)
+            stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                hiplib.spmv_acc_csr_spmv_strategy(sid, 0, 0.5, -2.0, m, n, nnz, None, drp.data_ptr(), dci.data_ptr(), dv.data_ptr(),
+                                                  dx.data_ptr(), y.data_ptr())
+            assert hiplib.spmv_acc_last_error() == 0, hiplib.spmv_acc_last_error_string()
+        ref = oracle.host_spmv(0.5, -2.0, rowptr, cols, vals, x, y0)
+        for _ in range(3):
+            y.copy_(dy0)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y, first)
+        assert oracle.scaled_error(y.cpu().numpy(), ref, 0.5, -2.0, rowptr, cols, vals, x, y0) <= SCALED_TOL
+    finally:
+        hiplib.spmv_acc_set_stream(None)
         hiplib.spmv_acc_clear_error()
         hiplib.spmv_acc_reset_tunables()
         spmv_acc_amd.release_plans()
