@@ -59,6 +59,9 @@ for case in range(cases):
         if cols_law == "clusters":
             ci = ci + torch.randint(0, 3, (nnz,), generator=g, device="cuda") * (n // 3)
         ci = ci % n
+    ordered = case % 2 == 0  # every other case with ascending columns inside the rows (what files usually hold, and what the
+    if ordered:              # column-slab run lists need); the others as generated (those passes then fall back)
+        ci = torch.sort(rows * n + ci.long()).values % n
     ci = ci.to(torch.int32)
     v = torch.rand(nnz, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
     x = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
@@ -81,7 +84,7 @@ for case in range(cases):
         pv = torch.zeros(nnz + k, dtype=torch.float64, device="cuda"); pv[k:] = v; v = pv[k:]
     elif form == "shard" and m >= 4:
         r0 = int(rng.integers(1, m // 2 + 1)); r1 = int(rng.integers(r0 + 1, m + 1))
-    line = f"case {case:3d}: m={m} n={n} nnz={nnz} law={law} cols={cols_law} mean={mean} a/b={alpha}/{beta} form={form}"
+    line = f"case {case:3d}: m={m} n={n} nnz={nnz} law={law} cols={cols_law}{' sorted' if ordered else ''} mean={mean} a/b={alpha}/{beta} form={form}"
     lib = spmv_acc_amd.load_library()
     failures = []
     # the shipped configuration of every family, then the round-2 variants the per-matrix timings may or may not pick
@@ -96,7 +99,9 @@ for case in range(cases):
                 ("adaptive", {"oop": 1}), ("flat", {"oop": 1, "flat_finish": 0}), ("adaptive_plus", {"oop": 1}), ("vector_row", {"oop": 1}),
                 # later in round 3: the full row-pointer check, LIGHT / BLOCK_ROW_ORDINARY with their own kernels, flat's small-grid switch pinned both ways
                 ("adaptive", {"guard_full": 1}), ("light", {}), ("block_row_ordinary", {}), ("light", {"oop": 1}),
-                ("flat", {"flat_rowblock": 1}), ("flat", {"flat_rowblock": 0}), ("line_enhance", {"rowblock_target": 1900})]
+                ("flat", {"flat_rowblock": 1}), ("flat", {"flat_rowblock": 0}), ("line_enhance", {"rowblock_target": 1900}),
+                # column-slab passes over run lists, forced (rows whose columns do not ascend take the ordinary path)
+                ("line_enhance", {"slab_segments": 4}), ("adaptive", {"slab_segments": 16}), ("flat", {"slab_segments": 2, "oop": 1})]
     for strat, knobs in variants:
         lib.spmv_acc_reset_tunables()
         oop = bool(knobs.get("oop"))
