@@ -193,7 +193,8 @@ def test_configs2_sweep_standin_full_size(torch_dev, oracle, name):
 
 def test_configs3_rmat25_line_enhance_full_size(torch_dev, oracle):
     """BASELINE configs[3]: R-MAT scale 25 (33.5 M rows, ~0.53 B non-zeros, hub rows of millions) under line_enhance --
-    the balance probe must hand it to the row-block-plus kernel -- plus flat as the second opinion."""
+    the balance probe must hand it to the row-block-plus kernel, which the plan-time timing then replaces by the column-slab
+    passes over run lists (k_segment.hip) -- plus flat as the second opinion, and the row-block-plus kernel itself with the passes off."""
     torch = torch_dev
     _say("R-MAT scale 25: generating")
     A = synth.rmat_torch(25, device="cuda", seed=0xC4)
@@ -206,8 +207,16 @@ def test_configs3_rmat25_line_enhance_full_size(torch_dev, oracle):
     try:
         _full_size_checks(torch, oracle, A, ("line_enhance", "flat"), seed=0xC4C4)
         info = spmv_acc_amd.query_plan(rp, m)
-        assert info["plus_blocks"] > 0  # line_enhance was rescued by the row-block preprocessing pass
+        assert info["plus_blocks"] > 0  # line_enhance was rescued by the row-block preprocessing pass ...
+        # ... and (round 3) the plan-time timing then preferred the column-slab passes over run lists: that is the path checked above
+        assert info["slab_passes"] >= 2, info
+        # the one-kernel path it was timed against (hinted row-block-plus), same checks
+        spmv_acc_amd.release_plans(rp)
+        spmv_acc_amd.load_library().spmv_acc_set_tunable(b"slab_segments", 0)
+        _full_size_checks(torch, oracle, A, ("line_enhance",), seed=0xC4C4)
+        assert spmv_acc_amd.query_plan(rp, m)["slab_passes"] == 0
     finally:
+        spmv_acc_amd.load_library().spmv_acc_reset_tunables()
         spmv_acc_amd.release_plans(rp)
         del A
         torch.cuda.empty_cache()
@@ -309,6 +318,8 @@ def test_bench_line_carries_every_baseline_config(torch_dev):
     assert "ge_0.70" in d["sweep_summary"]["flat"] and "ge_0.70_back_to_back" in d["sweep_summary"]["flat"]
     assert d["rmat25"]["nnz"] > 480_000_000 and d["rmat25"]["line_enhance"]["us"] > 1000
     both_protocols(d["rmat25"]["line_enhance"], "rmat25")
+    both_protocols(d["rmat25"]["line_enhance_without_slab_passes"], "rmat25, one-kernel path")
+    assert "path" in d["rmat25"] and d["rmat25"]["line_enhance"]["us"] < d["rmat25"]["line_enhance_without_slab_passes"]["us"]
     assert d["banded_shard"]["rows"] == 32_000_000 and 0.3 < d["banded_shard"]["adaptive"]["frac"] < 1.2
     both_protocols(d["banded_shard"]["adaptive"], "banded_shard")
     assert d["per_launch_reset_ms_median"] > 0 and d["back_to_back_ms_mean"] > 0
