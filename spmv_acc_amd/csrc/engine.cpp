@@ -2043,8 +2043,19 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
   // the slab passes over run lists (k_segment.hip) are built once and timed against it, the faster stays.
   if (tun(kT_slab_segments) < 0 && p.hint_state == 1 && !t_in_slab) {
     if (p.seg_choice < 0 && !t_capturing && !tun(kT_deterministic) && !t_coarse_tuning) {
-      if (!ensure_segments(p, seg_auto_slabs(p.A.n), st)) return false;
+      // the lists are an optimisation: a matrix that leaves no room for them (or for the build's S x (m + 1) temporaries) keeps the
+      // one-kernel path instead of failing the SpMV
+      const int S_auto = seg_auto_slabs(p.A.n);
+      size_t free_b = 0, total_b = 0;
+      const size_t build_bytes = (2 * static_cast<size_t>(S_auto) + 2) * (static_cast<size_t>(p.A.m) + 1) * sizeof(int) + (static_cast<size_t>(p.A.nnz) / 4) * 12;
+      const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 2 * build_bytes;
+      (void)hipGetLastError();
       p.seg_choice = 0;
+      if (room && last_error_code_only() == kOk && !ensure_segments(p, S_auto, st)) {
+        (void)hipGetLastError();
+        clear_error();
+        p.free_segments();
+      }
       if (p.seg_state == 1) {
         ++t_plan_work;
         double *scratch = nullptr;
@@ -2068,7 +2079,12 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
     }
     if (p.seg_choice == 1) {
       // (a plan that adopted the choice from the tune cache builds its lists here; inside a capture only lists that exist are used)
-      if (p.seg_state != 1 && !t_capturing && !ensure_segments(p, seg_auto_slabs(p.A.n), st)) return false;
+      if (p.seg_state != 1 && !t_capturing && last_error_code_only() == kOk && !ensure_segments(p, seg_auto_slabs(p.A.n), st)) {
+        (void)hipGetLastError(); // (no room for the lists this time: the one-kernel path)
+        clear_error();
+        p.free_segments();
+        p.seg_choice = 0;
+      }
       if (p.seg_state == 1) {
         run_segments(st, p, alpha, beta, x, y);
         return true;
@@ -2271,6 +2287,12 @@ bool ensure_segments(Plan &p, int S, hipStream_t st) {
            hip_ok(hipMemcpyAsync(&entries, pos + A.m, sizeof(int), hipMemcpyDeviceToHost, st), "read run count") &&
            hip_ok(hipStreamSynchronize(st), "sync run count");
       if (!ok || entries == 0) continue;
+      // (the cost prefix is an int scan: a pass of hundreds of millions of one-element runs would overflow it -- such a matrix
+      // keeps the ordinary path)
+      if (static_cast<long long>(entries) * 4 + A.nnz > static_cast<long long>(INT_MAX) - 65536) {
+        unordered = 2;
+        break;
+      }
       // entries: row, first non-zero, length -> vptr; cost -> cptr -> the workgroups' first entries
       const size_t e1 = static_cast<size_t>(entries) + 1;
       int *len = nullptr, *cost = nullptr, *cptr = nullptr;
@@ -2312,7 +2334,11 @@ bool ensure_segments(Plan &p, int S, hipStream_t st) {
       tune_log("m %d nnz %d: slab_segments: slab %d of %d: %d non-zeros in %d runs, %d workgroups", A.m, A.nnz, s, S, last[1], entries, p.seg_blocks[s]);
     }
     ok = ok && hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_seg_ys), sizeof(double) * (static_cast<size_t>(max_entries) + 1)), "hipMalloc run sums");
-    if (ok) {
+    if (ok && unordered == 2) {
+      p.free_segments();
+      p.seg_state = 0;
+      tune_log("m %d nnz %d: slab_segments: too many short runs for 32-bit pass arithmetic, ordinary path", A.m, A.nnz);
+    } else if (ok) {
       p.seg_state = 1;
       p.seg_slabs = S;
     }

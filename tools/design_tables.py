@@ -28,6 +28,8 @@ for s in ("flat", "adaptive"):
     print(s, "ge_0.70", [r["sweep_summary"][s]["ge_0.70"] for r in runs], "b2b", [r["sweep_summary"][s]["ge_0.70_back_to_back"] for r in runs],
           "median", rng([r["sweep_summary"][s]["median_frac"] for r in runs]), "b2b median", rng([r["sweep_summary"][s]["median_frac_back_to_back"] for r in runs]))
 print("rmat ms", rng([r["rmat25"]["line_enhance"]["us"] / 1e3 for r in runs], 2), "frac", rng([r["rmat25"]["line_enhance"]["frac"] for r in runs]))
+if all("line_enhance_without_slab_passes" in r["rmat25"] for r in runs):
+    print("rmat one-kernel ms", rng([r["rmat25"]["line_enhance_without_slab_passes"]["us"] / 1e3 for r in runs], 2), "frac", rng([r["rmat25"]["line_enhance_without_slab_passes"]["frac"] for r in runs]), "path", {r["rmat25"].get("path", "")[:40] for r in runs})
 print("rmat slabs ms", rng([r["rmat25"]["line_enhance_col_slabs8_opt_in"]["us"] / 1e3 for r in runs], 2), "frac", rng([r["rmat25"]["line_enhance_col_slabs8_opt_in"]["frac"] for r in runs]))
 print("banded us", rng([r["banded_shard"]["adaptive"]["us"] for r in runs], 0), "frac", rng([r["banded_shard"]["adaptive"]["frac"] for r in runs]), "b2b", rng([r["banded_shard"]["adaptive"]["frac_back_to_back"] for r in runs]))
 print("cpu", [(r.get("cpu_baseline") or {}).get("value") for r in runs], [(r.get("cpu_baseline") or {}).get("value_1thread") for r in runs])
