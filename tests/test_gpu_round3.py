@@ -616,6 +616,56 @@ def test_tune_cache_is_adopted_by_the_next_process(torch_dev, tmp_path):
     assert float(second["adaptive__prepare_ms"]) < 0.5 * float(first["adaptive__prepare_ms"]), (first["adaptive__prepare_ms"], second["adaptive__prepare_ms"])
 
 
+_CHILD_POWERLAW = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+import spmv_acc_amd
+m, n, per_row = 300_000, 16_000_000, 40   # x = 128 MB: beyond the bound below which the column census is skipped
+g = torch.Generator(device="cuda"); g.manual_seed(11)
+nnz = m * per_row
+rows = torch.arange(m, device="cuda").repeat_interleave(per_row)
+ci = (torch.rand(nnz, generator=g, device="cuda", dtype=torch.float64) ** 6 * n).long().clamp_(0, n - 1)
+ci = (torch.sort(rows * n + ci).values % n).to(torch.int32)   # ascending inside every row
+rp = (torch.arange(m + 1, device="cuda") * per_row).to(torch.int32)
+v = torch.rand(nnz, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+x = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+ms = spmv_acc_amd.prepare(m, n, nnz, rp, ci, v, x, strategy="adaptive_plus")
+y = torch.ones(m, dtype=torch.float64, device="cuda")
+spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy="adaptive_plus")
+torch.cuda.synchronize()
+ref = 1.0 + torch.segment_reduce(v * x[ci.long()], "sum", lengths=torch.full((m,), per_row, device="cuda"), unsafe=True)
+scale = 1.0 + torch.segment_reduce((v * x[ci.long()]).abs(), "sum", lengths=torch.full((m,), per_row, device="cuda"), unsafe=True)
+np.savez({out!r}, y=y.cpu().numpy(), prepare_ms=np.array(ms), slab_passes=np.array(spmv_acc_amd.query_plan(rp, m)["slab_passes"]),
+         err=np.array(float(((y - ref).abs() / scale).max().item())))
+"""
+
+
+def test_slab_pass_choice_is_timed_once_and_kept_by_the_tune_cache(torch_dev, tmp_path):
+    """A matrix with power-law columns and an x beyond the caches: the first process takes the column census, builds the run lists and
+    times the slab passes against the row-block-plus kernel (one tune-log line says which stays); the second process adopts the
+    choice from the cache without timing anything, runs the same path, and computes bitwise the same y."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cache = str(tmp_path / "tune.txt")
+    res = []
+    for tag in ("p1", "p2"):
+        out = str(tmp_path / f"{tag}.npz")
+        env = dict(os.environ, SPMV_ACC_TUNE_LOG="1", SPMV_ACC_TUNE_CACHE=cache)
+        r = subprocess.run([sys.executable, "-c", _CHILD_POWERLAW.format(root=root, out=out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res.append((np.load(out), r.stderr))
+    (first, log1), (second, log2) = res
+    assert "column census" in log1 and "column-slab passes over run lists" in log1, log1[-3000:]
+    assert "adopted from the tune cache" in log2 and "column-slab passes over run lists" not in log2, log2[-3000:]
+    assert float(first["err"]) <= SCALED_TOL and float(second["err"]) <= SCALED_TOL
+    assert int(first["slab_passes"]) == int(second["slab_passes"])
+    assert np.array_equal(first["y"], second["y"])
+    assert float(second["prepare_ms"]) < float(first["prepare_ms"])
+
+
 def test_deterministic_switch_is_bitwise_stable_across_processes(torch_dev, tmp_path):
     """SPMV_ACC_DETERMINISTIC=1: nothing is timed (no timing line in the tune log), every choice follows a rule on the matrix'
     shape, so two processes compute bitwise the same y with every strategy."""
