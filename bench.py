@@ -591,6 +591,35 @@ def main():
                             "row-range shards, x replicated, beta = 0, allgather(y) per step",
                 "rows_per_gpu": rows, "nnz_per_gpu": BW["nnz"], "steps": bsteps,
                 "spmv_only_frac_of_hbm_peak": round(b_alg_b / (bev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            # beside it, what this matrix allows when x is partitioned like the rows (x_{k+1} = f(y_k) solvers): each rank receives only
+            # the x entries its columns reference -- 4 + 3 doubles per neighbour for this band -- instead of every peer's 256 MB slice
+            # (GhostedRowShardedSpmv, `--exchange ghost`).  Reported, never the headline: north_star prescribes the allgather of y.
+            try:
+                from spmv_acc_amd.dist import GhostedRowShardedSpmv
+
+                gbounds = np.arange(world + 1, dtype=np.int64) * rows
+                geng = GhostedRowShardedSpmv(rank, world, gbounds, brp, bci, bv, device, strategy="adaptive")
+                geng.set_x(bx[rank * rows: (rank + 1) * rows])
+                for _ in range(3):
+                    geng.iterate(0.4)  # (spectral radius of 0.4 * A is below 1)
+                dist.barrier()
+                torch.cuda.synchronize()
+                g0 = time.perf_counter()
+                for _ in range(bsteps):
+                    geng.iterate(0.4)
+                dist.barrier()
+                torch.cuda.synchronize()
+                gt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=device)
+                dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+                gwall = float(gt.item())
+                bextra["halo_exchange"] = {
+                    "what": "x partitioned like the rows, x <- 0.4 * A * x, each rank receiving only the columns it references",
+                    "ms_per_step": round(gwall / bsteps * 1e3, 6), "gflops_total": round(2.0 * BW["nnz"] * world * bsteps / gwall / 1e9, 3),
+                    "exchanged_bytes_per_rank_per_step": geng.exchanged_bytes_per_step, "ghost_columns": geng.n_ghost}
+                spmv_acc_amd.release_plans(brp)
+                del geng
+            except Exception as ex:  # noqa: BLE001 -- a side leg must not cost the run its line
+                bextra["halo_exchange_error"] = repr(ex)[:200]
             out_extra["banded"] = bextra
             spmv_acc_amd.release_plans(brp)
             del brp, bci, bv, bx, by0, BW
