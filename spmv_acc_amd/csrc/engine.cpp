@@ -2254,6 +2254,10 @@ bool ensure_segments(Plan &p, int S, hipStream_t st) {
   const CsrDev &A = p.A;
   const size_t m1 = static_cast<size_t>(A.m) + 1;
   const int width = (A.n + S - 1) / S > 0 ? (A.n + S - 1) / S : 1;
+  SlabBounds bounds;
+  for (int b = 0; b < 15; ++b) bounds.first[b] = static_cast<int>(std::min<long long>(static_cast<long long>(width) * (b + 1), INT_MAX));
+  // (equal column ranges.  Unequal ones were tried on R-MAT 25 through an environment hook since removed -- the hot eighth split in two
+  // or four, the cold half kept whole, 4 to 8 slabs in all: 5.53-5.92 ms against 5.30 for eight equal slabs, profiles/r03_slab_segments.txt)
   int *cnt = nullptr, *beg = nullptr, *pieces = nullptr, *pos = nullptr, *flag = nullptr;
   void *tmp = nullptr;
   const size_t tmp_bytes = col16_scan_bytes(A.m);
@@ -2266,7 +2270,7 @@ bool ensure_segments(Plan &p, int S, hipStream_t st) {
             hip_ok(hipMemsetAsync(flag, 0, sizeof(int), st), "memset order flag");
   int unordered = 0;
   if (ok) {
-    launch_segment_count(st, A, width, S, cnt, beg, flag);
+    launch_segment_count(st, A, bounds, S, cnt, beg, flag);
     ok = hip_ok(hipMemcpyAsync(&unordered, flag, sizeof(int), hipMemcpyDeviceToHost, st), "read order flag") &&
          hip_ok(hipStreamSynchronize(st), "sync run counts");
   }

@@ -45,7 +45,7 @@ static_assert(kSegCost + kSegPiece <= kSegTile && (kSegCost + kSegPiece) / kSegM
 static_assert(kNnzPerThread == 8, "the owner map is scanned 8 elements per lane (one 16-B LDS word)");
 
 // cnt[s][row] (S x (m + 1), entry m zeroed for the scans), beg[s][row] (same shape): first non-zero of slab s's run in row `row`
-__global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__restrict__ rp, const int *__restrict__ ci, int m, int width,
+__global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__restrict__ rp, const int *__restrict__ ci, int m, SlabBounds B,
                                                                  int S, int *__restrict__ cnt, int *__restrict__ beg,
                                                                  int *__restrict__ not_monotone) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -58,7 +58,13 @@ __global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__re
     for (int base = j0; base < j1; base += kWave) {
       const int j = base + lane;
       const bool live = j < j1;
-      const int slab = live ? ci[j] / width : S; // (dead lanes: above every slab, so the order test passes)
+      int slab = S; // (dead lanes: above every slab, so the order test passes)
+      if (live) {
+        const int c = ci[j];
+        slab = 0;
+#pragma unroll
+        for (int b = 0; b < 15; ++b) slab += (b < S - 1 && c >= B.first[b]) ? 1 : 0; // first[b] = first column of slab b + 1
+      }
       const int left = __shfl_up(slab, 1, kWave);
       bad = bad || (live && slab < (lane == 0 ? prev_last : left));
       const int last_live = (j1 - base < kWave ? j1 - base : kWave) - 1;
@@ -244,11 +250,11 @@ __global__ __launch_bounds__(kThreads) void segment_merge_kernel(int entries, co
 
 } // namespace
 
-void launch_segment_count(hipStream_t stream, const CsrDev &A, int width, int S, int *cnt, int *beg, int *not_monotone) {
+void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone) {
   if (A.m <= 0) return;
   long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave);
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(segment_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, width, S, cnt,
+  hipLaunchKernelGGL(segment_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S, cnt,
                      beg, not_monotone);
 }
 void launch_segment_pieces(hipStream_t stream, const int *cnt_s, int m, int piece_max, int *pieces) {

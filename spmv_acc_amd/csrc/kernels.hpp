@@ -33,7 +33,10 @@ constexpr int kGuardSamples = 64; // rowptr[k * m / 63], k = 0 .. 63 (includes r
 void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard);
 void launch_guard_check(hipStream_t stream, const CsrDev &A); // the check alone, for paths whose SpMV kernels run on derived matrices
 // column-slab blocking without a copy (k_segment.hip, tunable slab_segments): cnt S x (m + 1), beg S x (m + 1); *not_monotone pre-zeroed
-void launch_segment_count(hipStream_t stream, const CsrDev &A, int width, int S, int *cnt, int *beg, int *not_monotone);
+struct SlabBounds {
+  int first[15]; // first[b] = first column of slab b + 1 (ascending); slab of column c = number of entries <= c among the first S - 1
+};
+void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone);
 void launch_segment_pieces(hipStream_t stream, const int *cnt_s, int m, int piece_max, int *pieces);
 void launch_segment_compact(hipStream_t stream, const int *cnt_s, const int *beg_s, const int *pos, int m, int piece_max, int *seg_row,
                             int *seg_begin, int *seg_len, int *has_pieces); // *has_pieces pre-zeroed: set when some run was cut
