@@ -2042,7 +2042,9 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
   // Where the column census found a hot set (power-law columns, x far beyond the L2s) this kernel is bound by gathers that miss:
   // the slab passes over run lists (k_segment.hip) are built once and timed against it, the faster stays.
   if (tun(kT_slab_segments) < 0 && p.hint_state == 1 && !t_in_slab) {
-    if (p.seg_choice < 0 && !t_capturing && !tun(kT_deterministic) && !t_coarse_tuning) {
+    // (also while adaptive is timing its kernel families: row-block-plus is then timed as what it will run -- on R-MAT 25 the one-kernel
+    // path beats flat by 0.5 % only, 7.26 against 7.29 ms, and a family choice made on that would never meet the 5.3 ms of the passes)
+    if (p.seg_choice < 0 && !t_capturing && !tun(kT_deterministic)) {
       // the lists are an optimisation: a matrix that leaves no room for them (or for the build's S x (m + 1) temporaries) keeps the
       // one-kernel path instead of failing the SpMV
       const int S_auto = seg_auto_slabs(p.A.n);
