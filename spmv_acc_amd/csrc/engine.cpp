@@ -181,7 +181,8 @@ Tunable g_tunables[] = {
                                // per column slab the list of (row, first non-zero, length) runs -- structure only -- and an SpMV is S passes
                                // over those runs, each gathering from 1/S of x.  -1 = on matrices whose column census finds a hot set (the
                                // matrices that get gather hints: power-law columns, x far beyond the L2s) 8 slabs are built and timed once
-                               // against the row-block-plus kernel, the faster stays (R-MAT scale 25: 7.3 -> 5.3 ms); 0 = off; S >= 2 = always,
+                               // against the row-block-plus kernel, the faster stays (R-MAT scale 25: 7.3 -> 5.3 ms; with `deterministic`, which
+                               // times nothing, the row-block-plus kernel stays); 0 = off; S >= 2 = always,
                                // whatever the strategy (rows that are not ordered: the ordinary path)
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
