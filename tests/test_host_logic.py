@@ -261,6 +261,14 @@ def test_round3_switches_and_entry_points_without_a_gpu(hiplib, tmp_path):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                            env=dict(os.environ, SPMV_ACC_DETERMINISTIC=env_val, PYTHONPATH=ROOT))
         assert r.returncode == 0 and r.stdout.split() == [want, "0"], (r.stdout, r.stderr[-500:])
+    # the late round-3 switches and their shipped values: the full row-pointer check is opt-in, the slab passes are automatic (-1),
+    # the slab-major copy is opt-in; SPMV_ACC_TUNABLES seeds any of them for a process that cannot call the setter
+    assert [hiplib.spmv_acc_get_tunable(n) for n in (b"guard_full", b"slab_segments", b"col_slabs", b"legacy_kernels", b"rowblock_target")] == [0, -1, 0, 1, 1500]
+    assert hiplib.spmv_acc_query_plan_slab_passes(None, 5) == -2  # no such plan
+    code = "import spmv_acc_amd as s; l = s.load_library(); print(l.spmv_acc_get_tunable(b'slab_segments'), l.spmv_acc_get_tunable(b'guard_full'))"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, SPMV_ACC_TUNABLES="slab_segments=0,guard_full=1", PYTHONPATH=ROOT))
+    assert r.returncode == 0 and r.stdout.split() == ["0", "1"], (r.stdout, r.stderr[-500:])
     spmv_acc_amd.set_tune_cache(str(tmp_path / "tune.txt"))
     spmv_acc_amd.set_tune_cache(None)
     assert hiplib.spmv_acc_check_plans() == 0 and hiplib.spmv_acc_cached_plans() == 0
