@@ -171,9 +171,10 @@ Tunable g_tunables[] = {
                                // tile digest -> row extents -- than a row block, which a grid of two or three workgroups per CU cannot
                                // hide: 7-11 % per launch on the small sweep stand-ins); 0 = always the flat tile kernel; 1 = always the
                                // row blocks where balanced.  Large grids always run the tile kernel
-    {"legacy_kernels", 1, 1},  // KERNEL_STRATEGY LIGHT / BLOCK_ROW_ORDINARY: 1 = their own kernels (k_legacy.hip: rows handed out by an atomic
-                               // counter; one workgroup per row -- what the names mean in the reference), 0 = the round-1/2 stand-ins (the
-                               // vector-row tile kernel; one wavefront per row), which are faster on most matrices
+    {"legacy_kernels", 1, 1},  // KERNEL_STRATEGY LIGHT / BLOCK_ROW_ORDINARY / THREAD_ROW: 1 = what the names mean in the reference (k_legacy.hip: rows
+                               // handed out by an atomic counter; one workgroup per row; THREAD_ROW: one lane per row at every row length), 0 = the
+                               // round-1/2 stand-ins (the vector-row tile kernel; one wavefront per row; the row-block kernel's own lanes-per-row
+                               // pick), which are faster on most matrices (THREAD_ROW: by 0-4.5 %)
     {"guard_full", 0, 0},      // OPT-IN: 1 = every SpMV re-reads ALL of rowptr and compares a 64-bit digest with the plan's (k_guard.hip) -- an
                                // in-place edit of the structure is then always noticed, not only where it touches one of the 64 samples of the
                                // guard the kernels carry.  4 * (m + 1) bytes and two small launches more per call
@@ -1717,7 +1718,7 @@ template <class Launch> bool autotune_hint(Plan &p, int fam, hipStream_t st, Lau
 }
 
 bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y,
-                  bool allow_uneven_switch);
+                  bool allow_uneven_switch = false, int lanes_per_row = 0);
 bool probe_rowblock(Plan &p, int rpb, hipStream_t st);
 
 // A flat tile is one workgroup and walks its rows 256 at a time.  Where a tile owns tens of thousands of rows (hypersparse
@@ -1730,7 +1731,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
   if (p.flat.max_tile_rows > kFlatMaxTileRows && tun(kT_rowblock_guard)) {
     // (guard against mutual recursion: the row-block rescue goes to row-block-plus unless rescue_flat is set, and a matrix with
     // such tiles has no row-block imbalance of the hub-row kind)
-    if (!(tun(kT_rescue_flat) && p.rowblock_ok == 0)) return run_rowblock(st, p, nullptr, alpha, beta, x, y, false);
+    if (!(tun(kT_rescue_flat) && p.rowblock_ok == 0)) return run_rowblock(st, p, nullptr, alpha, beta, x, y, false, 0);
   }
   p.A.cold = nullptr; // (the plan-time timings below run without gather hints)
   p.flat.col16 = nullptr;
@@ -1753,7 +1754,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
       int vec = 1, rpb = kThreads;
       pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
       if (t_capturing ? (p.rowblock_ok == 1 && p.rowblock_rpb == rpb) : (probe_rowblock(p, rpb, st) && p.rowblock_ok == 1))
-        return run_rowblock(st, p, nullptr, alpha, beta, x, y, false);
+        return run_rowblock(st, p, nullptr, alpha, beta, x, y, false, 0);
     } else if (p.flat_rowblock_choice < 0 && !t_capturing && !tun(kT_deterministic)) {
       int vec = 1, rpb = kThreads;
       pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
@@ -1777,7 +1778,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
                  p.flat_rowblock_choice ? "row blocks" : "tile kernel");
       }
     }
-    if (rb_mode < 0 && p.flat_rowblock_choice == 1) return run_rowblock(st, p, nullptr, alpha, beta, x, y, false);
+    if (rb_mode < 0 && p.flat_rowblock_choice == 1) return run_rowblock(st, p, nullptr, alpha, beta, x, y, false, 0);
   }
   launch_flat_with(st, p, policy_for(p, kFamFlat), alpha, beta, x, y);
   return true;
@@ -1900,9 +1901,11 @@ bool ensure_digest(Plan &p, int rpb, hipStream_t st) {
 bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y);
 
 bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y,
-                  bool allow_uneven_switch = false) {
+                  bool allow_uneven_switch, int lanes_per_row) {
   int vec = 1, rpb = kThreads;
   pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
+  // (THREAD_ROW: one lane per row whatever the row length, the rows per workgroup still from the tile target)
+  if (lanes_per_row > 0) vec = lanes_per_row;
   const int forced = tun(kT_rowblock_vec);
   if (forced > 0) {
     vec = forced;
@@ -2560,6 +2563,12 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     run_rowblock(st, *p, h_rowptr, alpha, beta, dx, dy, true); // engine's choice, like adaptive's even-matrix branch
     break;
   case kThreadRow:
+    // KERNEL_STRATEGY THREAD_ROW (hip-thread-row/thread_row.cpp:17-48, thread_row_block.hpp): ONE lane sums each row -- the reference's
+    // block-level form: the workgroup's non-zeros staged through LDS by coalesced loads, then a thread per row.  Up to 5.8 non-zeros
+    // per row that is the row-block kernel's own shape; beyond, where the reference falls back to a 128-block naive loop, the name
+    // keeps its meaning here (rows longer than a wavefront are handed to whole waves by tile_row_sum) unless legacy_kernels is 0
+    run_rowblock(st, *p, h_rowptr, alpha, beta, dx, dy, false, tun(kT_legacy_kernels) ? 1 : 0);
+    break;
   case kLineEnhance:
   case kLine:
     run_rowblock(st, *p, h_rowptr, alpha, beta, dx, dy);
