@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__re
       beg[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row] = j0 + incl - acc;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x < S) cnt[static_cast<size_t>(threadIdx.x) * (static_cast<size_t>(m) + 1) + m] = 0;
+  if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < S) cnt[static_cast<size_t>(threadIdx.x) * (static_cast<size_t>(m) + 1) + m] = 0;
 }
 
 // pieces[r] = entries row r contributes to this slab's list (0, or its run cut into pieces of at most piece_max); pieces[m] = 0

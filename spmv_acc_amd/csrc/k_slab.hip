@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kThreads) void slab_count_kernel(const int *__restr
     if (lane < S) cnt[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row] = acc;
   }
   // the scan runs over m + 1 entries per slab: the last one is the total
-  if (blockIdx.x == 0 && threadIdx.x < S) cnt[static_cast<size_t>(threadIdx.x) * (static_cast<size_t>(m) + 1) + m] = 0;
+  if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < S) cnt[static_cast<size_t>(threadIdx.x) * (static_cast<size_t>(m) + 1) + m] = 0;
 }
 
 // off[s] = first position of slab s in the re-ordered arrays (exclusive sums of the slabs' non-zero counts)
