@@ -691,7 +691,7 @@ def main():
     result.update(out_extra)
     info = spmv_acc_amd.query_plan(W["rp"], m) if args.exchange != "ghost" else None
     if info:  # what the first call measured and kept for this matrix (kernel family: 0 fixed row blocks, 1 row-block-plus, 2 flat)
-        result["plan"] = {k: info[k] for k in ("stream_policy", "adaptive_family", "flat_fixup", "plus_blocks", "flat_tiles")}
+        result["plan"] = {k: info[k] for k in ("stream_policy", "adaptive_family", "flat_fixup", "plus_blocks", "flat_tiles", "slab_passes")}
     if rank == 0:
         result["copy_ceiling_gbs"] = round(copy_ceiling_gbs(torch, device), 1)
     if rank == 0 and world == 1 and not args.no_legs:

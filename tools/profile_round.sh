@@ -20,6 +20,9 @@ S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 # candidates: they run with the cache policy the (unperturbed) trace pass settled on, so all three passes profile one kernel.
 POL=$(python3 -c "import json,sys; d=json.loads(open('$OUT/bench_under_trace.json').read().strip().splitlines()[-1]); print(d.get('plan',{}).get('stream_policy',-1))")
 if [ "$POL" -ge 0 ] 2>/dev/null; then export SPMV_ACC_TUNABLES="stream_plain=$POL${SPMV_ACC_TUNABLES:+,$SPMV_ACC_TUNABLES}"; fi
+# ... and with the column-slab passes where the trace pass's plan-time timing chose them (under the counters it can fall the other way)
+SLABS=$(python3 -c "import json,sys; d=json.loads(open('$OUT/bench_under_trace.json').read().strip().splitlines()[-1]); print(d.get('plan',{}).get('slab_passes',0))")
+if [ "$SLABS" -ge 2 ] 2>/dev/null; then export SPMV_ACC_TUNABLES="slab_segments=$SLABS${SPMV_ACC_TUNABLES:+,$SPMV_ACC_TUNABLES}"; fi
 echo "[profile_round] counter passes with SPMV_ACC_TUNABLES=$SPMV_ACC_TUNABLES"
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "[profile_round] pmc $c"
@@ -50,7 +53,25 @@ def dominant(path):
             if best is None or int(m.group(3)) > best[1]:
                 best = (m.group(2), int(m.group(3)), float(m.group(4)))
     return best
+def slab_passes(path):
+    # column-slab passes over run lists (k_segment.hip): one SpMV = S dispatches of segment_tile_kernel (+ the merge of pieces, + one
+    # guard_check_kernel, whose dispatch count is therefore the number of SpMVs); per-SpMV KB = the sum over those kernels / SpMVs
+    rows = {}
+    for line in open(path):
+        m = re.match(r"(\w+) kernel=(.+?) dispatches=(\d+) mean_KB=([\d.]+)", line)
+        if m:
+            rows[m.group(2)] = (int(m.group(3)), float(m.group(4)))
+    tiles = [k for k in rows if "segment_tile" in k]
+    checks = [k for k in rows if "guard_check" in k]
+    if not tiles or not checks or rows[tiles[0]][0] < 4 * rows[checks[0]][0]:
+        return None
+    spmvs = rows[checks[0]][0]
+    total = sum(n * kb for k, (n, kb) in rows.items() if any(s in k for s in ("segment_tile", "segment_merge", "guard_check", "scale_y")))
+    return (f"{tiles[0]} x {rows[tiles[0]][0] // spmvs} passes per SpMV (+ merge)", spmvs, total / spmvs)
 f, w = dominant(f"{out}/pmc_FETCH_SIZE.summary.txt"), dominant(f"{out}/pmc_WRITE_SIZE.summary.txt")
+sf, sw = slab_passes(f"{out}/pmc_FETCH_SIZE.summary.txt"), slab_passes(f"{out}/pmc_WRITE_SIZE.summary.txt")
+if sf and sw:
+    f, w = sf, sw
 if f is None or w is None:
     sys.exit(f"profile_round: no SpMV kernel of the library found in {out}/pmc_*.summary.txt (kernel names changed? see dominant())")
 bench = json.loads(open(f"{out}/bench_under_trace.json").read().strip().splitlines()[-1])
