@@ -2466,8 +2466,15 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   if (tun(kT_slab_segments) >= 2 && !t_in_slab) {
     // column-slab blocking without a copy: S passes over the plan's run lists (k_segment.hip), whatever the strategy name
     const int S = tun(kT_slab_segments) > 16 ? 16 : tun(kT_slab_segments);
-    if (!ensure_segments(*p, S, st)) return;
-    if (p->seg_state == 1) {
+    if (last_error_code_only() == kOk && !t_capturing && !ensure_segments(*p, S, st)) {
+      // (no room for the lists or their S x (m + 1) build temporaries: the passes are an optimisation, the strategy's own kernel runs)
+      (void)hipGetLastError();
+      clear_error();
+      p->free_segments();
+      p->seg_state = 0; // (not tried again for this plan)
+      tune_log("m %d nnz %d: slab_segments: the run lists could not be built, ordinary path", m, p->A.nnz);
+    }
+    if (p->seg_state == 1 && p->seg_slabs == S) {
       run_segments(st, *p, alpha, beta, dx, dy);
       if (t_plan_work != prepare_clock.work0 && p->tune_key) tune_store(*p);
       return;
