@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """The measurement tables of DESIGN.md section 6 from bench.py JSON lines (ranges over the runs given):
-    python tools/design_tables.py gpurun_out/r3_bench7.json gpurun_out/r3_bench8.json ..."""
+    python tools/design_tables.py gpurun_out/r3_bench7.json gpurun_out/r3_bench8.json ...      (one line per file, or)
+    python tools/design_tables.py profiles/r03_bench_final_runs.jsonl                          (one run per line)"""
 import json, sys
-runs = [json.load(open(p)) for p in sys.argv[1:]]
+runs = [json.loads(line) for p in sys.argv[1:] for line in open(p) if line.strip().startswith("{")]
 def rng(vals, nd=3):
     vals = [v for v in vals if v is not None]
     lo, hi = min(vals), max(vals)
