@@ -90,7 +90,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kT_slab_segments, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kT_slab_segments, kT_vector_target, kTunableCount
 };
 #ifdef FLAT_SEGMENT_SUM_REDUCE
 constexpr int kFlatReduceBuilt = 1;
@@ -185,6 +185,9 @@ Tunable g_tunables[] = {
                                // against the row-block-plus kernel, the faster stays (R-MAT scale 25: 7.3 -> 5.3 ms; with `deterministic`, which
                                // times nothing, the row-block-plus kernel stays); 0 = off; S >= 2 = always,
                                // whatever the strategy (rows that are not ordered: the ordinary path)
+    {"vector_target", 1900, 1900}, // vector-row tile kernel: products a workgroup's rows should bring to its 2048-product tile (the row-block family's
+                               // `rowblock_target` went to 1500 in round 3; this kernel, with two rows per lane group, keeps the fuller tile:
+                               // 1900 against 1500 is 3-5.5 % faster on four of five sweep stand-ins, equal on the fifth)
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -2551,7 +2554,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
       // the reference's lane width per row (vector_row.cpp:15-27) on the tile machinery
       const double a = static_cast<double>(p->A.nnz) / m;
       auto launch = [&](int pol, double al, double be, double *yy) {
-        launch_vector_tile(st, p->A, m, w, w, a, a, tun(kT_rowblock_target), tun(kT_xcd_chunk), pol, al, be, dx, yy,
+        launch_vector_tile(st, p->A, m, w, w, a, a, tun(kT_vector_target), tun(kT_xcd_chunk), pol, al, be, dx, yy,
                            next_reverse(*p));
       };
       if (!autotune_policy(*p, kFamVector, st, [&](int pol, double *ys) { launch(pol, 1.0, trial_beta(), ys); })) return;
@@ -2603,7 +2606,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
         if (tun(kT_vector_tile)) {
           const double f0 = half_rows > 0 ? static_cast<double>(p->samples.half) / half_rows : 0.0;
           const double f1 = (static_cast<double>(p->samples.last) - p->samples.half) / (m - half_rows);
-          launch_vector_tile(st, p->A, half_rows, tile_vec(a0), tile_vec(a1), f0, f1, tun(kT_rowblock_target),
+          launch_vector_tile(st, p->A, half_rows, tile_vec(a0), tile_vec(a1), f0, f1, tun(kT_vector_target),
                              tun(kT_xcd_chunk), policy_for(*p, kFamVector), alpha, beta, dx, dy);
         } else {
           launch_vector_row(st, p->A, half_rows, classic_vec(a0), classic_vec(a1), alpha, beta, dx, dy);
