@@ -137,7 +137,9 @@ void launch_light(hipStream_t stream, const CsrDev &A, int w, int grid_blocks, u
 
 void launch_block_row(hipStream_t stream, const CsrDev &A, int grid_blocks, double alpha, double beta, const double *x, double *y) {
   if (A.m <= 0) return;
-  const int grid = A.m < grid_blocks ? A.m : grid_blocks;
+  // (an ODD number of workgroups: with a power-of-two grid workgroup 0 would walk the rows k * grid, which on matrices whose row length follows
+  // the bits of the row index -- R-MAT -- are all hubs)
+  const int grid = A.m < grid_blocks ? A.m : (grid_blocks | 1);
   hipLaunchKernelGGL(block_row_kernel, dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci, A.v, x, y,
                      A.yin ? A.yin : y, A.guard, A.stale);
 }

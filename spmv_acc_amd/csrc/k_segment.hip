@@ -37,6 +37,7 @@ namespace {
 
 using namespace dev;
 
+constexpr int kSegShortRow = 32;                    // rows up to this long are counted one lane per row at plan time
 constexpr int kSegTile = kThreads * kNnzPerThread; // 2048 products
 constexpr int kSegCost = 1536;                      // cost per workgroup; + one entry of at most kSegPiece = at most 2047 products
 constexpr int kSegMinCost = 4;                      // an entry costs at least this much: at most 511 entries per workgroup
@@ -49,9 +50,12 @@ __global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__re
                                                                  int S, int *__restrict__ cnt, int *__restrict__ beg,
                                                                  int *__restrict__ not_monotone) {
   const int lane = threadIdx.x & (kWave - 1);
-  const long long waves = static_cast<long long>(gridDim.x) * (kThreads / kWave);
-  for (long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave; row < m; row += waves) {
+  // ONE wavefront per row, no grid stride: a stride of 2^16 wavefronts gave wavefront 0 the rows k * 2^16 -- on R-MAT (a row's length falls
+  // with the number of set bits in its index) all hubs, 6.6 M non-zeros walked by one wavefront: 96 ms for the kernel, the hub row alone is 9
+  const long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave;
+  if (row < m) {
     const int j0 = rp[row], j1 = rp[row + 1];
+    if (j1 - j0 <= kSegShortRow) return; // (wave-uniform: short rows are counted 64 to a wavefront by segment_count_short_kernel)
     int acc = 0;
     int prev_last = 0; // slab of the last non-zero of the previous step
     bool bad = false;
@@ -87,7 +91,43 @@ __global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__re
       beg[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row] = j0 + incl - acc;
     }
   }
-  if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < S) cnt[static_cast<size_t>(threadIdx.x) * (static_cast<size_t>(m) + 1) + m] = 0;
+}
+
+// The same for rows of at most kSegShortRow non-zeros, one LANE per row (power-law matrices: 33.5 M rows of R-MAT 25 average 16 non-zeros, and one
+// wavefront per row spent 89 ms on them; neighbouring lanes read neighbouring rows, i.e. the same cache lines).  Counts are packed 8 bits per
+// slab into two 64-bit words (a row of <= 32 non-zeros cannot overflow a field).
+__global__ __launch_bounds__(kThreads) void segment_count_short_kernel(const int *__restrict__ rp, const int *__restrict__ ci, int m, SlabBounds B,
+                                                                       int S, int *__restrict__ cnt, int *__restrict__ beg,
+                                                                       int *__restrict__ not_monotone) {
+  const long long row = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
+  if (row == m) { // (the grid covers m + 1 entries: the scans' closing zeros)
+    for (int s = 0; s < S; ++s) cnt[static_cast<size_t>(s) * (static_cast<size_t>(m) + 1) + m] = 0;
+  }
+  if (row >= m) return;
+  const int j0 = rp[row], j1 = rp[row + 1];
+  if (j1 - j0 > kSegShortRow) return; // a long row: segment_count_kernel
+  unsigned long long p0 = 0ULL, p1 = 0ULL; // slabs 0-7, 8-15
+  int prev = 0;
+  bool bad = false;
+  for (int j = j0; j < j1; ++j) {
+    const int c = ci[j];
+    int slab = 0;
+#pragma unroll
+    for (int b = 0; b < 15; ++b) slab += (b < S - 1 && c >= B.first[b]) ? 1 : 0;
+    bad = bad || slab < prev;
+    prev = slab;
+    const unsigned long long inc = 1ULL << (8 * (slab & 7));
+    if (slab < 8) p0 += inc;
+    else p1 += inc;
+  }
+  if (bad) atomicOr(not_monotone, 1);
+  int at = j0;
+  for (int s = 0; s < S; ++s) {
+    const int n = static_cast<int>(((s < 8 ? p0 : p1) >> (8 * (s & 7))) & 0xFFULL);
+    cnt[static_cast<size_t>(s) * (static_cast<size_t>(m) + 1) + row] = n;
+    beg[static_cast<size_t>(s) * (static_cast<size_t>(m) + 1) + row] = at;
+    at += n;
+  }
 }
 
 // pieces[r] = entries row r contributes to this slab's list (0, or its run cut into pieces of at most piece_max); pieces[m] = 0
@@ -252,10 +292,12 @@ __global__ __launch_bounds__(kThreads) void segment_merge_kernel(int entries, co
 
 void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone) {
   if (A.m <= 0) return;
-  long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave);
-  if (blocks > 16384) blocks = 16384;
+  const long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row
   hipLaunchKernelGGL(segment_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S, cnt,
                      beg, not_monotone);
+  const long long short_blocks = (static_cast<long long>(A.m) + 1 + kThreads - 1) / kThreads; // m + 1: the closing zeros
+  hipLaunchKernelGGL(segment_count_short_kernel, dim3(static_cast<unsigned>(short_blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S,
+                     cnt, beg, not_monotone);
 }
 void launch_segment_pieces(hipStream_t stream, const int *cnt_s, int m, int piece_max, int *pieces) {
   const long long blocks = (static_cast<long long>(m) + 1 + kThreads - 1) / kThreads;

@@ -27,8 +27,10 @@ using namespace dev;
 __global__ __launch_bounds__(kThreads) void slab_count_kernel(const int *__restrict__ rp, const int *__restrict__ ci, int m, int width,
                                                               int S, int *__restrict__ cnt) {
   const int lane = threadIdx.x & (kWave - 1);
-  const long long waves = static_cast<long long>(gridDim.x) * (kThreads / kWave);
-  for (long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave; row < m; row += waves) {
+  // (one wavefront per row, no grid stride: a stride of 2^16 wavefronts hands wavefront 0 the rows k * 2^16, which on R-MAT are all hubs --
+  // 82 ms for this kernel and 106 for the scatter where the longest row alone takes 9; see k_segment.hip)
+  const long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave;
+  if (row < m) {
     const int j0 = rp[row], j1 = rp[row + 1];
     int acc = 0;
     for (int base = j0; base < j1; base += kWave) {
@@ -51,8 +53,8 @@ __global__ __launch_bounds__(kThreads) void slab_scatter_kernel(const int *__res
                                                                 const int *__restrict__ rps, const long long *__restrict__ off,
                                                                 int *__restrict__ ci_out, double *__restrict__ v_out, int values_only) {
   const int lane = threadIdx.x & (kWave - 1);
-  const long long waves = static_cast<long long>(gridDim.x) * (kThreads / kWave);
-  for (long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave; row < m; row += waves) {
+  const long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave; // one wavefront per row
+  if (row < m) {
     const int j0 = rp[row], j1 = rp[row + 1];
     long long pos = 0; // lane s: where slab s's next non-zero of this row goes
     if (lane < S) pos = off[lane] + rps[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row];
@@ -125,16 +127,14 @@ void launch_slab_merge(hipStream_t stream, int ms, const int *rowid, const doubl
 
 void launch_slab_count(hipStream_t stream, const CsrDev &A, int width, int S, int *cnt) {
   if (A.m <= 0) return;
-  long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave);
-  if (blocks > 16384) blocks = 16384; // grid-stride: 64 Ki waves walk the rows
+  const long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row
   hipLaunchKernelGGL(slab_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, width, S, cnt);
 }
 
 void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, const int *rps, const long long *off, int *ci_out,
                          double *v_out, bool values_only) {
   if (A.m <= 0) return;
-  long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave);
-  if (blocks > 16384) blocks = 16384;
+  const long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave);
   hipLaunchKernelGGL(slab_scatter_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.v, A.m, width, S,
                      rps, off, ci_out, v_out, values_only ? 1 : 0);
 }
