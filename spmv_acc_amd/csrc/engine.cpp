@@ -1332,6 +1332,12 @@ struct TuneTimer {
     if (!hip_ok(hipEventSynchronize(e1), "sync tune") || !hip_ok(hipEventElapsedTime(&first, e0, e1), "elapsed tune")) return false;
     // (short kernels time noisily and cost nothing: more launches; from 0.1 ms on one more warm-up and three timed launches
     // separate candidates that differ by a few per cent -- the per-matrix timings of a 0.16 ms SpMV were 2/3 of a 21 ms first call)
+    // (a launch of several milliseconds -- R-MAT scale 25: 7-8 ms, eighteen candidate launches = 145 ms of a 300 ms first call -- is its own
+    // steady state: what the previous launch left in the caches is a fraction of a per cent of it.  One launch per candidate.)
+    if (first >= 4.0f) {
+      *ms_per_launch = first;
+      return true;
+    }
     const int warm = first < 0.1f ? 2 : (first < 2.0f ? 1 : 0);
     const int timed = first < 0.1f ? 5 : (first < 0.5f ? 3 : (first < 2.0f ? 2 : 1));
     for (int w = 0; w < warm; ++w) fn();
