@@ -2068,6 +2068,7 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
       p.seg_choice = 0;
       if (room && last_error_code_only() == kOk && !ensure_segments(p, S_auto, st)) {
         (void)hipGetLastError();
+        tune_log("m %d nnz %d: slab_segments: the run lists could not be built (%s), row-block-plus stays", p.A.m, p.A.nnz, last_error_string());
         clear_error();
         p.free_segments();
       }
@@ -2478,10 +2479,10 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     if (last_error_code_only() == kOk && !t_capturing && !ensure_segments(*p, S, st)) {
       // (no room for the lists or their S x (m + 1) build temporaries: the passes are an optimisation, the strategy's own kernel runs)
       (void)hipGetLastError();
+      tune_log("m %d nnz %d: slab_segments: the run lists could not be built (%s), ordinary path", m, p->A.nnz, last_error_string());
       clear_error();
       p->free_segments();
       p->seg_state = 0; // (not tried again for this plan)
-      tune_log("m %d nnz %d: slab_segments: the run lists could not be built, ordinary path", m, p->A.nnz);
     }
     if (p->seg_state == 1 && p->seg_slabs == S) {
       run_segments(st, *p, alpha, beta, dx, dy);

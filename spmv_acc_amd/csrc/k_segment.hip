@@ -50,12 +50,13 @@ __global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__re
                                                                  int S, int *__restrict__ cnt, int *__restrict__ beg,
                                                                  int *__restrict__ not_monotone) {
   const int lane = threadIdx.x & (kWave - 1);
-  // ONE wavefront per row, no grid stride: a stride of 2^16 wavefronts gave wavefront 0 the rows k * 2^16 -- on R-MAT (a row's length falls
-  // with the number of set bits in its index) all hubs, 6.6 M non-zeros walked by one wavefront: 96 ms for the kernel, the hub row alone is 9
-  const long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave;
-  if (row < m) {
+  // One wavefront per row; beyond kMaxGridBlocks * 4 rows the wavefronts stride over the rows -- by a PRIME number of workgroups: a stride of 2^16
+  // wavefronts gave wavefront 0 the rows k * 2^16, on R-MAT (a row's length falls with the number of set bits in its index) all hubs, 6.6 M
+  // non-zeros walked by one wavefront: 96 ms for the kernel, where the longest row alone takes 9
+  for (long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave; row < m;
+       row += static_cast<long long>(gridDim.x) * (kThreads / kWave)) {
     const int j0 = rp[row], j1 = rp[row + 1];
-    if (j1 - j0 <= kSegShortRow) return; // (wave-uniform: short rows are counted 64 to a wavefront by segment_count_short_kernel)
+    if (j1 - j0 <= kSegShortRow) continue; // (wave-uniform: short rows are counted 64 to a wavefront by segment_count_short_kernel)
     int acc = 0;
     int prev_last = 0; // slab of the last non-zero of the previous step
     bool bad = false;
@@ -292,7 +293,8 @@ __global__ __launch_bounds__(kThreads) void segment_merge_kernel(int entries, co
 
 void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone) {
   if (A.m <= 0) return;
-  const long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row
+  long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row ...
+  if (blocks > kMaxGridBlocks) blocks = kMaxGridBlocks;                                               // ... up to what a launch holds
   hipLaunchKernelGGL(segment_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S, cnt,
                      beg, not_monotone);
   const long long short_blocks = (static_cast<long long>(A.m) + 1 + kThreads - 1) / kThreads; // m + 1: the closing zeros

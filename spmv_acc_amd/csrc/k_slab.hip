@@ -29,8 +29,8 @@ __global__ __launch_bounds__(kThreads) void slab_count_kernel(const int *__restr
   const int lane = threadIdx.x & (kWave - 1);
   // (one wavefront per row, no grid stride: a stride of 2^16 wavefronts hands wavefront 0 the rows k * 2^16, which on R-MAT are all hubs --
   // 82 ms for this kernel and 106 for the scatter where the longest row alone takes 9; see k_segment.hip)
-  const long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave;
-  if (row < m) {
+  for (long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave; row < m;
+       row += static_cast<long long>(gridDim.x) * (kThreads / kWave)) { // (the stride: kMaxGridBlocks, a prime, and only beyond 33.5 M rows)
     const int j0 = rp[row], j1 = rp[row + 1];
     int acc = 0;
     for (int base = j0; base < j1; base += kWave) {
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(kThreads) void slab_scatter_kernel(const int *__res
                                                                 const int *__restrict__ rps, const long long *__restrict__ off,
                                                                 int *__restrict__ ci_out, double *__restrict__ v_out, int values_only) {
   const int lane = threadIdx.x & (kWave - 1);
-  const long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave; // one wavefront per row
-  if (row < m) {
+  for (long long row = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave; row < m;
+       row += static_cast<long long>(gridDim.x) * (kThreads / kWave)) { // one wavefront per row, striding beyond kMaxGridBlocks workgroups
     const int j0 = rp[row], j1 = rp[row + 1];
     long long pos = 0; // lane s: where slab s's next non-zero of this row goes
     if (lane < S) pos = off[lane] + rps[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row];
@@ -127,14 +127,16 @@ void launch_slab_merge(hipStream_t stream, int ms, const int *rowid, const doubl
 
 void launch_slab_count(hipStream_t stream, const CsrDev &A, int width, int S, int *cnt) {
   if (A.m <= 0) return;
-  const long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row
+  long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row ...
+  if (blocks > kMaxGridBlocks) blocks = kMaxGridBlocks;                                               // ... up to what a launch holds
   hipLaunchKernelGGL(slab_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, width, S, cnt);
 }
 
 void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, const int *rps, const long long *off, int *ci_out,
                          double *v_out, bool values_only) {
   if (A.m <= 0) return;
-  const long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave);
+  long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave);
+  if (blocks > kMaxGridBlocks) blocks = kMaxGridBlocks;
   hipLaunchKernelGGL(slab_scatter_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.v, A.m, width, S,
                      rps, off, ci_out, v_out, values_only ? 1 : 0);
 }

@@ -192,8 +192,10 @@ __global__ __launch_bounds__(kThreads) void wave_row_kernel(int m, int nnz, doub
                                                             const int *__restrict__ guard, int *__restrict__ stale) {
   check_plan_guard(rp, m, guard, stale);
   const int lane = threadIdx.x & (kWave - 1);
-  const long long row_ll = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave;
-  const bool live = row_ll < m; // wave-uniform
+  // (one wavefront per row; beyond kMaxGridBlocks * 4 rows -- 33.5 M -- the wavefronts stride over the rows)
+  for (long long row_ll = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave; row_ll < m;
+       row_ll += static_cast<long long>(gridDim.x) * (kThreads / kWave)) {
+  const bool live = true; // wave-uniform
   const int row = static_cast<int>(row_ll);
   double s = 0.0;
   if (live) {
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(kThreads) void wave_row_kernel(int m, int nnz, doub
   }
   s = group_sum<64>(s);
   if (live && lane == 0) store_y(y, yin, row, alpha, beta, s);
+  }
 }
 
 // the stale-plan guard's samples: rowptr[k * m / 63], k = 0 .. 63 (same indices as device_utils.hpp::check_plan_guard)
@@ -314,6 +317,12 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
   // rows per lane group: 1 when rows outgrow the hoisted steps, or when the caller knows the row lengths are very uneven
   // (four hub rows of a power-law matrix in one group would run one after the other)
   const int rows = (single_row_groups || avg > 2LL * wide) ? 1 : 4;
+  // (a forced width on a matrix of very many short rows would need more workgroups than a launch holds: narrower lane groups then)
+  while ((static_cast<long long>(A.m) + rows * (kThreads / (w0 > w1 ? w0 : w1)) - 1) / (rows * (kThreads / (w0 > w1 ? w0 : w1))) + 1 > kMaxGridBlocks &&
+         (w0 > 1 || w1 > 1)) {
+    if (w0 > 1) w0 >>= 1;
+    if (w1 > 1) w1 >>= 1;
+  }
   const int nb0 = ceil_div_ll(row_split, rows * (kThreads / w0));
   const int nb1 = ceil_div_ll(A.m - row_split, rows * (kThreads / w1));
   if (nb0 + nb1 == 0) return;
@@ -356,7 +365,8 @@ void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int 
 
 void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y) {
   if (A.m <= 0) return;
-  const int grid = ceil_div_ll(A.m, kThreads / kWave);
+  int grid = ceil_div_ll(A.m, kThreads / kWave);
+  if (grid > kMaxGridBlocks) grid = kMaxGridBlocks;
   hipLaunchKernelGGL(wave_row_kernel, dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci, A.v,
                      x, y, A.yin ? A.yin : y, A.guard, A.stale);
 }

@@ -66,6 +66,10 @@ constexpr int kStreamPolicyValueDefault = 3; // colindex non-temporal, values de
 
 // ---- tile geometry (fixed at build time) -----------------------------------------------------------
 constexpr int kThreads = 256;             // 4 waves per workgroup
+// HIP launches hold fewer than 2^32 work-items: a grid of 2^24 or more 256-thread workgroups WRAPS (measured on this stack: 70 M rows at one
+// wavefront per row = 17.5 M workgroups ran the first 2.9 M rows and reported nothing).  Kernels whose grid grows with m alone stride over a capped,
+// prime number of workgroups (prime: a power-of-two stride gives one wavefront all the hub rows of an R-MAT matrix, k_segment.hip).
+constexpr int kMaxGridBlocks = 8388593;
 constexpr int kNnzPerThread = 8;          // two 4-wide steps per lane per round
 constexpr int kTile = kThreads * kNnzPerThread; // 2048 products = 16 KB of LDS per workgroup
 constexpr int kPlusThreads = 256;         // row-block-plus ANALYSIS geometry: the reference's (THREADS 256, R 2,

@@ -1111,7 +1111,8 @@ def test_billion_rows(torch_dev):
     probe = torch.tensor([0, 1, 12345, m // 2 - 1, m // 2 + 1, m - 2, m - 1], dtype=torch.int64, device="cuda")
     big = torch.arange(m // 2, m // 2 + extra + 1, dtype=torch.int64, device="cuda")
     want_big = 2.0 * float(x[(big * 7919) % n].sum().item()) + 1.0
-    for strat in ("adaptive", "line_enhance", "flat", "adaptive_plus", "vector_row"):
+    # (wf_row: one wavefront per row -- far more wavefronts than one launch holds, see the test below)
+    for strat in ("adaptive", "line_enhance", "flat", "adaptive_plus", "vector_row", "wf_row", "thread_row"):
         y = torch.ones(m, dtype=torch.float64, device="cuda")
         spmv_acc_amd.csr_spmv(2.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
         torch.cuda.synchronize()
@@ -1128,6 +1129,52 @@ def test_billion_rows(torch_dev):
             del rows, ok
         del y
     spmv_acc_amd.release_plans(rp)
+
+
+def test_more_rows_than_a_launch_holds_wavefronts(torch_dev, hiplib):
+    """70 M rows: at one wavefront per row a grid would be 17.5 M workgroups = 2^32.06 work-items, and a HIP launch of 2^32 or more
+    work-items WRAPS on this stack (the first 2.9 M rows were computed, nothing was reported: KERNEL_STRATEGY WF_ROW returned a wrong y
+    from round 1 on, found in round 3 by tools/many_rows_probe.py).  Every kernel whose grid grows with m alone now strides over a capped
+    number of workgroups: wf_row, the direct vector-row form under a forced width, LIGHT, and the plan-time builds of both column-slab
+    forms, against an independent device evaluation on every row."""
+    torch = torch_dev
+    m = n = 70_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    lens = (torch.rand(m, generator=g, device="cuda") < 0.05).long() * torch.randint(1, 6, (m,), generator=g, device="cuda")
+    lens[12345] = 3000  # (longer rows only slow the checker down: its index_add serialises on one address)
+    lens[m - 3] = 70
+    rp = torch.zeros(m + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(lens, 0, out=rp[1:])
+    nnz = int(rp[-1].item())
+    rows = torch.repeat_interleave(torch.arange(m, device="cuda"), lens, output_size=nnz)
+    ci = torch.randint(0, n, (nnz,), generator=g, device="cuda")
+    ci = (torch.sort(rows * n + ci).values % n).to(torch.int32)  # ascending inside the rows: the run lists apply
+    rp = rp.to(torch.int32)
+    v = torch.rand(nnz, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    x = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    y0 = torch.rand(m, generator=g, device="cuda", dtype=torch.float64)
+    prod = v * x[ci.long()]
+    ref = y0.clone().index_add_(0, rows, prod)
+    scale = y0.abs().index_add_(0, rows, prod.abs()) + 1e-300
+    del prod, rows, lens
+    try:
+        for strat, knobs in (("wf_row", {}), ("light", {}), ("vector_row", {"vector_tile": 0, "vector_width": 64}),
+                             ("line_enhance", {"slab_segments": 4}), ("adaptive", {"col_slabs": 2})):
+            hiplib.spmv_acc_reset_tunables()
+            for k, val in knobs.items():
+                assert hiplib.spmv_acc_set_tunable(k.encode(), val) == 0
+            y = y0.clone()
+            spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
+            torch.cuda.synchronize()
+            assert float(((y - ref).abs() / scale).max().item()) <= SCALED_TOL, (strat, knobs)
+            if "slab_segments" in knobs:
+                assert spmv_acc_amd.query_plan(rp, m)["slab_passes"] == 4
+            spmv_acc_amd.release_plans(rp)
+            del y
+    finally:
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans()
 
 
 def test_against_rocsparse_as_second_opinion(torch_dev):
