@@ -1296,6 +1296,29 @@ void tune_log(const char *fmt, ...) {
 // Shared by the per-matrix timings below: average milliseconds of fn() in the cache state fn itself leaves behind.  The
 // first launch is timed alone and sizes the rest, so tuning a matrix whose SpMV takes milliseconds costs 2 launches per
 // candidate, not 8: under 0.1 ms per launch 2 more warm-ups + 5 timed, under 0.5 ms 1 + 3, under 2 ms 1 + 2, else the one warm-up + 1 timed.
+// ONE scratch y per run_spmv call, shared by every timing phase of that call (cache policy, block sizes, hints, adaptive's families, the
+// slab passes): each phase used to hipMalloc / hipFree its own -- a device synchronisation apiece, and seconds apiece at 2 G rows (17 GB).
+// The phases nest (adaptive's family timing calls the families' own timings): the content is never read, only written and reset.
+thread_local double *t_scratch = nullptr;
+thread_local size_t t_scratch_len = 0;
+double *tune_scratch(size_t len) {
+  if (t_scratch && t_scratch_len >= len) return t_scratch;
+  if (t_scratch) (void)hipFree(t_scratch);
+  t_scratch = nullptr;
+  t_scratch_len = 0;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&t_scratch), sizeof(double) * (len ? len : 1)), "hipMalloc tune y")) {
+    t_scratch = nullptr;
+    return nullptr;
+  }
+  t_scratch_len = len;
+  return t_scratch;
+}
+void release_tune_scratch() {
+  if (t_scratch) (void)hipFree(t_scratch);
+  t_scratch = nullptr;
+  t_scratch_len = 0;
+}
+
 struct TuneTimer {
   static constexpr int kMaxTimed = 5;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1388,8 +1411,7 @@ template <typename Launch> bool autotune_policy(Plan &p, int fam, hipStream_t st
   }
   ++t_plan_work;
   double *scratch = nullptr;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
-    return false;
+  if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
   TuneTimer timer;
   timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
   // (zeroed: in the beta != 0 class the trial launches accumulate into it)
@@ -1408,7 +1430,6 @@ template <typename Launch> bool autotune_policy(Plan &p, int fam, hipStream_t st
       best_policy = candidates[c];
     }
   }
-  (void)hipFree(scratch);
   if (ok) tune_log("m %d nnz %d family %d: keeps stream policy %d", p.A.m, p.A.nnz, fam, best_policy);
   if (ok) p.stream_policy[fam][cls] = best_policy;
   return ok;
@@ -1511,8 +1532,7 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
   }
   ++t_plan_work;
   double *scratch = nullptr;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
-    return false;
+  if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
   TuneTimer timer;
   timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
   bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
@@ -1521,7 +1541,6 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
     F.needs_fixup = mode == 0;
     ok = timer.time(st, [&] { launch_flat_with(st, p, policy_for(p, kFamFlat), 1.0, trial_beta(), x, scratch); }, &ms[mode]);
   }
-  (void)hipFree(scratch);
   F.tuned_fixup[cls] = F.needs_fixup = !(ok && ms[1] < ms[0]);
   F.mode_tuned[cls] = ok;
   if (ok) p.flat_mode_choice[cls] = F.tuned_fixup[cls] ? 1 : 0;
@@ -1542,8 +1561,7 @@ bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
   if (!time_npt && !time_early) return true; // pinned (A/B runs)
   ++t_plan_work;
   double *scratch = nullptr;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
-    return false;
+  if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
   TuneTimer timer;
   timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
   bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
@@ -1577,7 +1595,6 @@ bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
       }
     }
   }
-  (void)hipFree(scratch);
   if (ok) {
     if (best_plan == 1) {
       Plan::free_flat_plan(p.flat);
@@ -1706,7 +1723,7 @@ template <class Launch> bool autotune_hint(Plan &p, int fam, hipStream_t st, Lau
   if (p.hint_use[fam] < 0) {
     ++t_plan_work;
     double *scratch = nullptr;
-    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y")) return false;
+    if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
     TuneTimer timer;
     timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
     bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
@@ -1715,7 +1732,6 @@ template <class Launch> bool autotune_hint(Plan &p, int fam, hipStream_t st, Lau
       p.A.cold = h ? p.d_cold : nullptr;
       ok = timer.time(st, [&] { launch(scratch); }, &ms[h]);
     }
-    (void)hipFree(scratch);
     p.A.cold = nullptr;
     if (!ok) return false;
     p.hint_use[fam] = ms[1] < 0.98f * ms[0] ? 1 : 0;
@@ -1772,7 +1788,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
       if (p.rowblock_ok == 1) {
         ++t_plan_work;
         double *scratch = nullptr;
-        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y")) return false;
+        if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
         TuneTimer timer;
         timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
         bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
@@ -1780,7 +1796,6 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
         ok = ok && run_rowblock(st, p, nullptr, 1.0, trial_beta(), x, scratch, false); // (builds and tunes the row-block side)
         ok = ok && timer.time(st, [&] { launch_flat_with(st, p, policy_for(p, kFamFlat), 1.0, trial_beta(), x, scratch); }, &ms_flat);
         ok = ok && timer.time(st, [&] { (void)run_rowblock(st, p, nullptr, 1.0, trial_beta(), x, scratch, false); }, &ms_rb);
-        (void)hipFree(scratch);
         if (!ok) return false;
         p.flat_rowblock_choice = ms_rb < 0.97f * ms_flat ? 1 : 0;
         tune_log("m %d nnz %d flat on a small grid: tile kernel %.2f us, row blocks %.2f us -> %s", p.A.m, p.A.nnz, ms_flat * 1e3f, ms_rb * 1e3f,
@@ -2000,8 +2015,7 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
   // first call on this matrix: cache policy on the middle candidate, then the three block sizes under that policy
   if (!ensure_plus(p, h_rowptr, st, 1536) || !autotune_policy(p, kFamPlus, st, launch)) return false;
   double *scratch = nullptr;
-  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
-    return false;
+  if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
   TuneTimer timer;
   timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
   bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
@@ -2019,7 +2033,6 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
       best_min = candidates[c];
     }
   }
-  (void)hipFree(scratch);
   if (!ok) return false;
   p.plus_tuned_min = best_min;
   return ensure_plus(p, h_rowptr, st, best_min);
@@ -2075,7 +2088,7 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
       if (p.seg_state == 1) {
         ++t_plan_work;
         double *scratch = nullptr;
-        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y")) return false;
+        if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
         TuneTimer timer;
         timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
         bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
@@ -2085,7 +2098,6 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
         ok = ok && timer.time(st, [&] { launch_here(1.0, trial_beta(), scratch); }, &ms[0]) &&
              timer.time(st, [&] { run_segments(st, p, 1.0, trial_beta(), x, scratch); }, &ms[1]);
         p.A.yin = keep_yin;
-        (void)hipFree(scratch);
         if (!ok) return false;
         p.seg_choice = ms[1] < 0.95f * ms[0] ? 1 : 0;
         tune_log("m %d nnz %d beta class %d: row-block-plus %.2f us, %d column-slab passes over run lists %.2f us -> %s", p.A.m, p.A.nnz,
@@ -2135,8 +2147,7 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
   if (p.adaptive_family[cls] < 0) {
     ++t_plan_work;
     double *scratch = nullptr;
-    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double) * static_cast<size_t>(p.A.m)), "hipMalloc tune y"))
-      return false;
+    if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
     TuneTimer timer;
     timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
     bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
@@ -2170,7 +2181,6 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
       if (ms[f] < (best_family == 0 ? 0.97f * ms[0] : ms[best_family])) best_family = f;
     tune_log("m %d nnz %d adaptive (beta %s 0): fixed row blocks %.2f us, row-block-plus %.2f us, flat %.2f us -> family %d", p.A.m, p.A.nnz,
              beta != 0.0 ? "!=" : "==", ms[0] * 1e3f, ms[1] * 1e3f, ms[2] * 1e3f, best_family);
-    (void)hipFree(scratch);
     if (!ok) return false;
     p.adaptive_family[cls] = best_family;
   }
@@ -2435,6 +2445,13 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   const std::shared_ptr<Plan> p = get_plan(m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value);
   if (!p) return;
   t_last_plan = p;
+  // the timing phases of this call share one scratch y (tune_scratch); it goes when the outermost call returns
+  struct ScratchScope {
+    bool outer;
+    ~ScratchScope() {
+      if (outer) release_tune_scratch();
+    }
+  } scratch_scope{!t_in_slab};
   // one call at a time per matrix: plan fields, the per-matrix timings and the carry buffers of flat / row-block-plus belong
   // to the plan (two host threads on DIFFERENT matrices do not meet here; this lock is never held together with g_mu)
   std::lock_guard<std::mutex> plan_lock(p->mu);
