@@ -519,6 +519,7 @@ struct Plan {
   int device = 0;
   PlanKey key;                     // where the plan sits in g_plans
   hipStream_t last_stream = nullptr; // stream of the plan's latest launches (a plan may be used from several streams in turn)
+  hipEvent_t order_event = nullptr;  // orders a call on another stream behind the plan's previous launches (run_spmv)
   bool launched = false;           // some kernel carrying this plan's guard slot has been enqueued
   unsigned long long last_use = 0; // plan-cache clock at the last call that used this plan
   std::mutex mu;                   // held by run_spmv for the whole call: plan fields, carry buffers and tunings are per matrix
@@ -637,6 +638,8 @@ struct Plan {
     seg_slabs = 0;
   }
   void free_device() {
+    if (order_event) (void)hipEventDestroy(order_event);
+    order_event = nullptr;
     free_slabs();
     free_segments();
     if (d_light_counter) (void)hipFree(d_light_counter);
@@ -2470,6 +2473,14 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   } prepare_clock{t_plan_work, std::chrono::steady_clock::now()};
   if (p->calls++ == 0) ++t_plan_work; // the plan itself (nnz / guard samples) was just made by get_plan
   (void)hipGetLastError(); // errors of earlier, unrelated HIP calls of this thread are not this call's
+  // A plan owns scratch that its kernels write (flat's carries, row-block-plus partials, the slab passes' partial sums, LIGHT's counter):
+  // two SpMVs of one matrix in flight on DIFFERENT streams would share it.  The lock above orders the enqueueing, this orders the execution:
+  // a call on another stream than the plan's last one waits for that one's work (an event behind its last launch).  Same stream: nothing.
+  if (p->launched && p->last_stream != st && !t_capturing && !t_in_slab) {
+    if (!p->order_event && hipEventCreateWithFlags(&p->order_event, hipEventDisableTiming) != hipSuccess) p->order_event = nullptr;
+    if (p->order_event && hipEventRecord(p->order_event, p->last_stream) == hipSuccess) (void)hipStreamWaitEvent(st, p->order_event, 0);
+    (void)hipGetLastError(); // (the other stream may have been destroyed by its owner: its work is then complete)
+  }
   p->last_stream = st;
   p->launched = true;
   // where this call's kernels read the old y (kernels.hpp CsrDev::yin); the plan's lock is held until the launches are enqueued

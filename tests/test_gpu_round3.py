@@ -266,6 +266,57 @@ def test_capture_of_an_unprepared_strategy_is_refused_not_broken(torch_dev, orac
         spmv_acc_amd.release_plans(drp)
 
 
+def test_one_matrix_on_two_streams_is_ordered(torch_dev, oracle, hiplib):
+    """A plan owns scratch its kernels write (flat's carries, row-block-plus partials, the slab passes' partial sums, LIGHT's counter).  Two
+    SpMVs of ONE matrix enqueued on two different streams would share it while both run; the engine orders them (the call on the other
+    stream waits for an event behind the plan's previous launches).  Many alternating launches on two streams, different x and y per
+    stream, no synchronisation in between: every result is right."""
+    torch = torch_dev
+    m, n = 30000, 30000
+    rowptr, cols, vals = synth.random_csr(m, n, 40, seed=91, kind="uniform")
+    lens = np.diff(rowptr).astype(np.int64)
+    lens[[5, m // 2]] = (9000, 4100)  # rows cut across many tiles / sliced over row blocks
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(17)
+    cols = np.sort(rng.integers(0, n, nnz).astype(np.int32).reshape(-1))  # (sorted globally is sorted per row too: the run lists apply)
+    cols = np.concatenate([np.sort(cols[rowptr[i]:rowptr[i + 1]]) for i in range(m)]).astype(np.int32)
+    vals = rng.standard_normal(nnz)
+    xs = [rng.standard_normal(n) for _ in range(2)]
+    y0 = rng.standard_normal(m)
+    drp, dci, dv = (dev(torch, a) for a in (rowptr, cols, vals))
+    dxs = [dev(torch, x) for x in xs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    refs = [oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0) for x in xs]
+    try:
+        for strat, knobs in (("flat", {"flat_finish": 0}), ("adaptive_plus", {}), ("light", {}), ("line_enhance", {"slab_segments": 4})):
+            hiplib.spmv_acc_reset_tunables()
+            for k, val in knobs.items():
+                hiplib.spmv_acc_set_tunable(k.encode(), val)
+            warm = dev(torch, y0)
+            spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dxs[0], warm, strategy=strat)  # plan + timings on the NULL stream
+            torch.cuda.synchronize()
+            ys = [[dev(torch, y0) for _ in range(12)] for _ in range(2)]
+            sid = spmv_acc_amd.strategy_id(strat)
+            for k in range(12):
+                for s in (0, 1):
+                    hiplib.spmv_acc_set_stream(streams[s].cuda_stream)
+                    hiplib.spmv_acc_csr_spmv_strategy(sid, 0, 1.0, 1.0, m, n, nnz, None, drp.data_ptr(), dci.data_ptr(), dv.data_ptr(),
+                                                      dxs[s].data_ptr(), ys[s][k].data_ptr())
+            torch.cuda.synchronize()
+            assert hiplib.spmv_acc_last_error() == 0, hiplib.spmv_acc_last_error_string()
+            for s in (0, 1):
+                for k in range(12):
+                    err = oracle.scaled_error(ys[s][k].cpu().numpy(), refs[s], 1.0, 1.0, rowptr, cols, vals, xs[s], y0)
+                    assert err <= SCALED_TOL, (strat, s, k, err)
+            spmv_acc_amd.release_plans(drp)
+    finally:
+        hiplib.spmv_acc_set_stream(None)
+        hiplib.spmv_acc_reset_tunables()
+        hiplib.spmv_acc_clear_error()
+        spmv_acc_amd.release_plans()
+
+
 # ---- stale-plan attribution (ADVICE round 2) ----------------------------------------------------------------------------------
 def test_stale_plan_is_reported_to_the_thread_that_used_it(torch_dev, hiplib):
     """spmv_acc_last_error() asks the plan the CALLING thread used last and nothing else: a plan made stale by thread A is not
