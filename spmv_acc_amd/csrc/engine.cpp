@@ -1630,7 +1630,8 @@ bool ensure_hint(Plan &p, hipStream_t st) {
   ++t_plan_work;
   const auto census_t0 = std::chrono::steady_clock::now();
   const int nlines = (A.n + (1 << kHintLineShift) - 1) >> kHintLineShift;
-  const int stride = (A.nnz + kHintSamples - 1) / kHintSamples;
+  // (odd: an even stride on rows of one even length would sample the same position of every row -- with sorted rows always low columns)
+  const int stride = ((A.nnz + kHintSamples - 1) / kHintSamples) | 1;
   const int samples = (A.nnz + stride - 1) / stride;
   unsigned *counts = nullptr, *hist_lines = nullptr;
   unsigned long long *hist_hits = nullptr;
