@@ -194,8 +194,9 @@ def test_bitwise_reproducible(torch_dev, hiplib):
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), strat
     spmv_acc_amd.release_plans(drp)
     try:
-        for k, val in (("adaptive_timed", 0), ("stream_plain", 0), ("flat_finish", 0), ("plus_min_nnz", 1024)):
-            assert hiplib.spmv_acc_set_tunable(k.encode(), val) == 0
+        # ONE switch pins every timed choice (round 3; rounds 1-2 pinned four tunables by hand, which no longer covers them all: flat's
+        # small-grid choice between its tile kernel and the row blocks is timed too, and two fresh plans can fall differently)
+        assert hiplib.spmv_acc_set_tunable(b"deterministic", 1) == 0
         for strat in ALL:
             a = run(torch, strat, 1.0, 1.0, rowptr, cols, vals, x, y0)  # run() releases the plan: b is computed on a new one
             b = run(torch, strat, 1.0, 1.0, rowptr, cols, vals, x, y0)
@@ -1031,8 +1032,14 @@ def test_long_spans_among_short_rows(torch_dev, oracle, hiplib):
             hiplib.spmv_acc_reset_tunables()
         err = oracle.scaled_error(got, ref, -0.5, 2.0, rowptr, cols, vals, x, y0)
         assert err <= SCALED_TOL, (strat, knobs, err)
-        if not knobs and strat != "adaptive":  # (a fresh adaptive plan may settle on another family: same result to rounding only)
-            assert np.array_equal(got, run(torch, strat, -0.5, 2.0, rowptr, cols, vals, x, y0)), (strat, "not reproducible")
+        if not knobs:  # two FRESH plans with every timed choice pinned (the timed ones may fall differently: same result to rounding only)
+            try:
+                hiplib.spmv_acc_set_tunable(b"deterministic", 1)
+                a = run(torch, strat, -0.5, 2.0, rowptr, cols, vals, x, y0)
+                b = run(torch, strat, -0.5, 2.0, rowptr, cols, vals, x, y0)
+            finally:
+                hiplib.spmv_acc_reset_tunables()
+            assert np.array_equal(a, b), (strat, "not reproducible")
 
 
 def test_plan_cache_is_lru_bounded(torch_dev, hiplib):
