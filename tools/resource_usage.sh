@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-kernel register / LDS / occupancy table from hipcc's -Rpass-analysis=kernel-resource-usage.
 cd "$(dirname "$0")/../spmv_acc_amd/csrc"
-for f in k_vector_row k_rowblock k_flat k_plus; do
+for f in k_vector_row k_rowblock k_flat k_plus k_segment k_slab k_legacy k_guard k_col16 k_hint k_analyze; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I../../include -c $f.hip -o /tmp/$f.ru.o \
     -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|AGPRs|ScratchSize|Occupancy|LDS Size|SGPRs:" |
     sed -E 's/.*remark: //; s/ \[-Rpass.*//' | awk '/Function Name/{if(line)print line; line=$0; next}{line=line" | "$0}END{print line}' |
