@@ -15,8 +15,8 @@
 // they touch (short rows of a power-law matrix lie mostly inside one slab, which is what keeps that affordable), and every
 // run is one more read-modify-write of a y element (the copy form pays the same for its compact slabs).
 //
-// Build: one wavefront per row counts the row's non-zeros per slab (ballots, as k_slab.hip) and checks that the slab index never
-// decreases along the row; lane s then knows where slab s's run starts (exclusive prefix over the lanes).  Runs longer than
+// Build: a row's non-zeros are counted per slab -- rows of more than 32 by one wavefront each (ballots, as k_slab.hip), shorter ones by one LANE
+// each -- and the slab index is checked never to decrease along the row; the exclusive prefix of the counts is where each slab's run starts.  Runs longer than
 // kSegPiece are cut into pieces (entries of their own); pieces -> scan -> compact as in k_slab.hip; the entries' lengths are
 // scanned into `vptr` (an entry's place in the pass's VIRTUAL non-zero order: the runs laid end to end), and the pass is cut into
 // workgroups by cost (max(length, 4) per entry, kSegCost per workgroup: at most 2047 products and 511 entries each).
@@ -24,10 +24,11 @@
 // stages as ONE 2048-product LDS tile exactly like the other tile kernels -- lane t takes virtual non-zeros t, t + 256, ..., so
 // a wavefront's loads are as coalesced as the runs are long -- after finding every element's entry: each entry marks its first
 // element in a 2-byte owner map, a max-scan over the map fills the rest, address = run start + offset in the run.  Then w lanes
-// per entry sum its span of the tile (tile_row_sum, long spans to whole waves), ys[e] = alpha * sum.  (The first form, w lanes
+// per entry sum its span of the tile (tile_row_sum, long spans to whole waves); a whole run adds alpha * sum straight into y, a piece
+// of a cut run writes it to ys[e].  (The first form, w lanes
 // walking each run straight from global memory, ran R-MAT 25 in 6.8-10 ms against 7.1 for the default path: runs are power-law
-// long, every wavefront waits for its longest, and cutting them shorter only added entries.)  Merge: the first entry of every
-// row-run adds the run's partial sums to y in entry order (pieces of one long segment are consecutive entries: deterministic, no atomics).
+// long, every wavefront waits for its longest, and cutting them shorter only added entries.)  Merge (slabs that hold cut runs only): the first
+// piece of a run adds the run's partial sums to y in entry order (the pieces are consecutive entries: deterministic, no atomics).
 #include "device_utils.hpp"
 #include "kernels.hpp"
 #include "tile_stage.hpp"
