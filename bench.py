@@ -19,6 +19,9 @@ roofline    = algorithmic bytes (12*nnz + 4*(m+1) + 8*n + 16*m) / 
               one hipEvent pair per launch on the stream the kernels run on, median.  The back-to-back mean (one event pair
               around K launches, no reset: what a solver loop sees) is reported beside it, never instead of it.
 cpu_baseline= the oracle (CPU restatement of cli/verification.cpp:56-66) on the host cores, same matrix.
+
+N = 1, default: the extra legs (configs[2] sweep, configs[3] R-MAT 25, configs[4] banded shard) are measured in one CHILD process per matrix, as the
+reference's batch runs its CLI once per matrix file (examples/large-data-set-batch.sh); `--legs-in-process` keeps them here.
 """
 import argparse
 import json
@@ -54,6 +57,10 @@ def parse():
                         "ghost (square workloads, i.e. --workload banded): x is partitioned like the rows and each rank receives "
                         "only the entries its columns reference (x <- alpha*A*x iteration, beta = 0)")
     p.add_argument("--no-overlap", action="store_true", help="N>1: wait for each allgather before the next SpMV")
+    p.add_argument("--legs-in-process", action="store_true",
+                   help="N = 1: measure the extra legs inside this process instead of one child process per matrix (e.g. to see their kernels "
+                        "in one rocprofv3 trace)")
+    p.add_argument("--leg-child", default=None, help=argparse.SUPPRESS)  # internal: measure ONE leg and print its JSON (see extra_legs)
     return p.parse_args()
 
 
@@ -191,46 +198,162 @@ def timed_leg(torch, strat, A, x, y0, iters, warm=10, beta=1.0, cols_touched=Non
             "plan": [info.get(k, -1) for k in ("stream_policy", "adaptive_family", "flat_fixup")]}
 
 
-def extra_legs(torch, device, headline):
-    """BASELINE configs[2..4] measured live in the same run (rank 0, N = 1): the 12-matrix sweep under flat (the strategy
-    BASELINE names) and adaptive, R-MAT scale 25 under line_enhance, one 32 M-row banded shard.  Keys are additions to the
-    one JSON line; the headline value is untouched."""
+def _leg_vectors(torch, device, m, n):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234)
+    return (torch.rand(n, generator=gen, device=device, dtype=torch.float64) * 2 - 1,
+            torch.rand(m, generator=gen, device=device, dtype=torch.float64) * 2 - 1)
+
+
+def leg_sweep(torch, device, name, A=None):
+    """One stand-in of the configs[2] sweep: flat (the strategy BASELINE names), adaptive, and the opt-in 16-bit column stream."""
     import spmv_acc_amd
     from spmv_acc_amd import synth
 
-    def vectors(m, n):
-        gen = torch.Generator(device=device)
-        gen.manual_seed(1234)
-        return (torch.rand(n, generator=gen, device=device, dtype=torch.float64) * 2 - 1,
-                torch.rand(m, generator=gen, device=device, dtype=torch.float64) * 2 - 1)
+    if A is None:
+        A = synth.sweep_standin_torch(name, device=device)
+    x, y0 = _leg_vectors(torch, device, A[0], A[1])
+    iters = 200 if A[2] < 20_000_000 else 60
+    row = {"rows": A[0], "nnz": A[2]}
+    for strat in ("flat", "adaptive"):
+        row[strat] = timed_leg(torch, strat, A, x, y0, iters)
+    # opt-in leg, never the headline: flat over the plan's 16-bit column encoding (tunable col16; the plan then holds a copy
+    # derived from colindex).  frac stays algorithmic bytes of the CSR format (12 B per non-zero) over time.
+    lib = spmv_acc_amd.load_library()
+    spmv_acc_amd.release_plans(A[3])
+    lib.spmv_acc_set_tunable(b"col16", 1)
+    try:
+        row["flat_col16_opt_in"] = timed_leg(torch, "flat", A, x, y0, iters)
+    finally:
+        lib.spmv_acc_set_tunable(b"col16", 0)
+    spmv_acc_amd.release_plans(A[3])
+    return row
+
+
+def leg_rmat25(torch, device):
+    """BASELINE configs[3]: R-MAT scale 25 under line_enhance -- the default path, the one-kernel path it is timed against, the opt-in slab-major copy."""
+    import spmv_acc_amd
+    from spmv_acc_amd import synth
+
+    A = synth.rmat_torch(25, device=device, seed=0xC4)
+    x, y0 = _leg_vectors(torch, device, A[0], A[1])
+    out = {"workload": "R-MAT scale 25, edge factor 16 (BASELINE configs[3])", "rows": A[0], "nnz": A[2],
+           "line_enhance": timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)}
+    info = spmv_acc_amd.query_plan(A[3], A[0]) or {}
+    out["path"] = ("column-slab passes over run lists, no copy of the matrix (k_segment.hip; timed against the row-block-plus "
+                   "kernel at plan time)" if info.get("slab_passes") else "row-block-plus kernel")
+    spmv_acc_amd.release_plans(A[3])
+    # the same strategy with the slab passes switched off: the one-kernel path of rounds 1-2 (gather hints), for comparison
+    lib = spmv_acc_amd.load_library()
+    lib.spmv_acc_set_tunable(b"slab_segments", 0)
+    try:
+        out["line_enhance_without_slab_passes"] = timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)
+    finally:
+        lib.spmv_acc_set_tunable(b"slab_segments", -1)
+        spmv_acc_amd.release_plans(A[3])
+    # opt-in leg, never the headline of configs[3]: column-slab blocking (tunable col_slabs: the plan holds a re-ordered copy of the
+    # matrix in 8 column ranges and runs 8 consecutive SpMVs, each gathering from an eighth of x).  Same algorithmic bytes.
+    lib.spmv_acc_set_tunable(b"col_slabs", 8)
+    try:
+        out["line_enhance_col_slabs8_opt_in"] = timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)
+    finally:
+        lib.spmv_acc_set_tunable(b"col_slabs", 0)
+        spmv_acc_amd.release_plans(A[3])
+    return out
+
+
+def leg_banded_shard(torch, device):
+    """BASELINE configs[4] on one GPU: rank 3's 32 M-row shard of the 256 M-row banded matrix, beta = 0."""
+    import spmv_acc_amd
+    from spmv_acc_amd import synth
+
+    rows, total = 32_000_000, 256_000_000
+    rp, ci, v = synth.banded_torch(rows, first_row=3 * rows, total_rows=total, device=device)
+    A = (rows, total, int(rp[-1].item()), rp, ci, v)
+    x, y0 = _leg_vectors(torch, device, rows, total)
+    out = {"workload": "rank 3's 32 M-row shard of the 256 M-row banded matrix (BASELINE configs[4]), beta = 0",
+           "rows": rows, "nnz": A[2], "adaptive": timed_leg(torch, "adaptive", A, x, y0, iters=30, warm=5, beta=0.0, cols_touched=rows + 7),
+           "algorithmic_bytes_note": "x counted over the rows + 7 columns the shard references, not over all 256 M"}
+    spmv_acc_amd.release_plans(rp)
+    return out
+
+
+def leg_child(args):
+    """`python bench.py --leg-child <spec>`: ONE leg in a process of its own, its JSON on stdout (last line)."""
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)  # libraries' chatter to stderr, as in main()
+    import torch
+
+    import spmv_acc_amd
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    spmv_acc_amd.load_library()
+    spec = args.leg_child
+    if spec.startswith("sweep:"):
+        out = leg_sweep(torch, device, spec[6:])
+    elif spec == "rmat25":
+        out = leg_rmat25(torch, device)
+    elif spec == "banded_shard":
+        out = leg_banded_shard(torch, device)
+    else:
+        raise SystemExit(f"unknown leg {spec}")
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
+def run_leg_child(spec):
+    """One leg in a child process (never an exec: this process holds the GPU).  Returns the leg's dict, or None if the child failed."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.pop("SPMV_ACC_TUNE_LOG", None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg-child", spec], env=env, capture_output=True, text=True, timeout=900)
+    except Exception as ex:  # noqa: BLE001
+        print(f"[bench legs] {spec}: child did not finish ({ex!r}); measuring in this process", file=sys.stderr, flush=True)
+        return None
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        print(f"[bench legs] {spec}: child failed (exit {r.returncode}): {r.stderr[-400:]!r}; measuring in this process", file=sys.stderr, flush=True)
+        return None
+    return json.loads(lines[-1])
+
+
+def extra_legs(torch, device, headline, in_process=False):
+    """BASELINE configs[2..4] measured live in the same run (rank 0, N = 1): the 12-matrix sweep under flat (the strategy
+    BASELINE names) and adaptive, R-MAT scale 25 under line_enhance, one 32 M-row banded shard.  Keys are additions to the
+    one JSON line; the headline value is untouched.
+
+    Every matrix is measured in a CHILD PROCESS of its own, as the reference's batch does (examples/large-data-set-batch.sh runs spmv-cli once per
+    matrix file): a matrix measured in a process that already holds others lands on whatever physical pages are left, which is worth 2-4 % on the
+    65 M-non-zero stand-ins (profiles/r03_leg_spread_probe.txt: Bump_2911-sized 149 us alone, 152-156 us after the headline matrix and the earlier
+    stand-ins).  The Hardesty3 entry of the sweep is the headline's own matrix and stays here.  `--legs-in-process` measures everything here."""
+    import spmv_acc_amd
+    from spmv_acc_amd import synth
 
     def progress(msg):  # stderr: the one JSON line on stdout stays alone (and a long run is seen to be alive)
         print(f"[bench legs] {msg}", file=sys.stderr, flush=True)
 
-    out = {}
+    def leg(spec, here):
+        got = None if in_process else run_leg_child(spec)
+        if got is None:
+            got = here()
+            torch.cuda.empty_cache()
+        return got
+
+    out = {"legs_measured": "in this process" if in_process else "one child process per matrix (examples/large-data-set-batch.sh: one spmv-cli run per file)"}
     sweep = {}
     for name in synth.SWEEP_NAMES:
-        A = headline if name == "Hardesty3" else synth.sweep_standin_torch(name, device=device)
-        x, y0 = vectors(A[0], A[1])
-        iters = 200 if A[2] < 20_000_000 else 60
-        sweep[name] = {"rows": A[0], "nnz": A[2]}
-        for strat in ("flat", "adaptive"):
-            sweep[name][strat] = timed_leg(torch, strat, A, x, y0, iters)
-        # opt-in leg, never the headline: flat over the plan's 16-bit column encoding (tunable col16; the plan then holds a copy
-        # derived from colindex).  frac stays algorithmic bytes of the CSR format (12 B per non-zero) over time.
-        lib = spmv_acc_amd.load_library()
-        spmv_acc_amd.release_plans(A[3])
-        lib.spmv_acc_set_tunable(b"col16", 1)
-        try:
-            sweep[name]["flat_col16_opt_in"] = timed_leg(torch, "flat", A, x, y0, iters)
-        finally:
-            lib.spmv_acc_set_tunable(b"col16", 0)
+        if name == "Hardesty3":
+            sweep[name] = leg_sweep(torch, device, name, A=headline)
+        else:
+            sweep[name] = leg(f"sweep:{name}", lambda name=name: leg_sweep(torch, device, name))
         progress(f"sweep {name}: flat {sweep[name]['flat']['us']} us ({sweep[name]['flat']['frac']}), "
                  f"adaptive {sweep[name]['adaptive']['us']} us ({sweep[name]['adaptive']['frac']}), "
                  f"flat+col16 {sweep[name]['flat_col16_opt_in']['us']} us ({sweep[name]['flat_col16_opt_in']['frac']})")
-        spmv_acc_amd.release_plans(A[3])
-        del A, x, y0
-        torch.cuda.empty_cache()
     out["sweep"] = sweep
     out["sweep_summary"] = {
         s: {"protocol": "per-launch, y reset (benchmark/csr_spmv.hpp:66-74); *_back_to_back beside it",
@@ -240,45 +363,12 @@ def extra_legs(torch, device, headline):
             "ge_0.70_back_to_back": sum(1 for r in sweep.values() if r[s]["frac_back_to_back"] >= 0.70),
             "median_frac_back_to_back": float(np.median([r[s]["frac_back_to_back"] for r in sweep.values()]))}
         for s in ("flat", "adaptive", "flat_col16_opt_in")}
-    A = synth.rmat_torch(25, device=device, seed=0xC4)
-    x, y0 = vectors(A[0], A[1])
-    out["rmat25"] = {"workload": "R-MAT scale 25, edge factor 16 (BASELINE configs[3])", "rows": A[0], "nnz": A[2],
-                     "line_enhance": timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)}
-    info = spmv_acc_amd.query_plan(A[3], A[0]) or {}
-    out["rmat25"]["path"] = ("column-slab passes over run lists, no copy of the matrix (k_segment.hip; timed against the row-block-plus "
-                             "kernel at plan time)" if info.get("slab_passes") else "row-block-plus kernel")
+    out["rmat25"] = leg("rmat25", lambda: leg_rmat25(torch, device))
     progress(f"rmat25: {out['rmat25']['line_enhance']} ({out['rmat25']['path']})")
-    spmv_acc_amd.release_plans(A[3])
-    # the same strategy with the slab passes switched off: the one-kernel path of rounds 1-2 (gather hints), for comparison
-    lib = spmv_acc_amd.load_library()
-    lib.spmv_acc_set_tunable(b"slab_segments", 0)
-    try:
-        out["rmat25"]["line_enhance_without_slab_passes"] = timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)
-        progress(f"rmat25 without the slab passes: {out['rmat25']['line_enhance_without_slab_passes']}")
-    finally:
-        lib.spmv_acc_set_tunable(b"slab_segments", -1)
-        spmv_acc_amd.release_plans(A[3])
-    # opt-in leg, never the headline of configs[3]: column-slab blocking (tunable col_slabs: the plan holds a re-ordered copy of the
-    # matrix in 8 column ranges and runs 8 consecutive SpMVs, each gathering from an eighth of x).  Same algorithmic bytes.
-    lib = spmv_acc_amd.load_library()
-    lib.spmv_acc_set_tunable(b"col_slabs", 8)
-    try:
-        out["rmat25"]["line_enhance_col_slabs8_opt_in"] = timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)
-        progress(f"rmat25 with 8 column slabs (opt-in): {out['rmat25']['line_enhance_col_slabs8_opt_in']}")
-    finally:
-        lib.spmv_acc_set_tunable(b"col_slabs", 0)
-        spmv_acc_amd.release_plans(A[3])
-    del A, x, y0
-    torch.cuda.empty_cache()
-    rows, total = 32_000_000, 256_000_000
-    rp, ci, v = synth.banded_torch(rows, first_row=3 * rows, total_rows=total, device=device)
-    A = (rows, total, int(rp[-1].item()), rp, ci, v)
-    x, y0 = vectors(rows, total)
-    out["banded_shard"] = {"workload": "rank 3's 32 M-row shard of the 256 M-row banded matrix (BASELINE configs[4]), beta = 0",
-                           "rows": rows, "nnz": A[2], "adaptive": timed_leg(torch, "adaptive", A, x, y0, iters=30, warm=5, beta=0.0, cols_touched=rows + 7),
-                           "algorithmic_bytes_note": "x counted over the rows + 7 columns the shard references, not over all 256 M"}
+    progress(f"rmat25 without the slab passes: {out['rmat25']['line_enhance_without_slab_passes']}")
+    progress(f"rmat25 with 8 column slabs (opt-in): {out['rmat25']['line_enhance_col_slabs8_opt_in']}")
+    out["banded_shard"] = leg("banded_shard", lambda: leg_banded_shard(torch, device))
     progress(f"banded shard: {out['banded_shard']['adaptive']}")
-    spmv_acc_amd.release_plans(rp)
     return out
 
 
@@ -449,6 +539,9 @@ def main():
         self_launch(args)  # does not return
     if os.environ.get("SPMV_ACC_BENCH_DRYRUN", "0") == "1":
         dry_run(args)
+        return
+    if args.leg_child:
+        leg_child(args)
         return
     # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner with NCCL_DEBUG set, loader
     # notices): from here on file descriptor 1 is stderr, and the JSON line is written to the saved descriptor at the end.
@@ -734,7 +827,7 @@ def main():
         spmv_acc_amd.release_plans(rp2)
         del rp2, ci2, v2, y2
     if rank == 0 and world == 1 and args.workload == "hardesty3" and args.scale == 1.0 and not args.no_legs:
-        result.update(extra_legs(torch, device, (m, n, nnz, W["rp"], W["ci"], W["v"])))
+        result.update(extra_legs(torch, device, (m, n, nnz, W["rp"], W["ci"], W["v"]), in_process=args.legs_in_process))
         ceiling_frac = result["copy_ceiling_gbs"] / HBM_PEAK_GBS
         for s in ("flat", "adaptive"):
             result["sweep_summary"][s]["median_frac_of_copy_ceiling"] = round(result["sweep_summary"][s]["median_frac"] / ceiling_frac, 4)
