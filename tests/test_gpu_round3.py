@@ -618,13 +618,20 @@ nnz = int(rp[-1].item())
 gen = torch.Generator(device="cuda"); gen.manual_seed(5)
 x = torch.rand(n, generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
 out = {{}}
+# first every strategy's plan work (first call + the refinements its second call may still make), THEN the results: the strategies share one
+# plan, a later strategy's timings (flat's tile size, say) are choices an earlier strategy (adaptive running flat) also uses from then on, and
+# the second process adopts the FINAL record -- results taken in between would be compared with other choices than they were computed with
 for strat in {strategies!r}:
-    ms = spmv_acc_amd.prepare(m, n, nnz, rp, ci, v, x, strategy=strat)
+    out[strat + "__prepare_ms"] = np.array(spmv_acc_amd.prepare(m, n, nnz, rp, ci, v, x, strategy=strat))
+    for _ in range(2):
+        y = torch.ones(m, dtype=torch.float64, device="cuda")
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
+torch.cuda.synchronize()
+for strat in {strategies!r}:
     y = torch.ones(m, dtype=torch.float64, device="cuda")
     spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
     torch.cuda.synchronize()
     out[strat] = y.cpu().numpy()
-    out[strat + "__prepare_ms"] = np.array(ms)
     out[strat + "__plan"] = np.array(list((spmv_acc_amd.query_plan(rp, m) or {{}}).values()))
 np.savez({out!r}, **out)
 """
