@@ -217,9 +217,17 @@ def leg_sweep(torch, device, name, A=None):
     row = {"rows": A[0], "nnz": A[2]}
     for strat in ("flat", "adaptive"):
         row[strat] = timed_leg(torch, strat, A, x, y0, iters)
+    lib = spmv_acc_amd.load_library()
+    # `flat` as shipped runs, on balanced rows, the faster of its tile kernel and the row-block kernel (timed once per matrix, tunable
+    # flat_rowblock); this leg pins the TILE kernel, so that the line shows both
+    spmv_acc_amd.release_plans(A[3])
+    lib.spmv_acc_set_tunable(b"flat_rowblock", 0)
+    try:
+        row["flat_tile_kernel"] = timed_leg(torch, "flat", A, x, y0, iters)
+    finally:
+        lib.spmv_acc_set_tunable(b"flat_rowblock", -1)
     # opt-in leg, never the headline: flat over the plan's 16-bit column encoding (tunable col16; the plan then holds a copy
     # derived from colindex).  frac stays algorithmic bytes of the CSR format (12 B per non-zero) over time.
-    lib = spmv_acc_amd.load_library()
     spmv_acc_amd.release_plans(A[3])
     lib.spmv_acc_set_tunable(b"col16", 1)
     try:
@@ -351,7 +359,7 @@ def extra_legs(torch, device, headline, in_process=False):
             sweep[name] = leg_sweep(torch, device, name, A=headline)
         else:
             sweep[name] = leg(f"sweep:{name}", lambda name=name: leg_sweep(torch, device, name))
-        progress(f"sweep {name}: flat {sweep[name]['flat']['us']} us ({sweep[name]['flat']['frac']}), "
+        progress(f"sweep {name}: flat {sweep[name]['flat']['us']} us ({sweep[name]['flat']['frac']}; tile kernel alone {sweep[name]['flat_tile_kernel']['us']} us), "
                  f"adaptive {sweep[name]['adaptive']['us']} us ({sweep[name]['adaptive']['frac']}), "
                  f"flat+col16 {sweep[name]['flat_col16_opt_in']['us']} us ({sweep[name]['flat_col16_opt_in']['frac']})")
     out["sweep"] = sweep
@@ -362,7 +370,7 @@ def extra_legs(torch, device, headline, in_process=False):
             "median_frac": float(np.median([r[s]["frac"] for r in sweep.values()])),
             "ge_0.70_back_to_back": sum(1 for r in sweep.values() if r[s]["frac_back_to_back"] >= 0.70),
             "median_frac_back_to_back": float(np.median([r[s]["frac_back_to_back"] for r in sweep.values()]))}
-        for s in ("flat", "adaptive", "flat_col16_opt_in")}
+        for s in ("flat", "adaptive", "flat_tile_kernel", "flat_col16_opt_in")}
     out["rmat25"] = leg("rmat25", lambda: leg_rmat25(torch, device))
     progress(f"rmat25: {out['rmat25']['line_enhance']} ({out['rmat25']['path']})")
     progress(f"rmat25 without the slab passes: {out['rmat25']['line_enhance_without_slab_passes']}")

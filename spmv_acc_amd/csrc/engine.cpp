@@ -166,11 +166,12 @@ Tunable g_tunables[] = {
                                // with S = 8; a slab keeps only the rows that have non-zeros in it).  Costs S passes over y; loses on matrices whose gathers already hit.  After editing values
                                // in place call spmv_acc_refresh_values, after editing colindex spmv_acc_release_plans.  0 = off (the
                                // default: plans hold no copy of the matrix)
-    {"flat_rowblock", -1, -1}, // flat on SMALL grids (below 24 Mi non-zeros) whose fixed row blocks are balanced: -1 = time the flat tile kernel
-                               // against the row-block kernel once per matrix and run the faster (a flat tile needs one more dependent hop --
-                               // tile digest -> row extents -- than a row block, which a grid of two or three workgroups per CU cannot
-                               // hide: 7-11 % per launch on the small sweep stand-ins); 0 = always the flat tile kernel; 1 = always the
-                               // row blocks where balanced.  Large grids always run the tile kernel
+    {"flat_rowblock", -1, -1}, // flat on matrices whose fixed row blocks are balanced (nothing for non-zero-cut tiles to repair): -1 = time the flat tile
+                               // kernel against the row-block kernel once per matrix and run the row blocks where they are >= 3 % faster (a flat tile
+                               // needs one more dependent hop -- tile digest -> row extents -- and its cut rows a second kernel or a neighbour's carry:
+                               // 7-11 % per launch on the small sweep stand-ins, 3-6 % on the large ones under the per-launch protocol); 0 = always
+                               // the flat tile kernel; 1 = always the row blocks where balanced.  (Until late in round 3 only grids below 24 Mi
+                               // non-zeros were timed.)  A caller that pins any of the tile kernel's own choices gets the tile kernel
     {"legacy_kernels", 1, 1},  // KERNEL_STRATEGY LIGHT / BLOCK_ROW_ORDINARY / THREAD_ROW: 1 = what the names mean in the reference (k_legacy.hip: rows
                                // handed out by an atomic counter; one workgroup per row; THREAD_ROW: one lane per row at every row length), 0 = the
                                // round-1/2 stand-ins (the vector-row tile kernel; one wavefront per row; the row-block kernel's own lanes-per-row
@@ -1777,7 +1778,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
   const int rb_mode = tun(kT_flat_rowblock);
   // (a caller that pins any of the tile kernel's own choices -- cut-row form, tile size, staging order -- is asking for that kernel)
   const bool tile_pinned = tun(kT_flat_finish) >= 0 || tun(kT_flat_npt) >= 0 || tun(kT_flat_early) >= 0;
-  if (rb_mode != 0 && (rb_mode > 0 || !tile_pinned) && p.A.nnz < kFlatSmallNnz && !flat_segment_sum() && tun(kT_col16) <= 0 &&
+  if (rb_mode != 0 && (rb_mode > 0 || !tile_pinned) && !flat_segment_sum() && tun(kT_col16) <= 0 &&
       !tun(kT_rescue_flat) && !t_coarse_tuning) {
     if (rb_mode > 0) {
       int vec = 1, rpb = kThreads;
@@ -1802,7 +1803,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
         ok = ok && timer.time(st, [&] { (void)run_rowblock(st, p, nullptr, 1.0, trial_beta(), x, scratch, false); }, &ms_rb);
         if (!ok) return false;
         p.flat_rowblock_choice = ms_rb < 0.97f * ms_flat ? 1 : 0;
-        tune_log("m %d nnz %d flat on a small grid: tile kernel %.2f us, row blocks %.2f us -> %s", p.A.m, p.A.nnz, ms_flat * 1e3f, ms_rb * 1e3f,
+        tune_log("m %d nnz %d flat on balanced rows: tile kernel %.2f us, row blocks %.2f us -> %s", p.A.m, p.A.nnz, ms_flat * 1e3f, ms_rb * 1e3f,
                  p.flat_rowblock_choice ? "row blocks" : "tile kernel");
       }
     }
