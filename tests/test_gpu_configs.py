@@ -316,6 +316,9 @@ def test_bench_line_carries_every_baseline_config(torch_dev):
             assert row[strat]["us"] > 0 and 0.05 < row[strat]["frac"] < 1.2, (name, strat, row[strat])
             both_protocols(row[strat], (name, strat))
     assert "ge_0.70" in d["sweep_summary"]["flat"] and "ge_0.70_back_to_back" in d["sweep_summary"]["flat"]
+    # `flat` as shipped may run the row-block kernel on balanced rows (timed per matrix): the tile kernel alone is reported beside it
+    assert all(row["flat_tile_kernel"]["us"] > 0 for row in d["sweep"].values()) and "ge_0.70" in d["sweep_summary"]["flat_tile_kernel"]
+    assert "child process" in d["legs_measured"]
     assert d["rmat25"]["nnz"] > 480_000_000 and d["rmat25"]["line_enhance"]["us"] > 1000
     both_protocols(d["rmat25"]["line_enhance"], "rmat25")
     both_protocols(d["rmat25"]["line_enhance_without_slab_passes"], "rmat25, one-kernel path")
