@@ -9,9 +9,19 @@ drp,dci,dv = (torch.from_numpy(a).cuda() for a in (rowptr, cols, vals))
 x=torch.ones(20000,dtype=torch.float64,device='cuda'); y=torch.zeros(20000,dtype=torch.float64,device='cuda')
 def free(): torch.cuda.synchronize(); return torch.cuda.mem_get_info()[0]
 f0=None
+lib = spmv_acc_amd.load_library()
+# (round 3: the opt-in modes too -- run lists, slab-major copies, the full row-pointer digest, LIGHT's counter, a second stream's ordering event)
+side = torch.cuda.Stream()
 for it in range(300):
-    for s in ("adaptive","flat","adaptive_plus","line_enhance","vector_row","default"):
+    for s in ("adaptive","flat","adaptive_plus","line_enhance","vector_row","default","light","thread_row"):
         spmv_acc_amd.csr_spmv(1.0,0.0,20000,20000,nnz,drp,dci,dv,x,y,strategy=s)
+    for knobs in ({"slab_segments": 4}, {"col_slabs": 3}, {"guard_full": 1}, {"col16": 1}, {"gather_hint": 1}):
+        for k, val in knobs.items(): lib.spmv_acc_set_tunable(k.encode(), val)
+        spmv_acc_amd.csr_spmv(1.0,0.0,20000,20000,nnz,drp,dci,dv,x,y,strategy="flat" if "col16" in knobs else "line_enhance")
+        lib.spmv_acc_reset_tunables()
+    lib.spmv_acc_set_stream(side.cuda_stream)
+    spmv_acc_amd.csr_spmv(1.0,0.0,20000,20000,nnz,drp,dci,dv,x,y,strategy="flat")
+    lib.spmv_acc_set_stream(None)
     spmv_acc_amd.release_plans(drp)
     if it==20: f0=free()
 f1=free()
