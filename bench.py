@@ -127,8 +127,7 @@ def cpu_baseline(W, x, y0, seconds):
     tc, rc = timed(lambda y: oracle_lib.host_spmv_omp(1.0, 1.0, rp, ci, v, hx, y, cores), seconds * 0.6)
     return {
         "value": round(2.0 * nnz / tc / 1e9, 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
-        "sample": f"whole matrix ({W['m']} rows, {nnz} nnz), best of {rc} runs on {cores} threads of {cpu_model} (OpenMP over "
-                  f"nnz-balanced row ranges); 1 thread: {2.0 * nnz / t1 / 1e9:.3f} GFLOP/s best of {r1}",
+        "sample": f"whole matrix ({W['m']} rows, {nnz} nnz), best of {rc} runs, OpenMP over nnz-balanced row ranges; 1 thread: best of {r1}",
         "cpu_model": cpu_model,
         "value_1thread": round(2.0 * nnz / t1 / 1e9, 3),
     }
@@ -205,8 +204,9 @@ def _leg_vectors(torch, device, m, n):
             torch.rand(m, generator=gen, device=device, dtype=torch.float64) * 2 - 1)
 
 
-def leg_sweep(torch, device, name, A=None):
-    """One stand-in of the configs[2] sweep: flat (the strategy BASELINE names), adaptive, and the opt-in 16-bit column stream."""
+def leg_sweep(torch, device, name, A=None, light=False):
+    """One stand-in of the configs[2] sweep: flat (the strategy BASELINE names), adaptive, and (not `light`) flat's tile kernel alone
+    and the opt-in 16-bit column stream."""
     import spmv_acc_amd
     from spmv_acc_amd import synth
 
@@ -217,6 +217,9 @@ def leg_sweep(torch, device, name, A=None):
     row = {"rows": A[0], "nnz": A[2]}
     for strat in ("flat", "adaptive"):
         row[strat] = timed_leg(torch, strat, A, x, y0, iters)
+    if light:
+        spmv_acc_amd.release_plans(A[3])
+        return row
     lib = spmv_acc_amd.load_library()
     # `flat` as shipped runs, on balanced rows, the faster of its tile kernel and the row-block kernel (timed once per matrix, tunable
     # flat_rowblock); this leg pins the TILE kernel, so that the line shows both
@@ -363,6 +366,19 @@ def extra_legs(torch, device, headline, in_process=False):
                  f"adaptive {sweep[name]['adaptive']['us']} us ({sweep[name]['adaptive']['frac']}), "
                  f"flat+col16 {sweep[name]['flat_col16_opt_in']['us']} us ({sweep[name]['flat_col16_opt_in']['frac']})")
     out["sweep"] = sweep
+    # The same 12 stand-ins once more with every matrix measured IN THIS PROCESS, one after the other (what a solver holding several
+    # matrices sees): the >= 0.70 count is quoted for both regimes, because placement moves the 65 M-non-zero stand-ins by 2-4 %.
+    inproc = None
+    if not in_process:
+        inproc = {}
+        for name in synth.SWEEP_NAMES:
+            if name == "Hardesty3":
+                inproc[name] = sweep[name]
+                continue
+            inproc[name] = leg_sweep(torch, device, name, light=True)
+            torch.cuda.empty_cache()
+            progress(f"sweep (in process) {name}: flat {inproc[name]['flat']['frac']}, adaptive {inproc[name]['adaptive']['frac']}")
+        out["sweep_in_process"] = {k: {s: v[s] for s in ("flat", "adaptive")} for k, v in inproc.items()}
     out["sweep_summary"] = {
         s: {"protocol": "per-launch, y reset (benchmark/csr_spmv.hpp:66-74); *_back_to_back beside it",
             "ge_0.70": sum(1 for r in sweep.values() if r[s]["frac"] >= 0.70),
@@ -371,6 +387,10 @@ def extra_legs(torch, device, headline, in_process=False):
             "ge_0.70_back_to_back": sum(1 for r in sweep.values() if r[s]["frac_back_to_back"] >= 0.70),
             "median_frac_back_to_back": float(np.median([r[s]["frac_back_to_back"] for r in sweep.values()]))}
         for s in ("flat", "adaptive", "flat_tile_kernel", "flat_col16_opt_in")}
+    for s in ("flat", "adaptive"):
+        rows = (inproc or sweep).values()
+        out["sweep_summary"][s]["ge_0.70_in_process"] = sum(1 for r in rows if r[s]["frac"] >= 0.70)
+        out["sweep_summary"][s]["median_frac_in_process"] = float(np.median([r[s]["frac"] for r in rows]))
     out["rmat25"] = leg("rmat25", lambda: leg_rmat25(torch, device))
     progress(f"rmat25: {out['rmat25']['line_enhance']} ({out['rmat25']['path']})")
     progress(f"rmat25 without the slab passes: {out['rmat25']['line_enhance_without_slab_passes']}")
@@ -484,6 +504,76 @@ def copy_ceiling_gbs(torch, device):
         best = max(best, spmv_acc_amd.copy_ceiling_gbs(b, a, reps=5))
     lib.spmv_acc_set_tunable(b"copy_nt", 1)
     return best
+
+
+LINE_BUDGET = 6000  # the driver keeps an 8,001-byte tail of stdout: the ONE line must fit it with room to spare
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full):
+    """The ONE stdout line: the contract's keys, `roofline`, `cpu_baseline` and one short figure per extra measurement -- as the
+    reference's harness prints one short `PERFORMANCE,` row per measurement (benchmark/utils/statistics_logger.cpp:11-31).
+    Everything else (prose notes, the third timing column, opt-in legs, launch floor, sensitivity, RCCL log lines) lives in
+    bench_full.json beside this script and on stderr."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                        "vs_baseline", "dtype", "data", "config"))
+    r = full["roofline"]
+    line["roofline"] = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_lower_bound",
+                                 "algorithmic_bytes_per_launch", "launch_ms_mean"))
+    line["roofline"]["back_to_back"] = _pick(r.get("back_to_back", {}), ("frac",))
+    if "frac_of_copy_ceiling" in r:
+        line["roofline"]["frac_of_copy_ceiling"] = r["frac_of_copy_ceiling"]
+    cb = full.get("cpu_baseline")
+    line["cpu_baseline"] = None if not cb else _pick(cb, ("value", "unit", "cores", "kind", "sample", "cpu_model", "value_1thread"))
+    line.update(_pick(full, ("copy_ceiling_gbs", "plan", "first_call_ms")))
+    if "sweep" in full:  # configs[2]: name -> [flat frac, adaptive frac] under the per-launch protocol
+        line["sweep"] = {k: [row["flat"]["frac"], row["adaptive"]["frac"]] for k, row in full["sweep"].items()}
+        line["sweep_summary"] = {s: _pick(v, ("ge_0.70", "ge_0.70_in_process", "median_frac", "min_frac", "median_frac_in_process"))
+                                 for s, v in full["sweep_summary"].items() if s in ("flat", "adaptive")}
+    if "rmat25" in full:  # configs[3]
+        le = full["rmat25"]["line_enhance"]
+        line["rmat25"] = {"us": le["us"], "frac": le["frac"], "nnz": full["rmat25"]["nnz"]}
+    if "banded_shard" in full:  # configs[4], one shard
+        ad = full["banded_shard"]["adaptive"]
+        line["banded_shard"] = {"us": ad["us"], "frac": ad["frac"]}
+    if "sensitivity" in full:
+        line["no_far_columns_frac"] = full["sensitivity"]["frac"]
+    # N > 1
+    line.update(_pick(full, ("exchange", "spmv_only_gflops_per_gpu", "spmv_only_ms_max_over_ranks", "spmv_plus_exchange_ms_per_step",
+                             "spmv_plus_exchange_gflops_total", "allgather_bytes_per_rank_per_step", "dependent_step_ms_by_pipeline",
+                             "pipeline_best", "exchanged_bytes_per_rank_per_step")))
+    if "rccl" in full:
+        line["rccl"] = {"ranks": full["rccl"].get("nranks_seen")}
+    if "banded" in full:
+        b = full["banded"]
+        line["banded"] = _pick(b, ("rows_per_gpu", "nnz_per_gpu", "steps", "exchange", "spmv_only_frac_of_hbm_peak", "spmv_only_gflops_per_gpu",
+                                   "spmv_plus_exchange_ms_per_step", "spmv_plus_exchange_gflops_total", "dependent_step_ms_by_pipeline"))
+        if "halo_exchange" in b:
+            line["banded"]["halo_exchange"] = _pick(b["halo_exchange"], ("ms_per_step", "gflops_total"))
+    if "strong_scaling" in full:
+        line["strong_scaling"] = _pick(full["strong_scaling"], ("gflops_total", "ms_per_step", "exchange", "spmv_only_ms_max_over_ranks"))
+    line["details"] = "bench_full.json"
+    text = json.dumps(line, separators=(",", ":"))
+    for drop in ("strong_scaling", "banded", "sweep", "plan", "copy_ceiling_gbs"):  # never reached today; the line must fit whatever is added later
+        if len(text) < LINE_BUDGET:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def write_full(full):
+    """The whole record: bench_full.json beside the script (best effort: a read-only checkout only loses the file) and stderr."""
+    text = json.dumps(full, indent=1)
+    try:
+        with open(os.path.join(ROOT, "bench_full.json"), "w") as f:
+            f.write(text + "\n")
+    except OSError as ex:
+        print(f"[bench] bench_full.json not written: {ex!r}", file=sys.stderr)
+    print("[bench full record]\n" + text, file=sys.stderr, flush=True)
 
 
 def self_launch(args):
@@ -615,8 +705,14 @@ def main():
     out_extra = {}
     if not dist_leg:
         # ---- warm-up (builds the plan: nnz / samples / break points are fetched once here) ----
-        for _ in range(max(args.warmup, 1)):
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        for i in range(max(args.warmup, 1)):
             spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y, strategy=strat)
+            if i == 0:  # the first call builds the plan (structural passes + per-matrix timings): reported, never inside the timed region
+                torch.cuda.synchronize()
+                out_extra["first_call_ms"] = round((time.perf_counter() - tf) * 1e3, 3)
+                out_extra["first_call_host_prepare_ms"] = round(spmv_acc_amd.load_library().spmv_acc_last_prepare_us() * 1e-3, 3)
         torch.cuda.synchronize()
         y.copy_(y0)
         sync_all()
@@ -844,8 +940,9 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:
+        write_full(result)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(result) + "\n").encode())
+        os.write(json_fd, (compact_line(result) + "\n").encode())
     os.close(json_fd)
     if dist_leg:
         dist.destroy_process_group()

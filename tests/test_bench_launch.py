@@ -73,3 +73,46 @@ def test_the_parent_of_a_self_launch_never_loads_torch_or_the_library():
     )
     r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=300)
     assert "LOADED []" in r.stdout, (r.stdout, r.stderr[-1500:])
+
+
+def _bench_module():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_the_stdout_line_fits_the_drivers_tail():
+    """BENCH_r03.json's `parsed` was null: the line had grown to 21 KB and the driver keeps an 8,001-byte tail.  compact_line() is what
+    goes to stdout now -- checked here on round 3's own full records (N = 1 with every leg; the forced-dist N > 1 shape) and on an
+    N = 8 record padded with every optional key: always < 6000 bytes, always carrying the contract's keys, roofline and cpu_baseline."""
+    bench = _bench_module()
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_final_runs.jsonl")).readline())
+    assert len(json.dumps(full)) > 15000  # (what round 3 printed)
+    text = bench.compact_line(full)
+    assert len(text) < 6000 and "\n" not in text
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert line[key] == full[key] or isinstance(full[key], dict), key
+    assert line["roofline"]["frac"] == full["roofline"]["frac"] and line["roofline"]["traffic"] == full["roofline"]["traffic"]
+    assert line["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"] and line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    assert line["sweep"]["Hardesty3"] == [full["sweep"]["Hardesty3"]["flat"]["frac"], full["sweep"]["Hardesty3"]["adaptive"]["frac"]]
+    assert line["rmat25"]["frac"] == full["rmat25"]["line_enhance"]["frac"] and line["banded_shard"]["frac"] == full["banded_shard"]["adaptive"]["frac"]
+
+    dist = json.load(open(os.path.join(ROOT, "profiles", "r03_force_dist_one_rank_rccl.json")))
+    dist["n_gpus"] = 8
+    leg = {k: dist[k] for k in ("exchange", "spmv_only_gflops_per_gpu", "spmv_only_ms_max_over_ranks", "spmv_plus_exchange_ms_per_step",
+                                "spmv_plus_exchange_gflops_total", "allgather_bytes_per_rank_per_step", "dependent_step_ms_by_pipeline")}
+    dist["banded"] = dict(leg, workload="x" * 300, rows_per_gpu=32_000_000, nnz_per_gpu=256_000_000, steps=50, spmv_only_frac_of_hbm_peak=0.7,
+                          exchange_ms={"allgather": 1.0, "p2p": 1.1}, halo_exchange={"what": "y" * 200, "ms_per_step": 0.7, "gflops_total": 5000.0})
+    dist["strong_scaling"] = dict(leg, workload="z" * 200, gflops_total=3000.0, ms_per_step=0.03)
+    dist["rccl"]["lines"] = ["NCCL INFO " + "w" * 150] * 8
+    text = bench.compact_line(dist)
+    assert len(text) < 6000
+    line = json.loads(text)
+    assert line["rccl"]["ranks"] == dist["rccl"]["nranks_seen"] and line["spmv_plus_exchange_ms_per_step"] == dist["spmv_plus_exchange_ms_per_step"]
+    assert line["banded"]["spmv_only_frac_of_hbm_peak"] == 0.7 and line["strong_scaling"]["gflops_total"] == 3000.0
+    assert "roofline" in line and "cpu_baseline" in line
