@@ -152,7 +152,8 @@ int spmv_acc_sharded_spmv(void *nccl_comm, int strategy, double alpha, double be
  * itself, i.e. in place) is read by the out-of-place kernels, so no slice is ever copied -- and then every rank receives every
  * slice, in place:
  *   pipeline <= 1: ONE ncclAllGather (send buffer = this rank's slice of dy_full) on the library stream, behind the kernels;
- *   pipeline  = C: the local rows are cut into C chunks (rowptr rebased once per chunk at create time, colindex / value as views);
+ *   pipeline  = C: the local rows are cut into C chunks -- row sub-ranges of the caller's own arrays, nothing is copied or rebased; their
+ *                  kernels alternate over two streams of the shard's own (consecutive chunks are independent);
  *                  chunk c's slice travels -- grouped ncclSend / ncclRecv with every peer, straight to its place in their
  *                  vectors, on a second stream -- as soon as its kernels have finished, while chunk c+1 computes.  This is the
  *                  overlap that survives when the next x depends on the gathered y.  The library stream waits for the last
@@ -166,6 +167,11 @@ int spmv_acc_shard_create(spmv_acc_shard_t *out, void *nccl_comm, int strategy, 
                           const int *d_rowptr, const int *d_colindex, const double *d_value, int pipeline);
 int spmv_acc_shard_step(spmv_acc_shard_t shard, double alpha, double beta, const double *dx, const double *dy_in_local,
                         double *dy_full);
+/* Builds and tunes every chunk's plan for the beta class of `beta` (beta == 0 / beta != 0) with x = dx, so that the steps only enqueue: plan
+ * building allocates, frees and synchronises, which must not fall between the exchanges of a step the peers are already in.  No collective
+ * inside; every rank calls it once before its first step (spmv-cli --gpus N does).  A rank whose local SpMV fails inside a step still takes
+ * part in all of that step's exchanges and reports its error afterwards: the peers are never left waiting in a collective. */
+int spmv_acc_shard_prepare(spmv_acc_shard_t shard, double beta, const double *dx);
 int spmv_acc_shard_pipeline(spmv_acc_shard_t shard); /* chunks per step actually in use */
 int spmv_acc_shard_destroy(spmv_acc_shard_t shard);
 int spmv_acc_rccl_comm_init_all(void **comms, int ndev, const int *devices);

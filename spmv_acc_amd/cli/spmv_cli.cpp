@@ -368,28 +368,43 @@ int run_multi_gpu(const Options &o, HostCsr &A, HostVectors &v) {
       ok = false;
     }
     auto step = [&] {
-      if (ok && spmv_acc_shard_step(shard, o.alpha, o.beta, d_x, d_y0, d_full) != 0) {
+      // (a rank whose step has failed keeps calling: the library still takes part in the step's exchanges, so the peers, which
+      // learn about the failure only at the next barrier, are not left waiting inside this phase)
+      if (shard && spmv_acc_shard_step(shard, o.alpha, o.beta, d_x, d_y0, d_full) != 0 && ok) {
         bail("spmv_acc_shard_step");
         ok = false;
       }
     };
-    // every rank takes part in every collective whatever happened to it locally would deadlock the others: a rank that failed
-    // before the first step makes ALL ranks skip the steps (agreed at the barrier)
-    barrier.wait();
-    bool all_ok = true;
-    for (int k = 0; k < N; ++k) all_ok = all_ok && rcs[k] == 0;
-    if (all_ok) {
-      for (int i = 0; i < 10; ++i) step(); // warm up GPU (cli/main.cpp:99-103); the first step builds the plan
-      HIP_CHECK(hipStreamSynchronize(st));
+    // Plans first, outside any collective: every chunk's plan is built and tuned here (allocations, device-wide synchronisations,
+    // timed launches), so that a step only enqueues kernels and exchanges.
+    if (ok && spmv_acc_shard_prepare(shard, o.beta, d_x) != 0) {
+      bail("spmv_acc_shard_prepare");
+      ok = false;
+    }
+    // Every rank takes part in every collective, whatever happened to it locally (spmv_acc_shard_step does that inside a step);
+    // BETWEEN phases the ranks agree at a barrier whether all of them are still fine, and if one is not, ALL skip what follows --
+    // a rank that stopped alone would leave its peers blocked in the next exchange for ever.
+    auto all_fine = [&] {
       barrier.wait();
-      const auto t0 = std::chrono::steady_clock::now();
-      step();
+      bool fine = true;
+      for (int k = 0; k < N; ++k) fine = fine && rcs[k] == 0;
+      barrier.wait(); // (nobody sets rcs between the two waits: everybody has read the same values)
+      return fine;
+    };
+    if (all_fine()) {
+      for (int i = 0; i < 10; ++i) step(); // warm up GPU (cli/main.cpp:99-103)
       HIP_CHECK(hipStreamSynchronize(st));
-      step_us[r] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-      barrier.wait();
-      step(); // result run (cli/main.cpp:116-118)
-      HIP_CHECK(hipStreamSynchronize(st));
-      if (r == 0) HIP_CHECK(hipMemcpy(gathered.data(), d_full, full_bytes, hipMemcpyDeviceToHost));
+      if (all_fine()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        step();
+        HIP_CHECK(hipStreamSynchronize(st));
+        step_us[r] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (all_fine()) {
+          step(); // result run (cli/main.cpp:116-118)
+          HIP_CHECK(hipStreamSynchronize(st));
+          if (r == 0) HIP_CHECK(hipMemcpy(gathered.data(), d_full, full_bytes, hipMemcpyDeviceToHost));
+        }
+      }
     }
     if (shard) spmv_acc_shard_destroy(shard);
     spmv_acc_release_plans(d_rp);

@@ -90,7 +90,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kT_slab_segments, kT_vector_target, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kT_slab_segments, kT_vector_target, kT_hub_rows, kT_hub_min_len, kT_hub_window_kb, kTunableCount
 };
 #ifdef FLAT_SEGMENT_SUM_REDUCE
 constexpr int kFlatReduceBuilt = 1;
@@ -189,6 +189,12 @@ Tunable g_tunables[] = {
     {"vector_target", 1900, 1900}, // vector-row tile kernel: products a workgroup's rows should bring to its 2048-product tile (the row-block family's
                                // `rowblock_target` went to 1500 in round 3; this kernel, with two rows per lane group, keeps the fuller tile:
                                // 1900 against 1500 is 3-5.5 % faster on four of five sweep stand-ins, equal on the fifth)
+    {"hub_rows", -1, -1},      // second level of the slab passes (k_hub.hip, round 4): the rows of >= hub_min_len non-zeros leave the coarse slab lists and
+                               // are cut into runs over column windows of hub_window_kb of x (one window fits an XCD's L2); one launch walks those runs
+                               // window by window, one merge kernel adds a hub row's partial sums in window order.  -1 / 1 = with the slab passes
+                               // (whenever they are built), 0 = off (round 3's passes alone)
+    {"hub_min_len", 128, 128}, // a row is a hub from this many non-zeros (a row of d non-zeros over W windows yields ~min(d, W) runs: windows pay where d >> W)
+    {"hub_window_kb", 4096, 4096}, // KB of x per column window (an XCD's L2 is 4 MB)
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 void apply_env_tunables();
@@ -624,7 +630,24 @@ struct Plan {
   std::vector<int *> seg_row, seg_begin, seg_vptr, seg_blk;
   std::vector<int> seg_entries, seg_blocks, seg_pieces; // seg_pieces[s] != 0: the slab holds runs cut into pieces (merge kernel needed)
   double *d_seg_ys = nullptr; // one partial sum per entry of the longest list
+  // hub rows through L2-sized column windows (k_hub.hip): built together with the slab lists (which then skip the hub rows)
+  int seg_hub_from = 0;        // the coarse lists were built skipping rows of this many non-zeros or more (0: none skipped)
+  int seg_rest_below = 0;      // two-class form: rows of fewer non-zeros than this are whole runs in the last plane (0: every row is cut by slab)
+  int hub_rows = 0, hub_windows = 0, hub_width = 0, hub_groups = 0, hub_entries = 0, hub_blocks = 0;
+  int *d_hub_row = nullptr, *d_hub_ent = nullptr, *d_hub_begin = nullptr, *d_hub_vptr = nullptr, *d_hub_blk = nullptr, *d_hub_cell = nullptr;
+  double *d_hub_ys = nullptr;
+  void free_hub() {
+    for (int **q : {&d_hub_row, &d_hub_ent, &d_hub_begin, &d_hub_vptr, &d_hub_blk, &d_hub_cell}) {
+      if (*q) (void)hipFree(*q);
+      *q = nullptr;
+    }
+    if (d_hub_ys) (void)hipFree(d_hub_ys);
+    d_hub_ys = nullptr;
+    hub_rows = hub_windows = hub_width = hub_groups = hub_entries = hub_blocks = 0;
+  }
   void free_segments() {
+    free_hub();
+    seg_hub_from = seg_rest_below = 0;
     for (auto *list : {&seg_row, &seg_begin, &seg_vptr, &seg_blk}) {
       for (int *q : *list)
         if (q) (void)hipFree(q);
@@ -2054,6 +2077,10 @@ void run_segments(hipStream_t st, Plan &p, double alpha, double beta, const doub
     launch_segment_tiles(st, p.seg_blocks[s], alpha, p.seg_blk[s], p.seg_row[s], p.seg_begin[s], p.seg_vptr[s], p.A.ci, p.A.v, x, p.d_seg_ys, y);
     if (p.seg_pieces[s]) launch_segment_merge(st, p.seg_entries[s], p.seg_row[s], p.d_seg_ys, y);
   }
+  if (p.hub_entries > 0) { // the hub rows: one launch over their runs, window by window; then their partial sums, in window order, into y
+    launch_segment_tiles(st, p.hub_blocks, alpha, p.d_hub_blk, nullptr, p.d_hub_begin, p.d_hub_vptr, p.A.ci, p.A.v, x, p.d_hub_ys, y);
+    launch_hub_merge(st, p.hub_rows, p.hub_windows, p.hub_groups, p.d_hub_cell, p.d_hub_ent, p.d_hub_ys, p.d_hub_row, y);
+  }
 }
 // automatic mode: slabs of about 32 MB of x (R-MAT scale 25, x = 256 MB, S = 4 / 8 / 12 / 16: 5.92 / 5.31 / 5.59 / 6.08 ms, 7.27 without;
 // scale 24, x = 128 MB, S = 4 / 8: 2.37 / 2.59 ms, 3.21 without)
@@ -2277,14 +2304,23 @@ bool ensure_slabs(Plan &p, int S, hipStream_t st) {
 }
 
 // Column-slab blocking without a copy (tunable slab_segments): the per-slab run lists of k_segment.hip.  Structure only; built once.
-bool ensure_segments(Plan &p, int S, hipStream_t st) {
-  if (p.seg_state >= 0 && (p.seg_state == 0 || p.seg_slabs == S)) return true;
+bool ensure_hub(Plan &p, int hub_from, hipStream_t st);
+inline int hub_from_now() { return tun(kT_hub_rows) == 1 && tun(kT_hub_min_len) > 1 ? tun(kT_hub_min_len) : 0; }
+bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
+  const int hub_from = tun(kT_hub_rows) == 1 ? hub_from_now() : 0;
+  // two-class form (hub_rows = 2): only the rows of >= hub_min_len non-zeros are cut by column slab; every shorter row is ONE run, all columns, in a
+  // pass of its own (plane S_cols).  A 128-B line of values holds 16 non-zeros -- of a short or medium row that is 4-6 different slabs' runs, and
+  // every pass that owns one of them fetches the line again (R-MAT 25, all rows cut: 15.5 M KB raw FETCH_SIZE per SpMV for 7.3 GB of algorithmic
+  // bytes); the long rows' runs fill their lines, the short rows are cheaper gathered from all of x than streamed five times.
+  const int rest_below = tun(kT_hub_rows) == 2 && tun(kT_hub_min_len) > 1 ? tun(kT_hub_min_len) : 0;
+  const int S = S_cols + (rest_below > 0 ? 1 : 0); // planes
+  if (p.seg_state >= 0 && (p.seg_state == 0 || (p.seg_slabs == S && p.seg_hub_from == hub_from && p.seg_rest_below == rest_below))) return true;
   if (!plan_work_allowed("building the column-slab run lists")) return false;
   ++t_plan_work;
   p.free_segments();
   const CsrDev &A = p.A;
   const size_t m1 = static_cast<size_t>(A.m) + 1;
-  const int width = (A.n + S - 1) / S > 0 ? (A.n + S - 1) / S : 1;
+  const int width = (A.n + S_cols - 1) / S_cols > 0 ? (A.n + S_cols - 1) / S_cols : 1;
   SlabBounds bounds;
   for (int b = 0; b < 15; ++b) bounds.first[b] = static_cast<int>(std::min<long long>(static_cast<long long>(width) * (b + 1), INT_MAX));
   // (equal column ranges.  Unequal ones were tried on R-MAT 25 through an environment hook since removed -- the hot eighth split in two
@@ -2301,7 +2337,7 @@ bool ensure_segments(Plan &p, int S, hipStream_t st) {
             hip_ok(hipMemsetAsync(flag, 0, sizeof(int), st), "memset order flag");
   int unordered = 0;
   if (ok) {
-    launch_segment_count(st, A, bounds, S, cnt, beg, flag);
+    launch_segment_count(st, A, bounds, S, cnt, beg, flag, hub_from, rest_below);
     ok = hip_ok(hipMemcpyAsync(&unordered, flag, sizeof(int), hipMemcpyDeviceToHost, st), "read order flag") &&
          hip_ok(hipStreamSynchronize(st), "sync run counts");
   }
@@ -2376,8 +2412,15 @@ bool ensure_segments(Plan &p, int S, hipStream_t st) {
     } else if (ok) {
       p.seg_state = 1;
       p.seg_slabs = S;
+      p.seg_hub_from = hub_from;
+      p.seg_rest_below = rest_below;
     }
   }
+  for (void *q : {static_cast<void *>(cnt), static_cast<void *>(beg), static_cast<void *>(pieces), static_cast<void *>(pos), static_cast<void *>(flag), tmp})
+    if (q) (void)hipFree(q);
+  cnt = beg = pieces = pos = flag = nullptr;
+  tmp = nullptr;
+  if (ok && p.seg_state == 1 && hub_from > 0 && !ensure_hub(p, hub_from, st)) ok = false;
   for (void *q : {static_cast<void *>(cnt), static_cast<void *>(beg), static_cast<void *>(pieces), static_cast<void *>(pos), static_cast<void *>(flag), tmp})
     if (q) (void)hipFree(q);
   if (!ok) {
@@ -2385,6 +2428,123 @@ bool ensure_segments(Plan &p, int S, hipStream_t st) {
     return false;
   }
   return true;
+}
+
+// Hub rows through L2-sized column windows (k_hub.hip): the lists of the rows of >= hub_from non-zeros, which the coarse slab lists skip.
+// Called at the end of ensure_segments.  Returns false on a HIP error; hub rows whose columns do not ascend send the whole matrix back to
+// the ordinary path (seg_state 0), like rows that are not ordered by slab.
+bool ensure_hub(Plan &p, int hub_from, hipStream_t st) {
+  const CsrDev &A = p.A;
+  p.free_hub();
+  const size_t m1 = static_cast<size_t>(A.m) + 1;
+  long long width = static_cast<long long>(tun(kT_hub_window_kb)) * 1024 / 8;
+  if (width < 4096) width = 4096;
+  while ((A.n + width - 1) / width > 1024) width *= 2; // (at most 1024 windows)
+  const int NW = static_cast<int>((A.n + width - 1) / width);
+  int *flag = nullptr, *pos = nullptr, *bad = nullptr;
+  void *tmp = nullptr;
+  const size_t tmp_bytes = col16_scan_bytes(A.m);
+  int H = 0, unsorted = 0;
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&flag), sizeof(int) * m1), "hipMalloc hub flags") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&pos), sizeof(int) * m1), "hipMalloc hub positions") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&bad), sizeof(int)), "hipMalloc hub order flag") &&
+            hip_ok(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16), "hipMalloc scan workspace") &&
+            hip_ok(hipMemsetAsync(bad, 0, sizeof(int), st), "memset hub order flag");
+  if (ok) {
+    launch_hub_flags(st, A.rp, A.m, hub_from, flag);
+    ok = launch_col16_scan(st, A.m, flag, pos, tmp, tmp_bytes) &&
+         hip_ok(hipMemcpyAsync(&H, pos + A.m, sizeof(int), hipMemcpyDeviceToHost, st), "read hub count") && hip_ok(hipStreamSynchronize(st), "sync hub count");
+  }
+  // (NW + 1) * H window bounds and as many scan entries: a matrix that is all hubs, or has too many for 32-bit cell arithmetic, keeps its hub rows out of
+  // reach of this path -- the caller then rebuilds nothing: such a matrix is not what the windows are for
+  const long long cells = static_cast<long long>(NW + 1) * H;
+  if (ok && H > 0 && (NW < 2 || cells > (1LL << 30))) {
+    tune_log("m %d nnz %d: hub windows: %d hub rows x %d windows is out of range, ordinary path", A.m, A.nnz, H, NW);
+    H = -1;
+  }
+  if (ok && H > 0) {
+    ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_row), sizeof(int) * static_cast<size_t>(H)), "hipMalloc hub rows");
+    if (ok) {
+      launch_hub_rows(st, flag, pos, A.m, p.d_hub_row);
+      launch_hub_sorted(st, A, p.d_hub_row, H, bad);
+      ok = hip_ok(hipMemcpyAsync(&unsorted, bad, sizeof(int), hipMemcpyDeviceToHost, st), "read hub order flag") && hip_ok(hipStreamSynchronize(st), "sync hub order");
+    }
+  }
+  for (void *q : {static_cast<void *>(flag), static_cast<void *>(pos), tmp})
+    if (q) (void)hipFree(q);
+  flag = pos = nullptr;
+  tmp = nullptr;
+  if (ok && (H < 0 || unsorted)) {
+    if (unsorted) tune_log("m %d nnz %d: hub windows: a hub row's columns do not ascend, ordinary path", A.m, A.nnz);
+    if (bad) (void)hipFree(bad);
+    p.free_segments();
+    p.seg_state = 0;
+    return true;
+  }
+  int *wbeg = nullptr, *pieces = nullptr, *cpos = nullptr, *len = nullptr, *cost = nullptr, *cptr = nullptr;
+  void *tmp_c = nullptr, *tmp_e = nullptr;
+  if (ok && H > 0) {
+    const size_t ncell = static_cast<size_t>(NW) * H + 1;
+    const size_t tmp_c_bytes = col16_scan_bytes(static_cast<int>(ncell - 1));
+    int entries = 0;
+    ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&wbeg), sizeof(int) * static_cast<size_t>(cells)), "hipMalloc hub window bounds") &&
+         hip_ok(hipMalloc(reinterpret_cast<void **>(&pieces), sizeof(int) * ncell), "hipMalloc hub pieces") &&
+         hip_ok(hipMalloc(reinterpret_cast<void **>(&cpos), sizeof(int) * ncell), "hipMalloc hub cell positions") &&
+         hip_ok(hipMalloc(&tmp_c, tmp_c_bytes > 0 ? tmp_c_bytes : 16), "hipMalloc scan workspace");
+    if (ok) {
+      launch_hub_bounds(st, A, p.d_hub_row, H, static_cast<int>(width), NW, wbeg);
+      launch_hub_pieces(st, wbeg, H, NW, kSegPiece, pieces);
+      ok = launch_col16_scan(st, static_cast<int>(ncell - 1), pieces, cpos, tmp_c, tmp_c_bytes) &&
+           hip_ok(hipMemcpyAsync(&entries, cpos + (ncell - 1), sizeof(int), hipMemcpyDeviceToHost, st), "read hub entry count") &&
+           hip_ok(hipStreamSynchronize(st), "sync hub entry count");
+    }
+    if (ok && entries > 0) {
+      const size_t e1 = static_cast<size_t>(entries) + 1;
+      const size_t tmp_e_bytes = col16_scan_bytes(entries);
+      const int NG = (H + kHubGroup - 1) / kHubGroup;
+      int last = 0;
+      ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_ent), sizeof(int) * e1), "hipMalloc hub entry rows") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_begin), sizeof(int) * e1), "hipMalloc hub entry starts") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_vptr), sizeof(int) * e1), "hipMalloc hub entry prefix") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_cell), sizeof(int) * static_cast<size_t>(NW) * (NG + 1)), "hipMalloc hub cells") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_ys), sizeof(double) * e1), "hipMalloc hub run sums") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&len), sizeof(int) * e1), "hipMalloc hub run lengths") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&cost), sizeof(int) * e1), "hipMalloc hub run costs") &&
+           hip_ok(hipMalloc(reinterpret_cast<void **>(&cptr), sizeof(int) * e1), "hipMalloc hub run cost prefix") &&
+           hip_ok(hipMalloc(&tmp_e, tmp_e_bytes > 0 ? tmp_e_bytes : 16), "hipMalloc scan workspace");
+      if (ok) {
+        launch_hub_compact(st, wbeg, cpos, H, NW, kSegPiece, p.d_hub_ent, p.d_hub_begin, len);
+        launch_hub_cells(st, cpos, H, NW, NG, p.d_hub_cell);
+        launch_segment_cost(st, entries, len, cost);
+        ok = launch_col16_scan(st, entries, len, p.d_hub_vptr, tmp_e, tmp_e_bytes) && launch_col16_scan(st, entries, cost, cptr, tmp_e, tmp_e_bytes) &&
+             hip_ok(hipMemcpyAsync(&last, cptr + entries, sizeof(int), hipMemcpyDeviceToHost, st), "read hub pass cost") &&
+             hip_ok(hipStreamSynchronize(st), "sync hub scans");
+      }
+      if (ok) {
+        const int nblocks = segment_block_count(last);
+        ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_blk), sizeof(int) * (static_cast<size_t>(nblocks) + 1)), "hipMalloc hub workgroups");
+        if (ok) {
+          launch_segment_blocks(st, entries, nblocks, cptr, p.d_hub_blk);
+          ok = hip_ok(hipStreamSynchronize(st), "sync hub workgroups");
+        }
+        if (ok) {
+          p.hub_rows = H;
+          p.hub_windows = NW;
+          p.hub_width = static_cast<int>(width);
+          p.hub_groups = NG;
+          p.hub_entries = entries;
+          p.hub_blocks = nblocks;
+          tune_log("m %d nnz %d: hub windows: %d rows of >= %d non-zeros, %d windows of %lld columns, %d runs, %d workgroups", A.m, A.nnz, H, hub_from, NW,
+                   width, entries, nblocks);
+        }
+      }
+    }
+  }
+  for (void *q : {static_cast<void *>(wbeg), static_cast<void *>(pieces), static_cast<void *>(cpos), static_cast<void *>(len), static_cast<void *>(cost),
+                  static_cast<void *>(cptr), static_cast<void *>(bad), tmp_c, tmp_e})
+    if (q) (void)hipFree(q);
+  if (!ok) p.free_hub();
+  return ok;
 }
 } // namespace
 
@@ -2505,7 +2665,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
 
   if (tun(kT_slab_segments) >= 2 && !t_in_slab) {
     // column-slab blocking without a copy: S passes over the plan's run lists (k_segment.hip), whatever the strategy name
-    const int S = tun(kT_slab_segments) > 16 ? 16 : tun(kT_slab_segments);
+    const int S = tun(kT_slab_segments) > 15 ? 15 : tun(kT_slab_segments); // (+ one plane for the short rows of the two-class form: 16 in all)
     if (last_error_code_only() == kOk && !t_capturing && !ensure_segments(*p, S, st)) {
       // (no room for the lists or their S x (m + 1) build temporaries: the passes are an optimisation, the strategy's own kernel runs)
       (void)hipGetLastError();
@@ -2514,7 +2674,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
       p->free_segments();
       p->seg_state = 0; // (not tried again for this plan)
     }
-    if (p->seg_state == 1 && p->seg_slabs == S) {
+    if (p->seg_state == 1) {
       run_segments(st, *p, alpha, beta, dx, dy);
       if (t_plan_work != prepare_clock.work0 && p->tune_key) tune_store(*p);
       return;

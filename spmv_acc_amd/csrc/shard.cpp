@@ -9,8 +9,11 @@
 // vector (the out-of-place kernels read the old slice wherever the caller keeps it) and moves the slice to every peer in place:
 //   pipeline 1 : the kernels, then ONE ncclAllGather (in place: send buffer = this rank's slice of the receive buffer) on the
 //                library stream;
-//   pipeline C : the rows are cut into C chunks; chunk c's kernels go to the library stream, and as soon as they have finished
-//                (event) the chunk travels on a second stream -- grouped ncclSend / ncclRecv with every peer, straight to its place
+//   pipeline C : the rows are cut into C chunks -- row SUB-RANGES of the shard's own arrays (rowptr + a, the whole colindex / value arrays: the kernels
+//                accept rowptr[0] > 0), nothing is copied; the chunks' kernels alternate over two compute streams of the shard's own (consecutive chunks are
+//                independent: on ONE stream each kernel would wait for its predecessor's last wavefront, 8 launches cost 0.245 ms against 0.156 for one;
+//                alternating, a chunk's tail overlaps the next one's start), and as soon as a chunk's kernels have finished
+//                (event) the chunk travels on the exchange stream -- grouped ncclSend / ncclRecv with every peer, straight to its place
 //                in their vectors -- while chunk c+1 computes.  xGMI is point to point, 7 links per GPU: the grouped fan-out
 //                drives all of them at once.  (An allgather of a row sub-range would land chunk-major in the receive buffer, which
 //                is why the chunks travel point to point.)  The library stream waits for the last chunk's arrival before anything
@@ -77,11 +80,6 @@ const Rccl &rccl() {
 }
 constexpr int kNcclFloat64 = 8; // ncclDataType_t ncclFloat64 / ncclDouble (rccl.h)
 
-__global__ void rebase_rowptr_kernel(const int *__restrict__ rp, int first, int count, int *__restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) out[i] = rp[first + i] - rp[first];
-}
-
 int fail(int code, const std::string &what) {
   set_error(code, what);
   return code;
@@ -95,12 +93,13 @@ struct spmv_acc_shard {
   struct Chunk {
     int a = 0, b = 0;   // rows of this rank's slice the chunk computes (clipped to m_local)
     int c0 = 0, c1 = 0; // rows of the PADDED slice the chunk's exchange moves (the same on every rank)
-    const int *rp = nullptr;
-    const int *ci = nullptr;
-    const double *v = nullptr;
-    int nnz = 0;
-    int *owned_rp = nullptr; // rebased copy (pipeline > 1)
+    const int *rp = nullptr; // rowptr + a: the chunk as a row sub-range of the shard's arrays (rp[0] = first non-zero of row a, not 0)
+    int nnz_end = 0;         // rowptr[b]: what the library takes as `nnz` of an un-rebased view
   };
+  const int *ci = nullptr;
+  const double *v = nullptr;
+  hipStream_t chunk_stream[2] = {nullptr, nullptr}; // pipeline > 1: the chunks' kernels alternate over these
+  bool prepared[2] = {false, false};                // per beta class: every chunk's plan is built and tuned (spmv_acc_shard_prepare)
   std::vector<Chunk> chunks;
   hipStream_t comm_stream = nullptr;
   std::vector<hipEvent_t> chunk_done;
@@ -143,36 +142,28 @@ int spmv_acc_shard_create(spmv_acc_shard_t *out, void *nccl_comm, int strategy, 
   S->n = n;
   S->nnz = nnz_local;
   S->depth = pipeline < 1 ? 1 : (pipeline > m_pad ? m_pad : pipeline);
-  hipStream_t st = get_stream();
+  S->ci = d_colindex;
+  S->v = d_value;
   bool ok = true;
-  if (S->depth == 1) {
+  const int per = (m_pad + S->depth - 1) / S->depth;
+  std::vector<int> cut; // rows where chunks begin / end, clipped to m_local
+  for (int k = 0; k < S->depth && k * per < m_pad; ++k) {
     spmv_acc_shard::Chunk c;
-    c.a = 0, c.b = m_local, c.c0 = 0, c.c1 = m_pad, c.rp = d_rowptr, c.ci = d_colindex, c.v = d_value, c.nnz = nnz_local;
+    c.c0 = k * per;
+    c.c1 = (k + 1) * per < m_pad ? (k + 1) * per : m_pad;
+    c.a = c.c0 < m_local ? c.c0 : m_local;
+    c.b = c.c1 < m_local ? c.c1 : m_local;
+    c.rp = d_rowptr + c.a;
     S->chunks.push_back(c);
+  }
+  if (S->chunks.size() == 1) {
+    S->chunks[0].nnz_end = nnz_local; // (the whole shard: rowptr[0] = 0 by the entry's contract)
   } else {
-    const int per = (m_pad + S->depth - 1) / S->depth;
-    for (int k = 0; k < S->depth && k * per < m_pad; ++k) {
-      spmv_acc_shard::Chunk c;
-      c.c0 = k * per;
-      c.c1 = (k + 1) * per < m_pad ? (k + 1) * per : m_pad;
-      c.a = c.c0 < m_local ? c.c0 : m_local;
-      c.b = c.c1 < m_local ? c.c1 : m_local;
-      int ends[2] = {0, 0};
-      ok = ok && hipMemcpy(&ends[0], d_rowptr + c.a, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess &&
-           hipMemcpy(&ends[1], d_rowptr + c.b, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
-      if (ok && c.b > c.a) {
-        const int count = c.b - c.a + 1;
-        ok = hipMalloc(reinterpret_cast<void **>(&c.owned_rp), sizeof(int) * static_cast<size_t>(count)) == hipSuccess;
-        if (ok) hipLaunchKernelGGL(rebase_rowptr_kernel, dim3((count + 255) / 256), dim3(256), 0, st, d_rowptr, c.a, count, c.owned_rp);
-      }
-      c.rp = c.owned_rp;
-      c.ci = d_colindex ? d_colindex + ends[0] : nullptr;
-      c.v = d_value ? d_value + ends[0] : nullptr;
-      c.nnz = ends[1] - ends[0];
-      S->chunks.push_back(c);
-    }
-    ok = ok && hipStreamSynchronize(st) == hipSuccess &&
-         hipStreamCreateWithFlags(&S->comm_stream, hipStreamNonBlocking) == hipSuccess &&
+    for (auto &c : S->chunks) // one 4-byte read per chunk, once per shard
+      ok = ok && hipMemcpy(&c.nnz_end, d_rowptr + c.b, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&S->comm_stream, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&S->chunk_stream[0], hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&S->chunk_stream[1], hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&S->step_begin, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&S->arrived, hipEventDisableTiming) == hipSuccess;
     S->chunk_done.resize(S->chunks.size(), nullptr);
@@ -189,12 +180,10 @@ int spmv_acc_shard_create(spmv_acc_shard_t *out, void *nccl_comm, int strategy, 
 
 int spmv_acc_shard_destroy(spmv_acc_shard_t S) {
   if (!S) return kOk;
-  for (auto &c : S->chunks) {
-    if (c.owned_rp) {
-      release_plans(c.owned_rp);
-      (void)hipFree(c.owned_rp);
-    }
-  }
+  if (S->chunks.size() > 1)
+    for (auto &c : S->chunks) release_plans(c.rp); // (the chunk views' plans; the whole-shard plan, keyed on the caller's rowptr, is the caller's to release)
+  for (auto &q : S->chunk_stream)
+    if (q) (void)hipStreamDestroy(q);
   for (auto &e : S->chunk_done)
     if (e) (void)hipEventDestroy(e);
   if (S->step_begin) (void)hipEventDestroy(S->step_begin);
@@ -206,10 +195,35 @@ int spmv_acc_shard_destroy(spmv_acc_shard_t S) {
 
 int spmv_acc_shard_pipeline(spmv_acc_shard_t S) { return S ? static_cast<int>(S->chunks.size()) : 0; }
 
+// Build and tune every chunk's plan for the caller's beta class, so that a step only enqueues: plan building allocates, frees and
+// synchronises (implicit device-wide syncs), which must not happen between the chunk exchanges of a step that other ranks are already
+// in.  Collective-free; every rank calls it before its first step (a step on an unprepared shard still works: the first one then
+// builds what is missing, as a plain SpMV call does).
+int spmv_acc_shard_prepare(spmv_acc_shard_t S, double beta, const double *dx) {
+  if (!S || !dx) return fail(kErrBadArgument, "spmv_acc_shard_prepare: bad argument");
+  int current = -1;
+  if (hipGetDevice(&current) != hipSuccess || current != S->device)
+    return fail(kErrBadArgument, "spmv_acc_shard_prepare: the shard was created on device " + std::to_string(S->device) +
+                                     ", the calling thread's current device is " + std::to_string(current));
+  const int cls = beta != 0.0 ? 1 : 0;
+  hipStream_t st = get_stream();
+  int rc = kOk;
+  for (size_t k = 0; k < S->chunks.size() && rc == kOk; ++k) {
+    const auto &c = S->chunks[k];
+    if (c.b <= c.a) continue;
+    // on the stream the chunk's kernels will use (a plan orders itself behind its previous launches, whatever stream they were on)
+    if (S->chunks.size() > 1) set_stream(S->chunk_stream[k & 1]);
+    rc = spmv_acc_prepare_beta(S->strategy, beta, c.b - c.a, S->n, c.nnz_end, nullptr, c.rp, S->ci, S->v, dx, nullptr);
+  }
+  set_stream(st);
+  if (rc == kOk) S->prepared[cls] = true;
+  return rc;
+}
+
 int spmv_acc_shard_step(spmv_acc_shard_t S, double alpha, double beta, const double *dx, const double *dy_in_local, double *dy_full) {
   if (!S || !dy_full) return fail(kErrBadArgument, "spmv_acc_shard_step: bad argument");
   const Rccl &R = rccl();
-  // a shard belongs to the device that was current when it was made (its chunk arrays, events and second stream live there); a host
+  // a shard belongs to the device that was current when it was made (its events and streams live there); a host
   // thread that drives several shards has to hipSetDevice before each step, and forgetting it would launch on the wrong card
   int current = -1;
   if (hipGetDevice(&current) != hipSuccess || current != S->device)
@@ -218,25 +232,44 @@ int spmv_acc_shard_step(spmv_acc_shard_t S, double alpha, double beta, const dou
   hipStream_t st = get_stream();
   double *own = dy_full + static_cast<size_t>(S->rank) * S->m_pad;
   clear_error();
+  // A rank whose local SpMV fails STILL takes part in every exchange of the step (its peers are already in them: leaving early would
+  // leave them blocked in a collective for ever); the first local error is what the step returns, after the exchanges are enqueued.
+  int first_err = kOk;
+  std::string first_what;
+  auto note = [&](int code, const std::string &what) {
+    if (first_err == kOk) {
+      first_err = code;
+      first_what = what;
+    }
+  };
+  auto note_engine = [&] {
+    if (last_error() != kOk) note(last_error(), last_error_string());
+  };
   if (S->chunks.size() == 1) {
     const auto &c = S->chunks[0];
-    if (S->m_local > 0) run_spmv(S->strategy, 0, alpha, beta, S->m_local, S->n, c.nnz, nullptr, c.rp, c.ci, c.v, dx, own, dy_in_local);
-    if (last_error() != kOk) return last_error();
+    if (S->m_local > 0) run_spmv(S->strategy, 0, alpha, beta, S->m_local, S->n, c.nnz_end, nullptr, c.rp, S->ci, S->v, dx, own, dy_in_local);
+    note_engine();
     // in place (send buffer = this rank's slice of the receive buffer), same stream: behind the kernels that wrote the slice
     const int rc = R.all_gather(own, dy_full, static_cast<size_t>(S->m_pad), kNcclFloat64, S->comm, st);
-    return rc == 0 ? kOk : fail(kErrHip, "spmv_acc_shard_step: ncclAllGather failed (ncclResult " + std::to_string(rc) + ")");
+    if (rc != 0) note(kErrHip, "spmv_acc_shard_step: ncclAllGather failed (ncclResult " + std::to_string(rc) + ")");
+    return first_err == kOk ? kOk : fail(first_err, first_what);
   }
-  // the exchange writes the peers' slices of dy_full: whatever was enqueued before this step (readers of the old vector) first
-  if (hipEventRecord(S->step_begin, st) != hipSuccess || hipStreamWaitEvent(S->comm_stream, S->step_begin, 0) != hipSuccess)
-    return fail(kErrHip, "spmv_acc_shard_step: event failure");
+  // the exchange writes the peers' slices of dy_full, the chunk kernels read x and the old slice: whatever was enqueued before this
+  // step (the producer of x, readers of the old vector) comes first on all three streams
+  bool ev_ok = hipEventRecord(S->step_begin, st) == hipSuccess && hipStreamWaitEvent(S->comm_stream, S->step_begin, 0) == hipSuccess &&
+               hipStreamWaitEvent(S->chunk_stream[0], S->step_begin, 0) == hipSuccess &&
+               hipStreamWaitEvent(S->chunk_stream[1], S->step_begin, 0) == hipSuccess;
   for (size_t k = 0; k < S->chunks.size(); ++k) {
     const auto &c = S->chunks[k];
-    if (c.b > c.a)
-      run_spmv(S->strategy, 0, alpha, beta, c.b - c.a, S->n, c.nnz, nullptr, c.rp, c.ci, c.v, dx, own + c.a,
+    hipStream_t cs = S->chunk_stream[k & 1];
+    if (c.b > c.a && first_err == kOk) {
+      set_stream(cs);
+      run_spmv(S->strategy, 0, alpha, beta, c.b - c.a, S->n, c.nnz_end, nullptr, c.rp, S->ci, S->v, dx, own + c.a,
                dy_in_local ? dy_in_local + c.a : nullptr);
-    if (last_error() != kOk) return last_error();
-    if (hipEventRecord(S->chunk_done[k], st) != hipSuccess || hipStreamWaitEvent(S->comm_stream, S->chunk_done[k], 0) != hipSuccess)
-      return fail(kErrHip, "spmv_acc_shard_step: event failure");
+      set_stream(st);
+      note_engine();
+    }
+    ev_ok = ev_ok && hipEventRecord(S->chunk_done[k], cs) == hipSuccess && hipStreamWaitEvent(S->comm_stream, S->chunk_done[k], 0) == hipSuccess;
     if (S->world > 1) {
       const size_t count = static_cast<size_t>(c.c1 - c.c0);
       int rc = R.group_start();
@@ -246,13 +279,12 @@ int spmv_acc_shard_step(spmv_acc_shard_t S, double alpha, double beta, const dou
         if (rc == 0) rc = R.recv(dy_full + static_cast<size_t>(src) * S->m_pad + c.c0, count, kNcclFloat64, src, S->comm, S->comm_stream);
       }
       const int rc_end = R.group_end();
-      if (rc != 0 || rc_end != 0)
-        return fail(kErrHip, "spmv_acc_shard_step: grouped ncclSend / ncclRecv failed (ncclResult " + std::to_string(rc ? rc : rc_end) + ")");
+      if (rc != 0 || rc_end != 0) note(kErrHip, "spmv_acc_shard_step: grouped ncclSend / ncclRecv failed (ncclResult " + std::to_string(rc ? rc : rc_end) + ")");
     }
   }
-  if (hipEventRecord(S->arrived, S->comm_stream) != hipSuccess || hipStreamWaitEvent(st, S->arrived, 0) != hipSuccess)
-    return fail(kErrHip, "spmv_acc_shard_step: event failure");
-  return kOk;
+  ev_ok = ev_ok && hipEventRecord(S->arrived, S->comm_stream) == hipSuccess && hipStreamWaitEvent(st, S->arrived, 0) == hipSuccess;
+  if (!ev_ok) note(kErrHip, "spmv_acc_shard_step: event failure");
+  return first_err == kOk ? kOk : fail(first_err, first_what);
 }
 
 } // extern "C"

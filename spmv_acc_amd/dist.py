@@ -104,6 +104,9 @@ class RowShardedSpmv:
         self._gpu = torch.device(device).type == "cuda"
         self.own_stream = bool(own_stream)
         self.compute_stream = torch.cuda.Stream(device=device) if self._gpu else None
+        # the pipelined step alternates its chunks' kernels over two streams: consecutive chunks are independent, and on ONE stream
+        # each kernel waits for its predecessor's last wavefront (one rank, headline matrix, C = 8: 0.245 ms against 0.156 for C = 1)
+        self.chunk_streams = [self.compute_stream, torch.cuda.Stream(device=device)] if self._gpu else None
         self.spmv_done = None  # event behind the latest local SpMV (GPU only)
         self.exchange_issued_after_spmv = None  # for tests: did the latest exchange wait for that event?
 
@@ -123,18 +126,23 @@ class RowShardedSpmv:
         return [(min(c * per, self.pad), min((c + 1) * per, self.pad)) for c in range(depth) if c * per < self.pad]
 
     def _chunk_arrays(self, depth: int):
-        """Per-chunk CSR views of this rank's slice: rebased rowptr (a copy, made once per depth), colindex / values as views."""
+        """Per-chunk CSR views of this rank's slice.  A chunk is a row SUB-RANGE of the slice's own arrays: rowptr[a : b + 1] as a
+        view (so its first entry is the chunk's first non-zero, not 0), the whole colindex / value arrays, nnz = rowptr[b] -- the
+        library's kernels accept that form (tests/test_gpu_parity.py::test_row_shard_without_rebasing), so nothing is copied or
+        rebased (round 3 made one rebased rowptr copy per chunk)."""
         if depth not in self._chunks:
             out = []
+            ends = None
             for c0, c1 in self.chunk_bounds(depth):
                 a, b = min(c0, self.m_local), min(c1, self.m_local)
                 if depth == 1:
                     out.append((a, b, self.rowptr, self.cols, self.vals, self.nnz_local, self.h_rowptr))
                     continue
-                s, e = int(self.rowptr[a]), int(self.rowptr[b])
-                rp = (self.rowptr[a: b + 1] - self.rowptr[a])
-                rp = rp.contiguous() if hasattr(rp, "contiguous") else np.ascontiguousarray(rp)
-                out.append((a, b, rp, self.cols[s:e], self.vals[s:e], e - s, None))
+                if ends is None:  # every chunk's end offset in ONE device read
+                    cuts = sorted({min(c, self.m_local) for bounds in self.chunk_bounds(depth) for c in bounds})
+                    vals_at = self.rowptr[cuts] if not hasattr(self.rowptr, "cpu") else self.rowptr[self.torch.as_tensor(cuts, device=self.rowptr.device)].cpu()
+                    ends = {c: int(v) for c, v in zip(cuts, vals_at)}
+                out.append((a, b, self.rowptr[a: b + 1], self.cols, self.vals, ends[b], None))
             self._chunks[depth] = out
         return self._chunks[depth]
 
@@ -189,13 +197,15 @@ class RowShardedSpmv:
                 if not solo:
                     works = self._issue_exchange(cur, group)
             else:
-                cs.wait_stream(cur_stream)
+                for q in self.chunk_streams:
+                    q.wait_stream(cur_stream)
                 self.wait()  # (the pipelined exchange starts during this step: the previous one must have ended)
                 events = []
-                with torch.cuda.stream(cs):
-                    for ch in chunks:  # all kernels go out at once, back to back on the compute stream
+                for k, ch in enumerate(chunks):  # all kernels go out at once, alternating over the two chunk streams
+                    q = self.chunk_streams[k & 1]
+                    with torch.cuda.stream(q):
                         local(ch)
-                        events.append(cs.record_event())
+                        events.append(q.record_event())
                 self.spmv_done = events[-1]
                 for (c0, c1), ev in zip(self.chunk_bounds(depth), events):
                     cur_stream.wait_event(ev)  # chunk c travels as soon as ITS kernel has finished, while chunk c+1 computes

@@ -10,6 +10,11 @@
 //   mode 2: slab-routed, gathers with popcount(other bits) > T non-temporal (hints on top), T = 8
 //   mode 3: slab-routed by (b + 1) & 7 ... i.e. the SAME routing shifted by one block: control, must equal mode 1 if placement is by b & 7
 //   mode 4: "slab" taken from (blockIdx / 8) & 7: every XCD sees all eight slabs again -- control for the placement assumption
+//   round 4 -- how fast could gathers go if EVERY one hit the XCD's L2 (the ceiling of any finer slabbing):
+//   mode 5: 64 windows of 4 MB (2^19 columns); block b gathers only inside window 8 * round + (b & 7), round = which eighth of its class's blocks it is in:
+//           at any time the eight XCDs work in eight different windows, each window is read by one XCD only
+//   mode 6: the same 64 windows walked one after the other by all XCDs together (64 sequential passes: every window enters all eight L2s)
+//   mode 7: mode 5 with windows of 2 MB (128 windows, 16 rounds)
 // Usage: xcd_slab_gather_bench [Mgathers=512]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -30,9 +35,17 @@ __device__ __forceinline__ int draw(unsigned long long seed, long long i) {
 
 // element i belongs to block i / 2048 of the consuming kernel (512 lanes-steps x 4)
 __global__ void gen(int *idx, double *val, long long n, unsigned long long seed, int route) {
+  const long long nblk = n / 2048;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
     int c = draw(seed, i);
     const long long blk = i / 2048;
+    if (route == 5 || route == 7) {
+      const int wbits = route == 5 ? 19 : 18, rounds = route == 5 ? 8 : 16;
+      const long long per_class = (nblk + 7) / 8;
+      const int round = static_cast<int>(((blk >> 3) * rounds) / per_class);
+      c = (c & ((1 << wbits) - 1)) | ((round * 8 + static_cast<int>(blk & 7)) << wbits);
+    }
+    if (route == 6) c = (c & ((1 << 19) - 1)) | (static_cast<int>((blk * 64) / nblk) << 19);
     if (route == 1) c = (c & ~0x70) | (static_cast<int>(blk & 7) << 4);
     if (route == 3) c = (c & ~0x70) | (static_cast<int>((blk + 1) & 7) << 4);
     if (route == 4) c = (c & ~0x70) | (static_cast<int>((blk >> 3) & 7) << 4);
@@ -98,6 +111,9 @@ int main(int argc, char **argv) {
       {"slab-routed, popcount(other bits) > 10 non-temporal", 1, 10},
       {"control: slab (b + 1) & 7 (same placement, shifted)", 3, 0},
       {"control: slab (b / 8) & 7 (every XCD sees every slab)", 4, 0},
+      {"64 windows of 4 MB, eight at a time, one per XCD (all gathers L2 hits)", 5, 0},
+      {"64 windows of 4 MB one after the other, all XCDs in the same window", 6, 0},
+      {"128 windows of 2 MB, eight at a time, one per XCD", 7, 0},
   };
   for (auto &m : modes) {
     hipLaunchKernelGGL(gen, dim3(8192), dim3(256), 0, 0, d_idx, d_val, n, 0xC4ULL, m.route);
