@@ -90,7 +90,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kT_slab_segments, kT_vector_target, kT_hub_rows, kT_hub_min_len, kT_hub_window_kb, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kT_slab_segments, kT_vector_target, kT_first_call_budget, kT_later_call_budget, kT_slab_whole_below, kTunableCount
 };
 #ifdef FLAT_SEGMENT_SUM_REDUCE
 constexpr int kFlatReduceBuilt = 1;
@@ -189,14 +189,28 @@ Tunable g_tunables[] = {
     {"vector_target", 1900, 1900}, // vector-row tile kernel: products a workgroup's rows should bring to its 2048-product tile (the row-block family's
                                // `rowblock_target` went to 1500 in round 3; this kernel, with two rows per lane group, keeps the fuller tile:
                                // 1900 against 1500 is 3-5.5 % faster on four of five sweep stand-ins, equal on the fifth)
-    {"hub_rows", -1, -1},      // second level of the slab passes (k_hub.hip, round 4): the rows of >= hub_min_len non-zeros leave the coarse slab lists and
-                               // are cut into runs over column windows of hub_window_kb of x (one window fits an XCD's L2); one launch walks those runs
-                               // window by window, one merge kernel adds a hub row's partial sums in window order.  -1 / 1 = with the slab passes
-                               // (whenever they are built), 0 = off (round 3's passes alone)
-    {"hub_min_len", 128, 128}, // a row is a hub from this many non-zeros (a row of d non-zeros over W windows yields ~min(d, W) runs: windows pay where d >> W)
-    {"hub_window_kb", 4096, 4096}, // KB of x per column window (an XCD's L2 is 4 MB)
+    {"first_call_budget", 20, 20}, // what the FIRST call on a matrix may spend on per-matrix timings, in SpMV-equivalents (wall time since the call began against
+                               // N x the first trial launch it measured).  Once it is spent the call finishes by RULE -- every choice still open takes the
+                               // `deterministic` rule for now and stays open -- and the following calls resume the timings, `later_call_budget`
+                               // SpMV-equivalents each, until everything is settled.  0 = unbounded (rounds 1-3: 64 SpMVs' worth on the headline matrix).
+                               // spmv_acc_prepare / spmv_acc_prepare_beta are always unbounded: they exist to pay for everything up front
+    {"later_call_budget", 2, 2},   // see first_call_budget
+    {"slab_whole_below", 32, 32}, // slab passes, two-class form (round 4): rows of fewer non-zeros than this are not cut by column slab at all -- each is ONE run,
+                               // all columns, in a pass of its own after the S slab passes.  A row of d non-zeros gives ~min(d, 5.5) runs at S = 8; on R-MAT 25
+                               // the rows below 32 non-zeros are 95 % of the rows, 12 % of the non-zeros and 35 M of the 45 M runs, and every run of one or two
+                               // non-zeros is a 12-B list entry, a y read-modify-write and a part-used line of each stream: 5.30 -> 5.19 ms, first call 152 ->
+                               // 135 ms (thresholds 8 / 16 / 24 / 32 / 48 / 64 / 128 / 256: 5.33 / 5.28 / 5.19 / 5.19 / 5.21 / 5.25 / 5.29 / 5.79,
+                               // profiles/r04_rmat25_hub_windows_and_two_class.txt); 0 = every row is cut (round 3)
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
+// (the count alone does not catch two entries in the wrong order -- round 4 ran an afternoon with first_call_budget reading slab_whole_below's
+// value: the table's last names are checked against their ids once, at the first tunable lookup)
+inline bool tunable_order_ok() {
+  return std::strcmp(g_tunables[kT_first_call_budget].name, "first_call_budget") == 0 && std::strcmp(g_tunables[kT_later_call_budget].name, "later_call_budget") == 0 &&
+         std::strcmp(g_tunables[kT_slab_whole_below].name, "slab_whole_below") == 0 && std::strcmp(g_tunables[kT_vector_target].name, "vector_target") == 0 &&
+         std::strcmp(g_tunables[kT_slab_segments].name, "slab_segments") == 0 && std::strcmp(g_tunables[kT_deterministic].name, "deterministic") == 0 &&
+         std::strcmp(g_tunables[kT_zigzag].name, "zigzag") == 0 && std::strcmp(g_tunables[kT_xcd_remap].name, "xcd_remap") == 0;
+}
 void apply_env_tunables();
 inline int tun(TunableId id) { return g_tunables[id].val; } // apply_env_tunables() has run: run_spmv calls it first
 
@@ -206,6 +220,10 @@ namespace {
 // SPMV_ACC_TUNABLES="validate=1,flat_finish=0": initial values for a process that cannot call spmv_acc_set_tunable
 // (the reference's executables linked against this library).  Read once, before the first lookup.
 void apply_env_tunables_once() {
+  if (!tunable_order_ok()) {
+    std::fprintf(stderr, "spmv_acc: internal error: tunable table and TunableId disagree\n");
+    std::abort();
+  }
   if (const char *det = std::getenv("SPMV_ACC_DETERMINISTIC"))
     if (*det && *det != '0') g_tunables[kT_deterministic].val = g_tunables[kT_deterministic].def = 1;
   const char *env = std::getenv("SPMV_ACC_TUNABLES");
@@ -532,6 +550,8 @@ struct Plan {
   std::mutex mu;                   // held by run_spmv for the whole call: plan fields, carry buffers and tunings are per matrix
   unsigned long long calls = 0;    // SpMV calls served by this plan (the first one builds and tunes it)
   unsigned launches = 0;           // tile-kernel launches so far (parity = walking direction, tunable zigzag)
+  double trial_ms = 0.0;           // a trial launch of this matrix as the per-matrix timings measured it: prices later calls' tuning budget
+  bool tuning_open = true;         // some per-matrix timing was deferred (or has not been reached yet): later calls may resume it
   CsrDev A;
   int guard_slot = -1;
   bool have_samples = false;
@@ -551,6 +571,9 @@ struct Plan {
   // adaptive's timed choice per beta class ([0]: beta == 0, [1]: y is read too -- the ranking flips between the classes where rows
   // hold one or two non-zeros): 0 fixed row blocks, 1 row-block-plus, 2 flat; -1 not timed yet
   int adaptive_family[2] = {-1, -1};
+  float adaptive_ms[2][3] = {{1e30f, 1e30f, 1e30f}, {1e30f, 1e30f, 1e30f}}; // the comparison's timings per beta class (fixed row blocks, row-block-plus, flat)
+  bool adaptive_provisional[2] = {false, false}; // the choice rests on the first look only (or on the families timed so far): later calls complete it
+  bool adaptive_skipped[2][3] = {{false, false, false}, {false, false, false}}; // a family that is not a candidate on this matrix (rescued row blocks)
   RowDigest digest;             // row-block family: 1-byte row lengths + per-block bases (built for digest.rpb rows per block)
   // flat
   int flat_tiles = -1;
@@ -630,24 +653,9 @@ struct Plan {
   std::vector<int *> seg_row, seg_begin, seg_vptr, seg_blk;
   std::vector<int> seg_entries, seg_blocks, seg_pieces; // seg_pieces[s] != 0: the slab holds runs cut into pieces (merge kernel needed)
   double *d_seg_ys = nullptr; // one partial sum per entry of the longest list
-  // hub rows through L2-sized column windows (k_hub.hip): built together with the slab lists (which then skip the hub rows)
-  int seg_hub_from = 0;        // the coarse lists were built skipping rows of this many non-zeros or more (0: none skipped)
   int seg_rest_below = 0;      // two-class form: rows of fewer non-zeros than this are whole runs in the last plane (0: every row is cut by slab)
-  int hub_rows = 0, hub_windows = 0, hub_width = 0, hub_groups = 0, hub_entries = 0, hub_blocks = 0;
-  int *d_hub_row = nullptr, *d_hub_ent = nullptr, *d_hub_begin = nullptr, *d_hub_vptr = nullptr, *d_hub_blk = nullptr, *d_hub_cell = nullptr;
-  double *d_hub_ys = nullptr;
-  void free_hub() {
-    for (int **q : {&d_hub_row, &d_hub_ent, &d_hub_begin, &d_hub_vptr, &d_hub_blk, &d_hub_cell}) {
-      if (*q) (void)hipFree(*q);
-      *q = nullptr;
-    }
-    if (d_hub_ys) (void)hipFree(d_hub_ys);
-    d_hub_ys = nullptr;
-    hub_rows = hub_windows = hub_width = hub_groups = hub_entries = hub_blocks = 0;
-  }
   void free_segments() {
-    free_hub();
-    seg_hub_from = seg_rest_below = 0;
+    seg_rest_below = 0;
     for (auto *list : {&seg_row, &seg_begin, &seg_vptr, &seg_blk}) {
       for (int *q : *list)
         if (q) (void)hipFree(q);
@@ -1294,12 +1302,41 @@ int policy_for(const Plan &p, int fam) {
   for (int f = 0; f < kFamilyCount; ++f)
     if (p.stream_policy[f][c] >= 0) return p.stream_policy[f][c];
   if (p.stream_policy[fam][c ^ 1] >= 0) return p.stream_policy[fam][c ^ 1];
-  return kStreamPolicyNt;
+  return static_cast<long long>(p.A.nnz) <= 8LL * p.A.m ? kStreamPolicyNt : kStreamPolicyDefault; // (nothing measured yet: the rule)
 }
 
 // While adaptive compares the families it runs each with its default sub-choices (flat: carries + fix-up unless pinned;
 // row-block-plus: MIN_NNZ 1536); the family that wins refines its own sub-choice on its next call.
 thread_local bool t_coarse_tuning = false;
+thread_local bool t_no_policy_timing = false; // run_plus's early slab decision: the row-block-plus kernel runs under the rule's cache policy, nothing is timed for it
+
+// ---- plan-time budget (tunables first_call_budget / later_call_budget) ---------------------------------------------------------------
+// The reference pays a fixed, small preprocessing cost per call (hip-flat/flat.cpp:39-44: one malloc + memset + break-point kernel); a plan
+// that spends 64 SpMVs' worth of trial launches on its first call gives that advantage back to short solves.  So the trial launches of
+// a call are bounded: run_spmv notes when the call began and how many SpMV-equivalents it may spend; the first trial launch measured in the
+// call (TuneTimer) turns that into milliseconds; every timing PHASE asks defer_tuning() before it starts and, when the budget is
+// spent, leaves its choice open (the `deterministic` rule serves the call) for a later call to settle.  Structural passes are not
+// deferred -- a call cannot run without them -- but their time counts as spent.
+thread_local std::chrono::steady_clock::time_point t_call_began;
+thread_local double t_budget_spmvs = 0.0; // SpMV-equivalents this call may spend; <= 0: unbounded
+thread_local double t_budget_ms = -1.0;   // the same in milliseconds, known once a trial launch has been measured in this call (or from the plan)
+thread_local bool t_tuning_deferred = false; // some phase of this call left its choice open
+thread_local float t_first_trial_ms = 0.f;   // the first trial launch this call measured (0: none)
+thread_local int t_unbounded_tuning = 0;     // > 0: this thread is inside spmv_acc_prepare (UnboundedTuningScope): no budget
+inline bool defer_tuning() {
+  if (t_budget_spmvs <= 0.0 || t_budget_ms < 0.0) return false;
+  const double spent = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call_began).count();
+  // (a phase is atomic -- its candidates must be measured alike -- and costs 6-15 launches plus whatever structure it builds first, so phases only
+  // START during the first half of the budget: the overshoot of the last one then lands near the whole)
+  if (spent < 0.5 * t_budget_ms) return false;
+  t_tuning_deferred = true;
+  return true;
+}
+inline bool by_rule() { return tun(kT_deterministic) != 0 || defer_tuning(); }
+inline double budget_spent_fraction() { // 0 while the call is unbounded or its budget has no price yet
+  if (t_budget_spmvs <= 0.0 || t_budget_ms <= 0.0) return 0.0;
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call_began).count() / t_budget_ms;
+}
 
 // SPMV_ACC_TUNE_LOG=1: every per-matrix timing and the choice it led to, one line each on stderr (what was measured, not only
 // what was kept -- for users who want to pin a choice, and for finding out why a plan settled where it did).
@@ -1373,23 +1410,40 @@ struct TuneTimer {
     reset_ptr = ptr;
     reset_bytes = bytes;
   }
-  template <typename F> bool time(hipStream_t st, F &&fn, float *ms_per_launch) {
+  // at_least: launches a decision kept for the life of the plan rests on, whatever they cost (a launch of >= 4 ms is otherwise timed once)
+  template <typename F> bool time(hipStream_t st, F &&fn, float *ms_per_launch, int at_least = 1) {
     if (!ok) return false;
     float first = 0.f;
     (void)hipEventRecord(e0, st);
     fn();
     (void)hipEventRecord(e1, st);
     if (!hip_ok(hipEventSynchronize(e1), "sync tune") || !hip_ok(hipEventElapsedTime(&first, e0, e1), "elapsed tune")) return false;
+    if (t_first_trial_ms <= 0.f) t_first_trial_ms = first;
+    if (t_budget_spmvs > 0.0 && t_budget_ms < 0.0) t_budget_ms = t_budget_spmvs * static_cast<double>(first); // (the call's first trial launch prices its budget)
     // (short kernels time noisily and cost nothing: more launches; from 0.1 ms on one more warm-up and three timed launches
     // separate candidates that differ by a few per cent -- the per-matrix timings of a 0.16 ms SpMV were 2/3 of a 21 ms first call)
     // (a launch of several milliseconds -- R-MAT scale 25: 7-8 ms, eighteen candidate launches = 145 ms of a 300 ms first call -- is its own
     // steady state: what the previous launch left in the caches is a fraction of a per cent of it.  One launch per candidate.)
     if (first >= 4.0f) {
+      // (the first launch of a candidate runs right behind the build of its tables, the other candidate's state still in the caches:
+      // a decision that is kept and persisted gets a second sample, the smaller counts)
+      for (int extra = 1; extra < at_least; ++extra) {
+        float again = 0.f;
+        if (reset_ptr && tun(kT_tune_protocol) == 1) (void)hipMemsetAsync(reset_ptr, 0, reset_bytes, st);
+        (void)hipEventRecord(e0, st);
+        fn();
+        (void)hipEventRecord(e1, st);
+        if (!hip_ok(hipEventSynchronize(e1), "sync tune") || !hip_ok(hipEventElapsedTime(&again, e0, e1), "elapsed tune")) return false;
+        first = again < first ? again : first;
+      }
       *ms_per_launch = first;
       return true;
     }
-    const int warm = first < 0.1f ? 2 : (first < 2.0f ? 1 : 0);
-    const int timed = first < 0.1f ? 5 : (first < 0.5f ? 3 : (first < 2.0f ? 2 : 1));
+    // (under a call's tuning budget -- every call but spmv_acc_prepare's -- launches of >= 0.1 ms take no extra warm-up, the launch above was one, and
+    // two timed launches instead of three: 3 launches per candidate instead of 5; the candidates of one phase are still measured alike)
+    const bool lean = t_budget_spmvs > 0.0 && first >= 0.1f;
+    const int warm = first < 0.1f ? 2 : (first < 2.0f && !lean ? 1 : 0);
+    const int timed = first < 0.1f ? 5 : (first < 0.5f ? (lean ? 2 : 3) : (first < 2.0f ? 2 : 1));
     for (int w = 0; w < warm; ++w) fn();
     if (reset_ptr && tun(kT_tune_protocol) == 1) {
       for (int t = 0; t < timed; ++t) {
@@ -1403,7 +1457,7 @@ struct TuneTimer {
       for (int t = 0; t < timed; ++t)
         if (!hip_ok(hipEventElapsedTime(&each[t], per[2 * t], per[2 * t + 1]), "elapsed tune")) return false;
       std::sort(each, each + timed);
-      *ms_per_launch = each[timed / 2]; // median (of 5, 3, 2 -> the larger, or 1)
+      *ms_per_launch = each[timed == 2 ? 0 : timed / 2]; // median of 5 or 3; of two the smaller
       return true;
     }
     (void)hipEventRecord(e0, st);
@@ -1422,7 +1476,7 @@ struct TuneTimer {
 template <typename Launch> bool autotune_policy(Plan &p, int fam, hipStream_t st, Launch &&launch) {
   const int cls = t_beta_class;
   if (p.stream_policy[fam][cls] >= 0) return true;
-  if (tun(kT_stream_plain) >= 0 || tun(kT_deterministic)) return true; // pinned (A/B runs) / by rule: policy_for decides, nothing is recorded
+  if (tun(kT_stream_plain) >= 0 || by_rule() || t_no_policy_timing) return true; // pinned (A/B runs) / by rule (or the call's tuning budget is spent): policy_for decides, nothing is recorded
   // A matrix prepared in one beta class (spmv_acc_prepare: beta = 1) and then CAPTURED into a hipGraph in the other: timing would
   // synchronise inside the capture.  The call runs under the policy the other class measured (policy_for's fallback) and this
   // class is timed by the first call made outside a capture.
@@ -1549,6 +1603,10 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
     F.needs_fixup = F.tuned_fixup[cls];
     return true;
   }
+  if (!t_capturing && defer_tuning()) { // the call's tuning budget is spent: the rule for now, timed by a later call
+    F.needs_fixup = false;
+    return true;
+  }
   if (t_capturing) { // not timed in this class yet and no timing inside a capture: the other class' choice, else finish in the tile
     F.needs_fixup = F.mode_tuned[cls ^ 1] ? F.tuned_fixup[cls ^ 1] : false;
     return true;
@@ -1579,7 +1637,7 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
 // per matrix and keep the fastest.  The other tile size gets its own break points / carries; its cut rows are finished in
 // the tile whenever that is legal (no second launch: what wins on short kernels).
 bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
-  if (p.flat_geometry_tuned || tun(kT_col16) > 0 || flat_segment_sum() || t_capturing || tun(kT_deterministic)) return true;
+  if (p.flat_geometry_tuned || tun(kT_col16) > 0 || flat_segment_sum() || t_capturing || by_rule()) return true;
   if (p.A.nnz >= kFlatSmallNnz || p.flat.ntiles <= 1) {
     p.flat_geometry_tuned = true;
     return true;
@@ -1748,6 +1806,7 @@ template <class Launch> bool autotune_hint(Plan &p, int fam, hipStream_t st, Lau
     p.A.cold = p.d_cold;
     return true;
   }
+  if (p.hint_use[fam] < 0 && defer_tuning()) return true; // (plain gathers for now; timed by a later call)
   if (p.hint_use[fam] < 0) {
     ++t_plan_work;
     double *scratch = nullptr;
@@ -1808,7 +1867,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
       pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
       if (t_capturing ? (p.rowblock_ok == 1 && p.rowblock_rpb == rpb) : (probe_rowblock(p, rpb, st) && p.rowblock_ok == 1))
         return run_rowblock(st, p, nullptr, alpha, beta, x, y, false, 0);
-    } else if (p.flat_rowblock_choice < 0 && !t_capturing && !tun(kT_deterministic)) {
+    } else if (p.flat_rowblock_choice < 0 && !t_capturing && !by_rule()) {
       int vec = 1, rpb = kThreads;
       pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
       if (!probe_rowblock(p, rpb, st)) return false;
@@ -2038,7 +2097,7 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
   // (inside a capture: the row blocks the plan already holds, whatever block size they were analysed with; none yet -> refused)
   if (t_capturing) return (p.plus_blocks >= 0 || ensure_plus(p, h_rowptr, st, 1536)) && autotune_policy(p, kFamPlus, st, launch);
   // (coarse: 1024 where the balance probe found hub rows -- the block size that wins on power-law matrices -- else 1536)
-  if (t_coarse_tuning)
+  if (t_coarse_tuning || defer_tuning()) // (budget spent: the coarse choice for now, the three block sizes are timed by a later call)
     return ensure_plus(p, h_rowptr, st, p.rowblock_ok == 0 ? kPlusMinNnz : 1536) && autotune_policy(p, kFamPlus, st, launch);
   // first call on this matrix: cache policy on the middle candidate, then the three block sizes under that policy
   if (!ensure_plus(p, h_rowptr, st, 1536) || !autotune_policy(p, kFamPlus, st, launch)) return false;
@@ -2077,10 +2136,6 @@ void run_segments(hipStream_t st, Plan &p, double alpha, double beta, const doub
     launch_segment_tiles(st, p.seg_blocks[s], alpha, p.seg_blk[s], p.seg_row[s], p.seg_begin[s], p.seg_vptr[s], p.A.ci, p.A.v, x, p.d_seg_ys, y);
     if (p.seg_pieces[s]) launch_segment_merge(st, p.seg_entries[s], p.seg_row[s], p.d_seg_ys, y);
   }
-  if (p.hub_entries > 0) { // the hub rows: one launch over their runs, window by window; then their partial sums, in window order, into y
-    launch_segment_tiles(st, p.hub_blocks, alpha, p.d_hub_blk, nullptr, p.d_hub_begin, p.d_hub_vptr, p.A.ci, p.A.v, x, p.d_hub_ys, y);
-    launch_hub_merge(st, p.hub_rows, p.hub_windows, p.hub_groups, p.d_hub_cell, p.d_hub_ent, p.d_hub_ys, p.d_hub_row, y);
-  }
 }
 // automatic mode: slabs of about 32 MB of x (R-MAT scale 25, x = 256 MB, S = 4 / 8 / 12 / 16: 5.92 / 5.31 / 5.59 / 6.08 ms, 7.27 without;
 // scale 24, x = 128 MB, S = 4 / 8: 2.37 / 2.59 ms, 3.21 without)
@@ -2091,64 +2146,99 @@ int seg_auto_slabs(int n) {
 
 bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y) {
   p.A.cold = nullptr; // (the prepare timings run without hints)
-  if (!run_plus_prepare(p, h_rowptr, st, x)) return false;
   auto launch_here = [&](double a, double b, double *yy) {
     launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk_tiles), policy_for(p, kFamPlus),
                 p.d_ppartial, a, b, x, yy, next_reverse(p));
   };
-  if (!autotune_hint(p, kFamPlus, st, [&](double *ys) { launch_here(1.0, trial_beta(), ys); })) return false;
-  // Where the column census found a hot set (power-law columns, x far beyond the L2s) this kernel is bound by gathers that miss:
-  // the slab passes over run lists (k_segment.hip) are built once and timed against it, the faster stays.
-  if (tun(kT_slab_segments) < 0 && p.hint_state == 1 && !t_in_slab) {
-    // (also while adaptive is timing its kernel families: row-block-plus is then timed as what it will run -- on R-MAT 25 the one-kernel
-    // path beats flat by 0.5 % only, 7.26 against 7.29 ms, and a family choice made on that would never meet the 5.3 ms of the passes)
-    if (p.seg_choice < 0 && !t_capturing && !tun(kT_deterministic)) {
-      // the lists are an optimisation: a matrix that leaves no room for them (or for the build's S x (m + 1) temporaries) keeps the
-      // one-kernel path instead of failing the SpMV
-      const int S_auto = seg_auto_slabs(p.A.n);
+  // Builds the run lists (once) and times the slab passes against this kernel as it stands; ms[0] row-block-plus, ms[1] the passes.
+  // Returns false on an error; *timed says whether both timings exist (no room for the lists / rows not ordered: they do not).
+  auto time_against_segments = [&](float ms[2], bool *timed) {
+    *timed = false;
+    // the lists are an optimisation: a matrix that leaves no room for them (or for the build's S x (m + 1) temporaries) keeps the
+    // one-kernel path instead of failing the SpMV
+    const int S_auto = seg_auto_slabs(p.A.n);
+    if (p.seg_state < 0) {
       size_t free_b = 0, total_b = 0;
-      const size_t build_bytes = (2 * static_cast<size_t>(S_auto) + 2) * (static_cast<size_t>(p.A.m) + 1) * sizeof(int) + (static_cast<size_t>(p.A.nnz) / 4) * 12;
+      const size_t build_bytes = (2 * static_cast<size_t>(S_auto) + 4) * (static_cast<size_t>(p.A.m) + 1) * sizeof(int) + (static_cast<size_t>(p.A.nnz) / 4) * 12;
       const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 2 * build_bytes;
       (void)hipGetLastError();
-      p.seg_choice = 0;
       if (room && last_error_code_only() == kOk && !ensure_segments(p, S_auto, st)) {
         (void)hipGetLastError();
         tune_log("m %d nnz %d: slab_segments: the run lists could not be built (%s), row-block-plus stays", p.A.m, p.A.nnz, last_error_string());
         clear_error();
         p.free_segments();
       }
-      if (p.seg_state == 1) {
-        ++t_plan_work;
-        double *scratch = nullptr;
-        if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
-        TuneTimer timer;
-        timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
-        bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
-        float ms[2] = {0.f, 0.f};
-        const double *keep_yin = p.A.yin;
-        p.A.yin = nullptr; // (the trial runs update the scratch vector in place)
-        ok = ok && timer.time(st, [&] { launch_here(1.0, trial_beta(), scratch); }, &ms[0]) &&
-             timer.time(st, [&] { run_segments(st, p, 1.0, trial_beta(), x, scratch); }, &ms[1]);
-        p.A.yin = keep_yin;
-        if (!ok) return false;
-        p.seg_choice = ms[1] < 0.95f * ms[0] ? 1 : 0;
-        tune_log("m %d nnz %d beta class %d: row-block-plus %.2f us, %d column-slab passes over run lists %.2f us -> %s", p.A.m, p.A.nnz,
-                 t_beta_class, ms[0] * 1e3f, seg_auto_slabs(p.A.n), ms[1] * 1e3f, p.seg_choice ? "slab passes" : "row-block-plus");
-      }
-      if (p.seg_choice == 0) p.free_segments(); // (the lists of a matrix that does not use them: 12 B per run back)
     }
-    if (p.seg_choice == 1) {
-      // (a plan that adopted the choice from the tune cache builds its lists here; inside a capture only lists that exist are used)
-      if (p.seg_state != 1 && !t_capturing && last_error_code_only() == kOk && !ensure_segments(p, seg_auto_slabs(p.A.n), st)) {
-        (void)hipGetLastError(); // (no room for the lists this time: the one-kernel path)
-        clear_error();
-        p.free_segments();
-        p.seg_choice = 0;
-      }
-      if (p.seg_state == 1) {
-        run_segments(st, p, alpha, beta, x, y);
-        return true;
-      }
+    if (p.seg_state != 1) return true;
+    ++t_plan_work;
+    double *scratch = nullptr;
+    if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
+    TuneTimer timer;
+    timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
+    bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
+    const double *keep_yin = p.A.yin;
+    p.A.yin = nullptr; // (the trial runs update the scratch vector in place)
+    ok = ok && timer.time(st, [&] { launch_here(1.0, trial_beta(), scratch); }, &ms[0], /*at_least=*/2) &&
+         timer.time(st, [&] { run_segments(st, p, 1.0, trial_beta(), x, scratch); }, &ms[1], /*at_least=*/2);
+    p.A.yin = keep_yin;
+    *timed = ok;
+    return ok;
+  };
+  const bool slabs_auto = tun(kT_slab_segments) < 0 && !t_in_slab;
+  // Power-law columns (the column census finds a hot set, x far beyond the L2s): this kernel is bound by gathers that miss, and the slab
+  // passes over run lists (k_segment.hip) usually replace it.  So the passes are decided FIRST, against this kernel in its COARSE
+  // configuration -- the rule's cache policy and block size, no hints: nothing timed for it -- and the kernel's own choices (three block
+  // sizes, three cache policies, hints: eight trial launches of 7-8 ms each on R-MAT 25, 60 of the 145 ms its first call took) are only
+  // timed when the passes do not win clearly.  Clearly = by 15 %: tuned and hinted, this kernel gains up to ~12 % on its coarse form.
+  if (slabs_auto && p.seg_choice < 0 && !t_capturing && !by_rule() && tun(kT_gather_hint) != 0) {
+    if (!ensure_hint(p, st)) return false;
+    if (p.hint_state == 1) {
+      const bool was_coarse = t_coarse_tuning;
+      t_coarse_tuning = t_no_policy_timing = true;
+      const bool prepared = run_plus_prepare(p, h_rowptr, st, x);
+      t_coarse_tuning = was_coarse;
+      t_no_policy_timing = false;
+      if (!prepared) return false;
+      float ms[2] = {0.f, 0.f};
+      bool timed = false;
+      if (!time_against_segments(ms, &timed)) return false;
+      if (timed && ms[1] < 0.85f * ms[0]) p.seg_choice = 1;
+      if (timed)
+        tune_log("m %d nnz %d beta class %d: row-block-plus (coarse) %.2f us, %d column-slab passes over run lists %.2f us -> %s", p.A.m, p.A.nnz, t_beta_class,
+                 ms[0] * 1e3f, seg_auto_slabs(p.A.n), ms[1] * 1e3f, p.seg_choice == 1 ? "slab passes" : "not decided: the kernel is tuned first");
+      if (!timed) p.seg_choice = 0;
+    }
+  }
+  if (slabs_auto && p.seg_choice == 1) {
+    // (a plan that adopted the choice from the tune cache builds its lists here; inside a capture only lists that exist are used)
+    if (p.seg_state != 1 && !t_capturing && last_error_code_only() == kOk && !ensure_segments(p, seg_auto_slabs(p.A.n), st)) {
+      (void)hipGetLastError(); // (no room for the lists this time: the one-kernel path)
+      clear_error();
+      p.free_segments();
+      p.seg_choice = 0;
+    }
+    if (p.seg_state == 1) {
+      run_segments(st, p, alpha, beta, x, y);
+      return true;
+    }
+  }
+  if (!run_plus_prepare(p, h_rowptr, st, x)) return false;
+  if (!autotune_hint(p, kFamPlus, st, [&](double *ys) { launch_here(1.0, trial_beta(), ys); })) return false;
+  // the passes were not clearly faster than the coarse kernel: once more against the tuned one, the faster (by 5 %) stays
+  if (slabs_auto && p.hint_state == 1 && p.seg_choice < 0 && !t_capturing && !by_rule()) {
+    // (also while adaptive is timing its kernel families: row-block-plus is then timed as what it will run -- on R-MAT 25 the one-kernel
+    // path beats flat by 0.5 % only, 7.26 against 7.29 ms, and a family choice made on that would never meet the 5.3 ms of the passes)
+    float ms[2] = {0.f, 0.f};
+    bool timed = false;
+    if (!time_against_segments(ms, &timed)) return false;
+    p.seg_choice = timed && ms[1] < 0.95f * ms[0] ? 1 : 0;
+    if (timed)
+      tune_log("m %d nnz %d beta class %d: row-block-plus %.2f us, %d column-slab passes over run lists %.2f us -> %s", p.A.m, p.A.nnz,
+               t_beta_class, ms[0] * 1e3f, seg_auto_slabs(p.A.n), ms[1] * 1e3f, p.seg_choice ? "slab passes" : "row-block-plus");
+    if (p.seg_choice == 0) p.free_segments(); // (the lists of a matrix that does not use them: 12 B per run back)
+    if (p.seg_choice == 1 && p.seg_state == 1) {
+      run_segments(st, p, alpha, beta, x, y);
+      return true;
     }
   }
   launch_here(alpha, beta, y);
@@ -2176,45 +2266,88 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
     if (p.adaptive_family[cls ^ 1] >= 0) return run_family(p.adaptive_family[cls ^ 1], alpha, beta, y);
     return plan_work_allowed("adaptive: timing the kernel families on this matrix");
   }
-  if (p.adaptive_family[cls] < 0) {
+  // The comparison has two parts: a FIRST LOOK (each family built with its default sub-choices and timed once) and a SECOND LOOK at every
+  // family within 8 % of the fastest.  Under the call's tuning budget (defer_tuning) the second look may fall to a later call: the first
+  // look's choice serves until then (adaptive_provisional) and its timings are kept in the plan.
+  auto decide = [&](const float *ms) {
+    // fixed row blocks unless another family is at least 3 % faster (short kernels time within ~2 %)
+    int best_family = ms[0] < 1e29f ? 0 : 1;
+    for (int f = 1; f < 3; ++f)
+      if (ms[f] < (best_family == 0 ? 0.97f * ms[0] : ms[best_family])) best_family = f;
+    return best_family;
+  };
+  // The first look is incremental under the budget: a family that has not been timed yet is built and timed only while the call may still
+  // spend (the first call times fixed row blocks at least; the others follow, one per later call if need be), and until all three are in, the
+  // best of the measured ones serves.
+  float *ms = p.adaptive_ms[cls];
+  bool unmeasured = false;
+  for (int f = 0; f < 3; ++f) unmeasured = unmeasured || (ms[f] > 1e29f && !p.adaptive_skipped[cls][f]);
+  const bool open = p.adaptive_family[cls] < 0 || p.adaptive_provisional[cls];
+  if (open && !t_capturing && !(p.adaptive_family[cls] >= 0 && defer_tuning())) {
     ++t_plan_work;
     double *scratch = nullptr;
     if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
     TuneTimer timer;
     timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
     bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
-    float ms[3] = {1e30f, 1e30f, 1e30f};
     // The families are compared in the caller's beta class: with beta != 0 every row also reads its old y, which is a large
     // share of the traffic where rows hold one or two non-zeros and ranks the families differently (15 M rows of ~1 nnz:
     // flat looked 3 % faster than the row blocks at beta = 0 and is 9 % slower at beta = 1).
     const double beta_trial = trial_beta();
     t_coarse_tuning = true;
+    bool any_measured = false;
+    int timed_here = 0;
+    for (int f = 0; f < 3; ++f) any_measured = any_measured || ms[f] < 1e29f;
     for (int f = 0; ok && f < 3; ++f) {
+      if (ms[f] < 1e29f || p.adaptive_skipped[cls][f]) continue;
+      // (at least one family is timed whatever the budget: the call needs a kernel.  A further one is only started while most of the budget is
+      // left: building a family's plan is structural work of unknown size -- the row-block analysis, its tables and their allocations took 4 ms on
+      // the headline matrix, 25 SpMVs' worth)
+      // Every call that gets here times at least ONE family more (progress is guaranteed whatever the budget).
+      if (any_measured && timed_here > 0 && (defer_tuning() || budget_spent_fraction() > 0.25)) {
+        t_tuning_deferred = true;
+        break;
+      }
+      if (any_measured && timed_here == 0 && p.calls <= 1 && (defer_tuning() || budget_spent_fraction() > 0.25)) { // (the FIRST call: one family is enough)
+        t_tuning_deferred = true;
+        break;
+      }
       ok = run_family(f, 1.0, beta_trial, scratch); // builds this family's plan (sub-choices at their defaults)
       if (!ok) break;
-      if (f == 0 && p.rowblock_ok == 0) continue; // fixed row blocks were rescued: that run WAS family 1
+      if (f == 0 && p.rowblock_ok == 0) { // fixed row blocks were rescued: that run WAS family 1
+        p.adaptive_skipped[cls][0] = true;
+        continue;
+      }
       ok = timer.time(st, [&] { (void)run_family(f, 1.0, beta_trial, scratch); }, &ms[f]);
+      any_measured = any_measured || ok;
+      ++timed_here;
     }
+    unmeasured = false;
+    for (int f = 0; f < 3; ++f) unmeasured = unmeasured || (ms[f] > 1e29f && !p.adaptive_skipped[cls][f]);
     // second look at every family within 8 % of the fastest: the choice is kept for the life of the plan, and two families
     // 3 % apart changed places from process to process on single timings (the headline matrix ran fixed row blocks in one
     // run and row-block-plus in the next); the smaller of the two timings counts
-    float fastest = ms[0];
-    for (int f = 1; f < 3; ++f) fastest = ms[f] < fastest ? ms[f] : fastest;
-    for (int f = 0; ok && f < 3; ++f) {
-      if (ms[f] > 1.08f * fastest) continue;
-      float again = 1e30f;
-      ok = timer.time(st, [&] { (void)run_family(f, 1.0, beta_trial, scratch); }, &again);
-      if (ok && again < ms[f]) ms[f] = again;
+    bool looked_twice = false;
+    if (ok && !unmeasured && (timed_here == 0 || !defer_tuning())) { // (a call that timed no family takes the second look whatever its budget: progress)
+      float fastest = ms[0];
+      for (int f = 1; f < 3; ++f) fastest = ms[f] < fastest ? ms[f] : fastest;
+      for (int f = 0; ok && f < 3; ++f) {
+        if (ms[f] > 1.08f * fastest) continue;
+        float again = 1e30f;
+        ok = timer.time(st, [&] { (void)run_family(f, 1.0, beta_trial, scratch); }, &again);
+        if (ok && again < ms[f]) ms[f] = again;
+      }
+      looked_twice = ok;
     }
     t_coarse_tuning = false;
-    // fixed row blocks unless another family is at least 3 % faster (short kernels time within ~2 %)
-    int best_family = ms[0] < 1e29f ? 0 : 1;
-    for (int f = 1; f < 3; ++f)
-      if (ms[f] < (best_family == 0 ? 0.97f * ms[0] : ms[best_family])) best_family = f;
-    tune_log("m %d nnz %d adaptive (beta %s 0): fixed row blocks %.2f us, row-block-plus %.2f us, flat %.2f us -> family %d", p.A.m, p.A.nnz,
-             beta != 0.0 ? "!=" : "==", ms[0] * 1e3f, ms[1] * 1e3f, ms[2] * 1e3f, best_family);
+    const int best_family = decide(ms);
+    tune_log("m %d nnz %d adaptive (beta %s 0): fixed row blocks %.2f us, row-block-plus %.2f us, flat %.2f us -> family %d%s", p.A.m, p.A.nnz,
+             beta != 0.0 ? "!=" : "==", ms[0] * 1e3f, ms[1] * 1e3f, ms[2] * 1e3f, best_family,
+             looked_twice ? "" : (unmeasured ? " (so far: the other families wait for a later call's tuning budget)" : " (first look; the second look waits for a later call's tuning budget)"));
     if (!ok) return false;
     p.adaptive_family[cls] = best_family;
+    p.adaptive_provisional[cls] = !looked_twice;
+    if (!looked_twice) t_tuning_deferred = true;
   }
   return run_family(p.adaptive_family[cls], alpha, beta, y);
 }
@@ -2304,17 +2437,12 @@ bool ensure_slabs(Plan &p, int S, hipStream_t st) {
 }
 
 // Column-slab blocking without a copy (tunable slab_segments): the per-slab run lists of k_segment.hip.  Structure only; built once.
-bool ensure_hub(Plan &p, int hub_from, hipStream_t st);
-inline int hub_from_now() { return tun(kT_hub_rows) == 1 && tun(kT_hub_min_len) > 1 ? tun(kT_hub_min_len) : 0; }
 bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
-  const int hub_from = tun(kT_hub_rows) == 1 ? hub_from_now() : 0;
-  // two-class form (hub_rows = 2): only the rows of >= hub_min_len non-zeros are cut by column slab; every shorter row is ONE run, all columns, in a
-  // pass of its own (plane S_cols).  A 128-B line of values holds 16 non-zeros -- of a short or medium row that is 4-6 different slabs' runs, and
-  // every pass that owns one of them fetches the line again (R-MAT 25, all rows cut: 15.5 M KB raw FETCH_SIZE per SpMV for 7.3 GB of algorithmic
-  // bytes); the long rows' runs fill their lines, the short rows are cheaper gathered from all of x than streamed five times.
-  const int rest_below = tun(kT_hub_rows) == 2 && tun(kT_hub_min_len) > 1 ? tun(kT_hub_min_len) : 0;
+  // two-class form (tunable slab_whole_below): only the rows of at least that many non-zeros are cut by column slab; every shorter row is ONE run,
+  // all columns, in a pass of its own (plane S_cols)
+  const int rest_below = tun(kT_slab_whole_below) > 1 ? tun(kT_slab_whole_below) : 0;
   const int S = S_cols + (rest_below > 0 ? 1 : 0); // planes
-  if (p.seg_state >= 0 && (p.seg_state == 0 || (p.seg_slabs == S && p.seg_hub_from == hub_from && p.seg_rest_below == rest_below))) return true;
+  if (p.seg_state >= 0 && (p.seg_state == 0 || (p.seg_slabs == S && p.seg_rest_below == rest_below))) return true;
   if (!plan_work_allowed("building the column-slab run lists")) return false;
   ++t_plan_work;
   p.free_segments();
@@ -2337,7 +2465,7 @@ bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
             hip_ok(hipMemsetAsync(flag, 0, sizeof(int), st), "memset order flag");
   int unordered = 0;
   if (ok) {
-    launch_segment_count(st, A, bounds, S, cnt, beg, flag, hub_from, rest_below);
+    launch_segment_count(st, A, bounds, S, cnt, beg, flag, rest_below);
     ok = hip_ok(hipMemcpyAsync(&unordered, flag, sizeof(int), hipMemcpyDeviceToHost, st), "read order flag") &&
          hip_ok(hipStreamSynchronize(st), "sync run counts");
   }
@@ -2412,15 +2540,9 @@ bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
     } else if (ok) {
       p.seg_state = 1;
       p.seg_slabs = S;
-      p.seg_hub_from = hub_from;
       p.seg_rest_below = rest_below;
     }
   }
-  for (void *q : {static_cast<void *>(cnt), static_cast<void *>(beg), static_cast<void *>(pieces), static_cast<void *>(pos), static_cast<void *>(flag), tmp})
-    if (q) (void)hipFree(q);
-  cnt = beg = pieces = pos = flag = nullptr;
-  tmp = nullptr;
-  if (ok && p.seg_state == 1 && hub_from > 0 && !ensure_hub(p, hub_from, st)) ok = false;
   for (void *q : {static_cast<void *>(cnt), static_cast<void *>(beg), static_cast<void *>(pieces), static_cast<void *>(pos), static_cast<void *>(flag), tmp})
     if (q) (void)hipFree(q);
   if (!ok) {
@@ -2430,122 +2552,6 @@ bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
   return true;
 }
 
-// Hub rows through L2-sized column windows (k_hub.hip): the lists of the rows of >= hub_from non-zeros, which the coarse slab lists skip.
-// Called at the end of ensure_segments.  Returns false on a HIP error; hub rows whose columns do not ascend send the whole matrix back to
-// the ordinary path (seg_state 0), like rows that are not ordered by slab.
-bool ensure_hub(Plan &p, int hub_from, hipStream_t st) {
-  const CsrDev &A = p.A;
-  p.free_hub();
-  const size_t m1 = static_cast<size_t>(A.m) + 1;
-  long long width = static_cast<long long>(tun(kT_hub_window_kb)) * 1024 / 8;
-  if (width < 4096) width = 4096;
-  while ((A.n + width - 1) / width > 1024) width *= 2; // (at most 1024 windows)
-  const int NW = static_cast<int>((A.n + width - 1) / width);
-  int *flag = nullptr, *pos = nullptr, *bad = nullptr;
-  void *tmp = nullptr;
-  const size_t tmp_bytes = col16_scan_bytes(A.m);
-  int H = 0, unsorted = 0;
-  bool ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&flag), sizeof(int) * m1), "hipMalloc hub flags") &&
-            hip_ok(hipMalloc(reinterpret_cast<void **>(&pos), sizeof(int) * m1), "hipMalloc hub positions") &&
-            hip_ok(hipMalloc(reinterpret_cast<void **>(&bad), sizeof(int)), "hipMalloc hub order flag") &&
-            hip_ok(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16), "hipMalloc scan workspace") &&
-            hip_ok(hipMemsetAsync(bad, 0, sizeof(int), st), "memset hub order flag");
-  if (ok) {
-    launch_hub_flags(st, A.rp, A.m, hub_from, flag);
-    ok = launch_col16_scan(st, A.m, flag, pos, tmp, tmp_bytes) &&
-         hip_ok(hipMemcpyAsync(&H, pos + A.m, sizeof(int), hipMemcpyDeviceToHost, st), "read hub count") && hip_ok(hipStreamSynchronize(st), "sync hub count");
-  }
-  // (NW + 1) * H window bounds and as many scan entries: a matrix that is all hubs, or has too many for 32-bit cell arithmetic, keeps its hub rows out of
-  // reach of this path -- the caller then rebuilds nothing: such a matrix is not what the windows are for
-  const long long cells = static_cast<long long>(NW + 1) * H;
-  if (ok && H > 0 && (NW < 2 || cells > (1LL << 30))) {
-    tune_log("m %d nnz %d: hub windows: %d hub rows x %d windows is out of range, ordinary path", A.m, A.nnz, H, NW);
-    H = -1;
-  }
-  if (ok && H > 0) {
-    ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_row), sizeof(int) * static_cast<size_t>(H)), "hipMalloc hub rows");
-    if (ok) {
-      launch_hub_rows(st, flag, pos, A.m, p.d_hub_row);
-      launch_hub_sorted(st, A, p.d_hub_row, H, bad);
-      ok = hip_ok(hipMemcpyAsync(&unsorted, bad, sizeof(int), hipMemcpyDeviceToHost, st), "read hub order flag") && hip_ok(hipStreamSynchronize(st), "sync hub order");
-    }
-  }
-  for (void *q : {static_cast<void *>(flag), static_cast<void *>(pos), tmp})
-    if (q) (void)hipFree(q);
-  flag = pos = nullptr;
-  tmp = nullptr;
-  if (ok && (H < 0 || unsorted)) {
-    if (unsorted) tune_log("m %d nnz %d: hub windows: a hub row's columns do not ascend, ordinary path", A.m, A.nnz);
-    if (bad) (void)hipFree(bad);
-    p.free_segments();
-    p.seg_state = 0;
-    return true;
-  }
-  int *wbeg = nullptr, *pieces = nullptr, *cpos = nullptr, *len = nullptr, *cost = nullptr, *cptr = nullptr;
-  void *tmp_c = nullptr, *tmp_e = nullptr;
-  if (ok && H > 0) {
-    const size_t ncell = static_cast<size_t>(NW) * H + 1;
-    const size_t tmp_c_bytes = col16_scan_bytes(static_cast<int>(ncell - 1));
-    int entries = 0;
-    ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&wbeg), sizeof(int) * static_cast<size_t>(cells)), "hipMalloc hub window bounds") &&
-         hip_ok(hipMalloc(reinterpret_cast<void **>(&pieces), sizeof(int) * ncell), "hipMalloc hub pieces") &&
-         hip_ok(hipMalloc(reinterpret_cast<void **>(&cpos), sizeof(int) * ncell), "hipMalloc hub cell positions") &&
-         hip_ok(hipMalloc(&tmp_c, tmp_c_bytes > 0 ? tmp_c_bytes : 16), "hipMalloc scan workspace");
-    if (ok) {
-      launch_hub_bounds(st, A, p.d_hub_row, H, static_cast<int>(width), NW, wbeg);
-      launch_hub_pieces(st, wbeg, H, NW, kSegPiece, pieces);
-      ok = launch_col16_scan(st, static_cast<int>(ncell - 1), pieces, cpos, tmp_c, tmp_c_bytes) &&
-           hip_ok(hipMemcpyAsync(&entries, cpos + (ncell - 1), sizeof(int), hipMemcpyDeviceToHost, st), "read hub entry count") &&
-           hip_ok(hipStreamSynchronize(st), "sync hub entry count");
-    }
-    if (ok && entries > 0) {
-      const size_t e1 = static_cast<size_t>(entries) + 1;
-      const size_t tmp_e_bytes = col16_scan_bytes(entries);
-      const int NG = (H + kHubGroup - 1) / kHubGroup;
-      int last = 0;
-      ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_ent), sizeof(int) * e1), "hipMalloc hub entry rows") &&
-           hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_begin), sizeof(int) * e1), "hipMalloc hub entry starts") &&
-           hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_vptr), sizeof(int) * e1), "hipMalloc hub entry prefix") &&
-           hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_cell), sizeof(int) * static_cast<size_t>(NW) * (NG + 1)), "hipMalloc hub cells") &&
-           hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_ys), sizeof(double) * e1), "hipMalloc hub run sums") &&
-           hip_ok(hipMalloc(reinterpret_cast<void **>(&len), sizeof(int) * e1), "hipMalloc hub run lengths") &&
-           hip_ok(hipMalloc(reinterpret_cast<void **>(&cost), sizeof(int) * e1), "hipMalloc hub run costs") &&
-           hip_ok(hipMalloc(reinterpret_cast<void **>(&cptr), sizeof(int) * e1), "hipMalloc hub run cost prefix") &&
-           hip_ok(hipMalloc(&tmp_e, tmp_e_bytes > 0 ? tmp_e_bytes : 16), "hipMalloc scan workspace");
-      if (ok) {
-        launch_hub_compact(st, wbeg, cpos, H, NW, kSegPiece, p.d_hub_ent, p.d_hub_begin, len);
-        launch_hub_cells(st, cpos, H, NW, NG, p.d_hub_cell);
-        launch_segment_cost(st, entries, len, cost);
-        ok = launch_col16_scan(st, entries, len, p.d_hub_vptr, tmp_e, tmp_e_bytes) && launch_col16_scan(st, entries, cost, cptr, tmp_e, tmp_e_bytes) &&
-             hip_ok(hipMemcpyAsync(&last, cptr + entries, sizeof(int), hipMemcpyDeviceToHost, st), "read hub pass cost") &&
-             hip_ok(hipStreamSynchronize(st), "sync hub scans");
-      }
-      if (ok) {
-        const int nblocks = segment_block_count(last);
-        ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_hub_blk), sizeof(int) * (static_cast<size_t>(nblocks) + 1)), "hipMalloc hub workgroups");
-        if (ok) {
-          launch_segment_blocks(st, entries, nblocks, cptr, p.d_hub_blk);
-          ok = hip_ok(hipStreamSynchronize(st), "sync hub workgroups");
-        }
-        if (ok) {
-          p.hub_rows = H;
-          p.hub_windows = NW;
-          p.hub_width = static_cast<int>(width);
-          p.hub_groups = NG;
-          p.hub_entries = entries;
-          p.hub_blocks = nblocks;
-          tune_log("m %d nnz %d: hub windows: %d rows of >= %d non-zeros, %d windows of %lld columns, %d runs, %d workgroups", A.m, A.nnz, H, hub_from, NW,
-                   width, entries, nblocks);
-        }
-      }
-    }
-  }
-  for (void *q : {static_cast<void *>(wbeg), static_cast<void *>(pieces), static_cast<void *>(cpos), static_cast<void *>(len), static_cast<void *>(cost),
-                  static_cast<void *>(cptr), static_cast<void *>(bad), tmp_c, tmp_e})
-    if (q) (void)hipFree(q);
-  if (!ok) p.free_hub();
-  return ok;
-}
 } // namespace
 
 // The one plan-resident copy of VALUES is the column slabs' (opt-in).  A caller that changes values in place -- which every other
@@ -2566,6 +2572,8 @@ int refresh_values(const int *d_rowptr) {
   return static_cast<int>(todo.size());
 }
 
+UnboundedTuningScope::UnboundedTuningScope() { ++t_unbounded_tuning; }
+UnboundedTuningScope::~UnboundedTuningScope() { --t_unbounded_tuning; }
 FlatSegmentSumScope::FlatSegmentSumScope() : prev(t_flat_segment_sum) { t_flat_segment_sum = true; }
 FlatSegmentSumScope::~FlatSegmentSumScope() { t_flat_segment_sum = prev; }
 
@@ -2621,6 +2629,27 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   // to the plan (two host threads on DIFFERENT matrices do not meet here; this lock is never held together with g_mu)
   std::lock_guard<std::mutex> plan_lock(p->mu);
   t_beta_class = beta != 0.0 ? 1 : 0;
+  // this call's tuning budget (see defer_tuning): the first call on a matrix may spend first_call_budget SpMV-equivalents on trial launches,
+  // a later one later_call_budget while something is still open; spmv_acc_prepare, captures (which time nothing) and `deterministic` are outside it
+  struct BudgetScope {
+    Plan &p;
+    bool outer;
+    ~BudgetScope() {
+      if (!outer) return;
+      if (t_first_trial_ms > 0.f) p.trial_ms = t_first_trial_ms;
+      p.tuning_open = t_tuning_deferred; // (a call that deferred nothing has settled everything on its path)
+      t_budget_spmvs = 0.0;
+      t_budget_ms = -1.0;
+    }
+  } budget_scope{*p, !t_in_slab};
+  if (!t_in_slab) {
+    t_call_began = std::chrono::steady_clock::now();
+    t_tuning_deferred = false;
+    t_first_trial_ms = 0.f;
+    const int allowance = p->calls == 0 ? tun(kT_first_call_budget) : tun(kT_later_call_budget);
+    t_budget_spmvs = (t_unbounded_tuning > 0 || t_capturing || allowance <= 0) ? 0.0 : static_cast<double>(allowance);
+    t_budget_ms = (t_budget_spmvs > 0.0 && p->trial_ms > 0.0) ? t_budget_spmvs * p->trial_ms : -1.0;
+  }
   // What the reference's harness calls `pre` (its per-call break-point / analysis cost, benchmark_time.cpp:23-43) is paid here
   // by the FIRST call on a matrix: structural passes + per-matrix timings, all of which end in a synchronisation, so the host
   // time from here to the return of that call is the preparation time (the final launch itself is asynchronous).
@@ -2875,7 +2904,7 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->flat_fixup = p.flat_tiles > 0 ? (p.flat.needs_fixup ? 1 : 0) : -1;
       out->adaptive_family = afam;
       out->adaptive_family_beta0 = p.adaptive_family[0];
-      out->slab_passes = p.seg_state == 1 && (tun(kT_slab_segments) >= 2 || (tun(kT_slab_segments) < 0 && p.seg_choice == 1)) ? p.seg_slabs : 0;
+      out->slab_passes = p.seg_state == 1 && (tun(kT_slab_segments) >= 2 || (tun(kT_slab_segments) < 0 && p.seg_choice == 1)) ? p.seg_slabs - (p.seg_rest_below > 0 ? 1 : 0) : 0; // (column slabs: the whole-row pass of the two-class form is not counted)
       return true;
     }
   }

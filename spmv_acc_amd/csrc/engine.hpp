@@ -54,6 +54,13 @@ int set_tunable(const char *name, int value);
 int get_tunable(const char *name);
 void reset_tunables();
 
+// While one of these lives, run_spmv calls of this thread spend whatever the per-matrix timings cost (no first_call_budget / later_call_budget):
+// spmv_acc_prepare exists to pay for everything up front.
+struct UnboundedTuningScope {
+  UnboundedTuningScope();
+  ~UnboundedTuningScope();
+};
+
 // Host microseconds the calling thread's most recent run_spmv spent preparing its matrix (plan build + per-matrix timings);
 // 0 when the plan already existed.
 double last_prepare_us();

@@ -49,7 +49,7 @@ static_assert(kNnzPerThread == 8, "the owner map is scanned 8 elements per lane 
 // cnt[s][row] (S x (m + 1), entry m zeroed for the scans), beg[s][row] (same shape): first non-zero of slab s's run in row `row`
 __global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__restrict__ rp, const int *__restrict__ ci, int m, SlabBounds B,
                                                                  int S, int *__restrict__ cnt, int *__restrict__ beg,
-                                                                 int *__restrict__ not_monotone, int skip_from, int rest_below) {
+                                                                 int *__restrict__ not_monotone, int rest_below) {
   const int lane = threadIdx.x & (kWave - 1);
   const int SC = rest_below > 0 ? S - 1 : S; // column slabs; with rest_below the last plane (S - 1) lists the rows of < rest_below non-zeros WHOLE
   // One wavefront per row; beyond kMaxGridBlocks * 4 rows the wavefronts stride over the rows -- by a PRIME number of workgroups: a stride of 2^16
@@ -59,13 +59,6 @@ __global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__re
        row += static_cast<long long>(gridDim.x) * (kThreads / kWave)) {
     const int j0 = rp[row], j1 = rp[row + 1];
     if (j1 - j0 <= kSegShortRow) continue; // (wave-uniform: short rows are counted 64 to a wavefront by segment_count_short_kernel)
-    if (skip_from > 0 && j1 - j0 >= skip_from) { // a hub row (k_hub.hip owns it): empty in every slab of these lists
-      if (lane < S) {
-        cnt[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row] = 0;
-        beg[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row] = j0;
-      }
-      continue;
-    }
     if (j1 - j0 < rest_below) { // a short row of the two-class form: one run, all columns, in the last plane (its columns need no order)
       if (lane < S) {
         cnt[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row] = lane == S - 1 ? j1 - j0 : 0;
@@ -115,7 +108,7 @@ __global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__re
 // slab into two 64-bit words (a row of <= 32 non-zeros cannot overflow a field).
 __global__ __launch_bounds__(kThreads) void segment_count_short_kernel(const int *__restrict__ rp, const int *__restrict__ ci, int m, SlabBounds B,
                                                                        int S, int *__restrict__ cnt, int *__restrict__ beg,
-                                                                       int *__restrict__ not_monotone, int skip_from, int rest_below) {
+                                                                       int *__restrict__ not_monotone, int rest_below) {
   const int SC = rest_below > 0 ? S - 1 : S;
   const long long row = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
   if (row == m) { // (the grid covers m + 1 entries: the scans' closing zeros)
@@ -124,7 +117,6 @@ __global__ __launch_bounds__(kThreads) void segment_count_short_kernel(const int
   if (row >= m) return;
   const int j0 = rp[row], j1 = rp[row + 1];
   if (j1 - j0 > kSegShortRow) return; // a long row: segment_count_kernel
-  const bool hub = skip_from > 0 && j1 - j0 >= skip_from; // (a hub threshold at or below kSegShortRow: the row counts as empty here too)
   if (j1 - j0 < rest_below) { // two-class form: the whole row is one run of the last plane
     for (int s = 0; s < S; ++s) {
       cnt[static_cast<size_t>(s) * (static_cast<size_t>(m) + 1) + row] = s == S - 1 ? j1 - j0 : 0;
@@ -135,7 +127,7 @@ __global__ __launch_bounds__(kThreads) void segment_count_short_kernel(const int
   unsigned long long p0 = 0ULL, p1 = 0ULL; // slabs 0-7, 8-15
   int prev = 0;
   bool bad = false;
-  for (int j = j0; j < (hub ? j0 : j1); ++j) {
+  for (int j = j0; j < j1; ++j) {
     const int c = ci[j];
     int slab = 0;
 #pragma unroll
@@ -293,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void segment_tile_kernel(double alpha, co
     if (live && lane == 0) {
       // a whole run is the only entry of its row in this pass: straight into y (beta was applied before the first pass); a piece
       // of a long run goes through ys, the merge kernel adds a row's pieces in order
-      const int r = seg_row ? seg_row[e0 + r0 + id] : -1; // (k_hub.hip's entries: every sum goes to ys, its merge kernel adds them)
+      const int r = seg_row[e0 + r0 + id];
       if (r >= 0) y[r] += alpha * acc;
       else ys[e0 + r0 + id] = alpha * acc;
     }
@@ -316,15 +308,15 @@ __global__ __launch_bounds__(kThreads) void segment_merge_kernel(int entries, co
 
 } // namespace
 
-void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone, int skip_from, int rest_below) {
+void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone, int rest_below) {
   if (A.m <= 0) return;
   long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row ...
   if (blocks > kMaxGridBlocks) blocks = kMaxGridBlocks;                                               // ... up to what a launch holds
   hipLaunchKernelGGL(segment_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S, cnt,
-                     beg, not_monotone, skip_from, rest_below);
+                     beg, not_monotone, rest_below);
   const long long short_blocks = (static_cast<long long>(A.m) + 1 + kThreads - 1) / kThreads; // m + 1: the closing zeros
   hipLaunchKernelGGL(segment_count_short_kernel, dim3(static_cast<unsigned>(short_blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S,
-                     cnt, beg, not_monotone, skip_from, rest_below);
+                     cnt, beg, not_monotone, rest_below);
 }
 void launch_segment_pieces(hipStream_t stream, const int *cnt_s, int m, int piece_max, int *pieces) {
   const long long blocks = (static_cast<long long>(m) + 1 + kThreads - 1) / kThreads;

@@ -36,11 +36,9 @@ void launch_guard_check(hipStream_t stream, const CsrDev &A); // the check alone
 struct SlabBounds {
   int first[15]; // first[b] = first column of slab b + 1 (ascending); slab of column c = number of entries <= c among the first S - 1
 };
-// skip_from > 0: rows of skip_from or more non-zeros count as empty (they are the hub rows of k_hub.hip)
 // rest_below > 0 (two-class form): S counts one plane more than there are column slabs; rows of fewer than rest_below non-zeros are ONE run each, all
 // columns, in that last plane (they are not cut by column at all), the longer rows are cut into the S - 1 column slabs as usual
-void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone, int skip_from = 0,
-                          int rest_below = 0);
+void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone, int rest_below = 0);
 void launch_segment_pieces(hipStream_t stream, const int *cnt_s, int m, int piece_max, int *pieces);
 void launch_segment_compact(hipStream_t stream, const int *cnt_s, const int *beg_s, const int *pos, int m, int piece_max, int *seg_row,
                             int *seg_begin, int *seg_len, int *has_pieces); // *has_pieces pre-zeroed: set when some run was cut
@@ -51,17 +49,6 @@ void launch_segment_blocks(hipStream_t stream, int entries, int nblocks, const i
 void launch_segment_tiles(hipStream_t stream, int nblocks, double alpha, const int *blk_first, const int *seg_row, const int *seg_begin,
                           const int *vptr, const int *ci, const double *v, const double *x, double *ys, double *y);
 void launch_segment_merge(hipStream_t stream, int entries, const int *seg_row, const double *ys, double *y);
-// ---- hub rows through L2-sized column windows (k_hub.hip, tunable hub_rows): the runs of the rows of >= min_len non-zeros in (window, hub row)
-// order, staged by the segment tile kernel (seg_row == nullptr: every entry's sum goes to ys) and merged per group of kHubGroup hub rows
-constexpr int kHubGroup = 256;
-void launch_hub_flags(hipStream_t stream, const int *rp, int m, int min_len, int *flag);           // flag: m + 1
-void launch_hub_rows(hipStream_t stream, const int *flag, const int *pos, int m, int *hub_row);    // pos = exclusive scan of flag
-void launch_hub_sorted(hipStream_t stream, const CsrDev &A, const int *hub_row, int H, int *unsorted); // *unsorted pre-zeroed
-void launch_hub_bounds(hipStream_t stream, const CsrDev &A, const int *hub_row, int H, int width, int NW, int *wbeg); // wbeg: (NW + 1) * H, window-major
-void launch_hub_pieces(hipStream_t stream, const int *wbeg, int H, int NW, int piece_max, int *pieces); // pieces: NW * H + 1
-void launch_hub_compact(hipStream_t stream, const int *wbeg, const int *pos, int H, int NW, int piece_max, int *ent_hub, int *ent_begin, int *ent_len);
-void launch_hub_cells(hipStream_t stream, const int *pos, int H, int NW, int NG, int *cell);       // cell: NW * (NG + 1)
-void launch_hub_merge(hipStream_t stream, int H, int NW, int NG, const int *cell, const int *ent_hub, const double *ys, const int *hub_row, double *y);
 // opt-in full check (k_guard.hip, tunable guard_full): one partial digest of rowptr[0 .. m] per workgroup into part[0 .. parts);
 // then ONE workgroup adds them up and either writes the digest to digest_out (plan build) or compares it with `expected` and raises `stale`
 constexpr int kDigestMaxParts = 1024;

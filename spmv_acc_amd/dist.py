@@ -146,6 +146,25 @@ class RowShardedSpmv:
             self._chunks[depth] = out
         return self._chunks[depth]
 
+    def prepare(self, beta: float, x, depth: Optional[int] = None) -> float:
+        """Build and tune the plan of every chunk of a ``depth``-chunk step (default: the constructor's pipeline) for the beta class of
+        ``beta``, up front (spmv_acc_prepare: no tuning budget), so that the steps only enqueue -- plan building allocates, frees and
+        synchronises, which must not fall between the exchanges of a step the peers are already in, nor into a timed region.  No
+        collective inside.  GPU engine only (a pluggable ``local_spmv`` has no plans).  Returns the device milliseconds spent."""
+        if self.local_spmv != self._hip_spmv:
+            return 0.0
+        depth = self.pipeline if depth is None else max(int(depth), 1)
+        ms = 0.0
+        for k, (a, b, rp, ci, v, nnz, h_rp) in enumerate(self._chunk_arrays(depth)):
+            if b <= a:
+                continue
+            if self._gpu and depth > 1:  # on the stream the chunk's kernels will use
+                with self.torch.cuda.stream(self.chunk_streams[k & 1]):
+                    ms += spmv_acc_amd.prepare(b - a, self.n, nnz, rp, ci, v, x, strategy=self.strategy, h_rowptr=h_rp, beta=beta)
+            else:
+                ms += spmv_acc_amd.prepare(b - a, self.n, nnz, rp, ci, v, x, strategy=self.strategy, h_rowptr=h_rp, beta=beta)
+        return ms
+
     def _hip_spmv(self, alpha, beta, x, y_out, y_in, chunk):
         a, b, rp, ci, v, nnz, h_rp = chunk
         spmv_acc_amd.csr_spmv(alpha, beta, b - a, self.n, nnz, rp, ci, v, x, y_out, strategy=self.strategy, h_rowptr=h_rp,
@@ -287,6 +306,7 @@ class RowShardedSpmv:
         for depth in candidates:
             if depth > max(self.pad, 1):
                 continue
+            self.prepare(beta, x, depth)  # (every chunk's plan settled before the timed steps)
             for i in range(warm + iters):
                 if i == warm:
                     if self._gpu:

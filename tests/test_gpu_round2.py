@@ -232,8 +232,9 @@ def test_row_sharded_event_ordering_on_one_rank_rccl(torch_dev, oracle):
                                  always_collective=True, exchange=exchange, own_stream=True)
             assert eng.compute_stream is not None and eng.compute_stream.cuda_stream != 0  # explicit non-NULL stream
             assert eng.compute_stream.cuda_stream != torch.cuda.current_stream().cuda_stream
+            eng.prepare(0.5, dx)  # the plan, every per-matrix timing settled (a later step that still tuned would synchronise)
             eng.set_y(dy0)
-            eng.step(0.25, 0.5, dx)  # builds the plan
+            eng.step(0.25, 0.5, dx)
             eng.wait()
             torch.cuda.synchronize()
             with torch.cuda.stream(eng.compute_stream):

@@ -64,6 +64,9 @@ def test_out_of_place_is_bitwise_the_in_place_result(torch_dev, oracle, hiplib, 
                     for k, v in tun.items():
                         hiplib.spmv_acc_set_tunable(k.encode(), v)
                     try:
+                        # (a settled plan: two calls on a plan whose per-matrix timings are still being finished -- tunable first_call_budget --
+                        # may run different kernel families, i.e. sum in a different order)
+                        spmv_acc_amd.prepare(m, n, nnz, drp, dci, dv, dx, strategy=strat, beta=beta)
                         inplace = dy0.clone()
                         spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, inplace, strategy=strat)
                         y_in = dy0.clone()
@@ -152,10 +155,11 @@ def test_two_host_threads_two_streams(torch_dev, oracle, hiplib):
             A = mats[i]
             drp, dci, dv, dx = A["d"]
             with torch.cuda.stream(streams[i]):
-                # plans first (first calls synchronise), one strategy of each kernel family
+                # plans first, every per-matrix timing settled (calls that still tune synchronise), one strategy of each kernel family
                 for strat in ("adaptive", "flat", "adaptive_plus"):
                     y = A["dy0"].clone()
                     spmv_acc_amd.csr_spmv(1.0, 1.0, A["m"], A["m"], A["nnz"], drp, dci, dv, dx, y, strategy=strat)
+                    spmv_acc_amd.prepare(A["m"], A["m"], A["nnz"], drp, dci, dv, dx, strategy=strat)
                 # every buffer of the contended section exists before it starts: an allocation there may free cached blocks,
                 # and hipFree waits for the whole device -- including the other thread's sleeping stream
                 outs = [torch.empty(A["m"], dtype=torch.float64, device="cuda") for _ in range(30)]
@@ -765,6 +769,7 @@ def test_col_slabs_opt_in_matches_the_oracle(torch_dev, oracle, hiplib, kind, m,
             for strat in ALL:
                 for alpha, beta in ((1.0, 1.0), (0.5, -2.0), (2.0, 0.0)):
                     ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+                    spmv_acc_amd.prepare(m, n, nnz, drp, dci, dv, dx, strategy=strat, beta=beta)  # (settled: the bitwise comparison below)
                     y = dy0.clone()
                     spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y, strategy=strat)
                     y_in = dy0.clone()
@@ -944,6 +949,46 @@ def test_slab_segments_match_the_oracle(torch_dev, oracle, hiplib, kind, m, n, a
         spmv_acc_amd.release_plans()
 
 
+@pytest.mark.parametrize("whole_below", [0, 2, 8, 32, 1 << 30])
+def test_slab_passes_two_class_form(torch_dev, oracle, hiplib, whole_below):
+    """Round 4, tunable slab_whole_below = T: rows of fewer than T non-zeros are not cut by column slab -- each is ONE run, all columns, in a
+    pass of its own behind the S slab passes (T = 0: round 3's form, every row cut; T huge: every row whole, the slab passes are empty).  Same
+    sums whatever T (the oracle's, to the scaled tolerance), bitwise equal between two runs, the short rows need no column order, and
+    query_plan reports the COLUMN slabs."""
+    torch = torch_dev
+    m, n = 50000, 80000
+    rowptr, cols, vals = synth.random_csr(m, n, 14, seed=21, kind="powerlaw")
+    lens = np.diff(rowptr)
+    cols, vals = _sorted_rows(rowptr, cols, vals)
+    if whole_below > 2:  # rows below the threshold may be unsorted: shuffle them
+        rng = np.random.default_rng(2)
+        for i in np.nonzero((lens > 1) & (lens < min(whole_below, 1 << 20)))[0][:4000]:
+            a, b = rowptr[i], rowptr[i + 1]
+            perm = rng.permutation(b - a)
+            cols[a:b], vals[a:b] = cols[a:b][perm], vals[a:b][perm]
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(8)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    try:
+        hiplib.spmv_acc_set_tunable(b"slab_segments", 8)
+        hiplib.spmv_acc_set_tunable(b"slab_whole_below", whole_below)
+        for alpha, beta in ((1.0, 1.0), (-0.5, 0.0), (2.0, 3.0)):
+            ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+            y = dy0.clone()
+            spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y, strategy="line_enhance")
+            y2 = dy0.clone()
+            spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y2, strategy="line_enhance")
+            torch.cuda.synchronize()
+            assert oracle.scaled_error(y.cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL, (whole_below, alpha, beta)
+            assert torch.equal(y, y2)
+        if whole_below <= 2 or (whole_below >= (1 << 20)) or int((lens >= whole_below).sum()) > 0:
+            assert spmv_acc_amd.query_plan(drp, m)["slab_passes"] == 8
+    finally:
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans()
+
+
 def test_slab_segments_replay_from_a_graph_and_are_bitwise_stable(torch_dev, oracle, hiplib):
     """The passes are ordinary launches over plan-resident lists: captured after one warm-up call they replay, and two runs give the
     same bits (whole runs add straight into y, the pieces of a long run are added in entry order by one thread: no atomics)."""
@@ -1075,3 +1120,63 @@ def test_bench_gpus_2_launches_itself_and_runs_the_sharded_step(torch_dev):
     # value = both ranks' non-zeros over the max-over-ranks wall time
     assert abs(d["value"] - 2.0 * 2 * d["config"]["nnz_per_gpu"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e9) / d["value"] < 0.02
     assert "launching 2 ranks" in r.stderr
+
+
+# ---- round 4: the first call's tuning budget ----------------------------------------------------------------------------------------
+def test_first_call_is_bounded_and_later_calls_finish_the_timings(torch_dev, oracle, hiplib):
+    """Tunables first_call_budget / later_call_budget (round 4): the FIRST call on a matrix spends at most ~20 SpMV-equivalents on trial
+    launches, leaves the choices it did not get to OPEN (the `deterministic` rule serves meanwhile) and the following calls finish them, one
+    phase each; spmv_acc_prepare pays for everything up front.  Every call is right whatever the state of the plan; the bounded first
+    call does less plan work than the unbounded one (first_call_budget = 0: rounds 1-3); after a few calls nothing is left to do and the plan
+    reports its choices; a prepared plan has nothing left for the calls behind it."""
+    torch = torch_dev
+    m = n = 1_500_000
+    rowptr, cols, vals = synth.random_csr(m, n, 9, seed=77, kind="uniform")
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(12)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    lib = hiplib
+
+    def calls(k, strat):
+        work = []
+        for _ in range(k):
+            y = dy0.clone()
+            spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy=strat)
+            torch.cuda.synchronize()
+            work.append(lib.spmv_acc_last_prepare_us())
+            assert oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, (strat, len(work))
+        return work
+
+    try:
+        for strat in ("adaptive", "flat"):
+            spmv_acc_amd.release_plans(drp)
+            calls(1, strat)  # (this process's first use of the kernels: code-object loads are not the plan's cost)
+            spmv_acc_amd.release_plans(drp)
+            lib.spmv_acc_set_tunable(b"first_call_budget", 0)  # unbounded: everything on the call's path in call 1
+            unbounded = calls(3, strat)
+            lib.spmv_acc_reset_tunables()
+            spmv_acc_amd.release_plans(drp)
+            bounded = calls(14, strat)
+            assert bounded[0] > 0 and unbounded[0] > 0
+            assert bounded[0] < 0.8 * unbounded[0], (strat, bounded[0], unbounded[0])  # the first call does less ...
+            assert sum(1 for w in bounded[1:] if w > 0) >= 1, (strat, bounded)          # ... later calls do the rest ...
+            assert bounded[-1] == 0.0 and bounded[-2] == 0.0, (strat, bounded)          # ... and then it is over
+            info = spmv_acc_amd.query_plan(drp, m)
+            assert info["stream_policy"] in (0, 1, 3)
+            if strat == "adaptive":
+                assert info["adaptive_family"] in (0, 1, 2) and info["flat_tiles"] > 0 and info["plus_blocks"] > 0  # every family was looked at
+            # everything up front instead
+            spmv_acc_amd.release_plans(drp)
+            assert spmv_acc_amd.prepare(m, n, nnz, drp, dci, dv, dx, strategy=strat) > 0
+            assert calls(3, strat) == [0.0, 0.0, 0.0], strat
+            # and a settled plan gives the same bits call after call
+            y1, y2 = dy0.clone(), dy0.clone()
+            spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y1, strategy=strat)
+            spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y2, strategy=strat)
+            torch.cuda.synchronize()
+            assert torch.equal(y1, y2)
+    finally:
+        lib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans(drp)
