@@ -29,7 +29,7 @@ constexpr int __WRAP_SIZE__ = __WF_SIZE__;
 // building_config.h.in:18-21: flavour of the wavefront-row reduction.  One DPP reduction serves all three names here; the
 // macros exist so that code written against the generated header compiles.  FLAT_SEGMENT_SUM_REDUCE (:40) and
 // DEVICE_SIDE_VERIFY (:37) arrive from the build (-D..., CMakeLists.txt options of the same names as config.cmake:9,51); the
-// former makes the segmented-scan reduction flat's default (tunable flat_reduce, engine.cpp), as strategy_picker.cpp:34-39 does.
+// former makes the segmented-scan reduction flat's default (tunable flat_reduce, config.cpp), as strategy_picker.cpp:34-39 does.
 #if !defined(WF_REDUCE_DEFAULT) && !defined(WF_REDUCE_LDS) && !defined(WF_REDUCE_REG)
 #define WF_REDUCE_DEFAULT
 #endif

@@ -92,6 +92,19 @@ void spmv_acc_csr_spmv_oop(int strategy, int trans, double alpha, double beta, i
                            const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx,
                            const double *dy_in, double *dy_out);
 
+/* ---- row sub-ranges of one matrix as consecutive launches over two streams (new) ------------------------------------------
+ * replaces: nothing in the reference (one kernel per SpMV on the NULL stream).  The compute side of the pipelined row-sharded step
+ * (spmv_acc_shard_step with pipeline > 1, spmv_acc_amd/dist.py): rows [row_cuts[k], row_cuts[k + 1]) of the matrix are chunk k,
+ * handed to the kernels as an un-rebased row sub-range (d_rowptr + row_cuts[k], the whole colindex / value arrays; nnz_ends[k] =
+ * rowptr[row_cuts[k + 1]], which the caller reads once); chunk k's kernels go to streams[k & 1] -- consecutive chunks are
+ * independent, on one stream each would wait for its predecessor's last wavefront -- and events[k] (a hipEvent_t the caller
+ * made; may be NULL) is recorded behind them, so that the caller can send chunk k on its way while chunk k + 1 computes.  ONE
+ * host call instead of one per chunk (each costs microseconds of a step that lasts tens).  y_out / y_in as spmv_acc_csr_spmv_oop,
+ * indexed by the matrix' rows.  The calling thread's library stream is left as it was.  Returns 0 or the first error. */
+int spmv_acc_csr_spmv_chunks(int strategy, double alpha, double beta, int n, int nchunks, const int *row_cuts, const int *nnz_ends,
+                             const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx,
+                             const double *dy_in, double *dy_out, void *const *streams, void *const *events);
+
 /* ---- row-block preprocessing pass, device form ---------------------------------------------------------
  * replaces: pre_calc_break_point<STRIDE, BLOCKS, int><<<1024,512>>>(row_ptr, m, break_points, bp_len)
  *           -- src/acc/hip-flat/flat_imp.inl:108-131, launched from flat.cpp:25,43.
@@ -318,7 +331,7 @@ double spmv_acc_copy_ceiling_gbs(void *d_dst, const void *d_src, long long bytes
 
 /* ---- switches (new) -------------------------------------------------------------------------------------------------
  * A/B knobs for tools/kbench.py ("xcd_chunk", "rowblock_target", "stream_plain", "flat_finish", "flat_npt", ...; the table
- * with every default is in spmv_acc_amd/csrc/engine.cpp) and one behavioural switch:
+ * with every default is in spmv_acc_amd/csrc/config.cpp) and one behavioural switch:
  *   "validate" (0): 1 = check rowptr / colindex of every new matrix on the device before the first launch (rowptr
  *   monotone and non-negative, rowptr[m] == nnz, 0 <= colindex < n); a matrix that fails is refused with
  *   SPMV_ACC_ERR_BAD_ARGUMENT on this and every later call and y is left untouched.  One pass over the indices per

@@ -14,6 +14,8 @@
 #include "../../include/spmv_acc.h"
 #include "engine.hpp"
 
+#include <string>
+
 using namespace spmv_acc;
 
 // ---- pinned host -> device staging -----------------------------------------------------------------------
@@ -144,6 +146,40 @@ void spmv_acc_csr_spmv_oop(int strategy, int trans, double alpha, double beta, i
                            const double *dy_in, double *dy_out) {
   run_spmv(strategy < 0 ? active_strategy() : strategy, trans, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx,
            dy_out, dy_in);
+}
+
+int spmv_acc_csr_spmv_chunks(int strategy, double alpha, double beta, int n, int nchunks, const int *row_cuts, const int *nnz_ends,
+                             const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx,
+                             const double *dy_in, double *dy_out, void *const *streams, void *const *events) {
+  if (nchunks < 0 || (nchunks > 0 && (!row_cuts || !nnz_ends || !d_rowptr || !dy_out || !streams))) {
+    set_error(kErrBadArgument, "spmv_acc_csr_spmv_chunks: bad argument");
+    return kErrBadArgument;
+  }
+  const int sid = strategy < 0 ? active_strategy() : strategy;
+  hipStream_t keep = get_stream();
+  int first_err = kOk;
+  std::string first_what;
+  clear_error();
+  for (int k = 0; k < nchunks; ++k) {
+    const int a = row_cuts[k], b = row_cuts[k + 1];
+    hipStream_t cs = static_cast<hipStream_t>(streams[k & 1]);
+    if (b > a && first_err == kOk) {
+      set_stream(cs);
+      run_spmv(sid, 0, alpha, beta, b - a, n, nnz_ends[k], nullptr, d_rowptr + a, d_colindex, d_value, dx, dy_out + a, dy_in ? dy_in + a : nullptr);
+      if (last_error() != kOk) {
+        first_err = last_error();
+        first_what = last_error_string();
+      }
+    }
+    // (the event is recorded whatever happened: the caller's exchange of chunk k waits for it)
+    if (events && events[k] && hipEventRecord(static_cast<hipEvent_t>(events[k]), cs) != hipSuccess && first_err == kOk) {
+      first_err = kErrHip;
+      first_what = "spmv_acc_csr_spmv_chunks: hipEventRecord failed";
+    }
+  }
+  set_stream(keep);
+  if (first_err != kOk) set_error(first_err, first_what);
+  return first_err;
 }
 
 int spmv_acc_break_points_len(int nnz, int stride) {

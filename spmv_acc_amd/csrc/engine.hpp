@@ -49,7 +49,7 @@ int last_error();
 const char *last_error_string();
 void clear_error();
 
-// measurement switches (see engine.cpp g_tunables); -1 for an unknown name
+// measurement switches (see config.cpp g_tunables); -1 for an unknown name
 int set_tunable(const char *name, int value);
 int get_tunable(const char *name);
 void reset_tunables();
@@ -137,7 +137,7 @@ struct PlanInfo {
 };
 bool query_plan(const int *d_rowptr, int m, PlanInfo *out);
 int cached_plan_count();
-// Persistent per-matrix choices (engine.cpp "tune cache"): path of the text file, null / "" = off; default = environment
+// Persistent per-matrix choices (plan.cpp "tune cache"): path of the text file, null / "" = off; default = environment
 // variable SPMV_ACC_TUNE_CACHE.
 void set_tune_cache(const char *path);
 // Re-copy the caller's VALUES into the plan-resident column slabs of this matrix (tunable col_slabs; no other plan data holds values).

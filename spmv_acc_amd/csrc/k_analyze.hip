@@ -20,7 +20,7 @@
 namespace spmv_acc {
 namespace {
 
-// closing row of the block that opens at row s (host form: engine.cpp::plus_analyze_host)
+// closing row of the block that opens at row s (host form: config.cpp::plus_analyze_host)
 __global__ __launch_bounds__(256) void next_kernel(const int *__restrict__ rp, int m, int min_nnz, int cap,
                                                    int *__restrict__ next) {
   const long long s_ll = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;

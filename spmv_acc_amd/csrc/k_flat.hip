@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
   const int t0 = t * STRIDE; // host guarantees nnz + stride fits in int
   const int t1 = (nnz - t0 > STRIDE) ? t0 + STRIDE : nnz;
 
-  // EARLY (chosen by timing on small grids, engine.cpp): the tile's stream loads go out before anything else, so the
+  // EARLY (chosen by timing on small grids, tuner.cpp): the tile's stream loads go out before anything else, so the
   // break point -> rowptr chain below overlaps them instead of preceding them.
   StreamRegs<EARLY ? NPT : 4> early_regs;
   const bool early = EARLY && xcd_chunk >= 0 && stage_fast_ok(t1, nnz); // (block-uniform)

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
   __shared__ double row_acc[kPlusMaxRows];
   __shared__ TileSpans spans;
   if (threadIdx.x == 0) spans.n = 0; // published by the barrier that follows the first staging
-  int g = reverse ? zigzag_block(blockIdx.x, nblocks) : static_cast<int>(blockIdx.x); // zigzag (engine.cpp)
+  int g = reverse ? zigzag_block(blockIdx.x, nblocks) : static_cast<int>(blockIdx.x); // zigzag (dispatch.cpp)
   if (xcd_chunk > 0) g = xcd_chunked_block(g, nblocks, xcd_chunk);
   const int4v rec = blk[g]; // wave-uniform: one scalar 16-B load
   const int row_begin = rec.x;

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   if (threadIdx.x == 0) spans.n = 0; // published by the barrier that follows the first staging
 
   int b = blockIdx.x;
-  if (flags & 64) b = zigzag_block(b, nblocks); // every other SpMV on a plan walks the matrix backwards (engine.cpp)
+  if (flags & 64) b = zigzag_block(b, nblocks); // every other SpMV on a plan walks the matrix backwards (dispatch.cpp)
   if (flags & 1) b = xcd_contiguous_block(b, nblocks);
   if (flags & 4) b = xcd_chunked_block(b, nblocks, flags >> 8);
 

@@ -14,7 +14,7 @@
 //
 // Build (once per plan, order inside a row preserved, no atomics): one wavefront per row, 64 non-zeros per step;
 //   count  : per step one ballot per slab, lane s keeps slab s's count            -> cnt[s][row]
-//   scan   : exclusive scan of each slab's counts (rocPRIM, engine.cpp)           -> rowptr_s
+//   scan   : exclusive scan of each slab's counts (rocPRIM, tuner.cpp)           -> rowptr_s
 //   scatter: the same walk; a non-zero's place = rowptr_s[row] + non-zeros of slab s before it in the row (ballot + popcount).
 #include "device_utils.hpp"
 #include "kernels.hpp"
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void slab_scatter_kernel(const int *__res
 }
 
 // A slab keeps only the rows that HAVE non-zeros in it (power-law matrices: R-MAT 25 in 8 slabs has 45 M non-empty (row, slab)
-// pairs out of 268 M): flags -> exclusive scan (engine.cpp) -> row-id list + the row pointers of those rows.
+// pairs out of 268 M): flags -> exclusive scan (tuner.cpp) -> row-id list + the row pointers of those rows.
 // rps: the slab's DENSE row pointers (m + 1); flags / pos: m + 1 ints.
 __global__ __launch_bounds__(kThreads) void slab_flags_kernel(const int *__restrict__ rps, int m, int *__restrict__ flags) {
   const long long r = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;

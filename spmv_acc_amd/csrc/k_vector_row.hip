@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))
   __shared__ TileSpans spans;
   if (threadIdx.x == 0) spans.n = 0; // published by the barrier that follows the first staging
   const int nblocks = gridDim.x;
-  int blk = reverse ? zigzag_block(blockIdx.x, nblocks) : static_cast<int>(blockIdx.x); // zigzag (engine.cpp)
+  int blk = reverse ? zigzag_block(blockIdx.x, nblocks) : static_cast<int>(blockIdx.x); // zigzag (dispatch.cpp)
   if (xcd_chunk > 0) blk = xcd_chunked_block(blk, nblocks, xcd_chunk);
   const bool second = blk >= nb0; // block-uniform: which matrix half (one width when row_split == m)
   const int w = second ? w1 : w0;

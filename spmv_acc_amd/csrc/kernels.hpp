@@ -16,12 +16,12 @@ struct CsrDev {
   const int *ci = nullptr;
   const double *v = nullptr;
   bool aligned16 = false; // ci and v are 16-byte aligned and nnz >= 8: wide-load kernels allowed
-  // Stale-plan guard (engine.cpp): kGuardSamples rowptr entries recorded when the plan was built (device array) and a
+  // Stale-plan guard (plan.cpp): kGuardSamples rowptr entries recorded when the plan was built (device array) and a
   // sticky flag in pinned host memory.  The first wave of block 0 of every SpMV kernel re-reads the samples and raises
   // the flag when the matrix behind these pointers is no longer the one the plan was built for.  Null: no check.
   const int *guard = nullptr;
   int *stale = nullptr;
-  // Gather hints (engine.cpp ensure_hint, k_hint.hip): one bit per non-zero, set where the non-zero's x line is NOT among the
+  // Gather hints (tuner.cpp ensure_hint, k_hint.hip): one bit per non-zero, set where the non-zero's x line is NOT among the
   // hot lines that fit an L2; the tile kernels (row blocks, row-block-plus, flat) issue those gathers non-temporal.  Null: no hints (set per launch by the
   // engine: only while the plan's timed comparison says they pay, and only where x is below 4 GB).  Speed only.
   const unsigned char *cold = nullptr;
@@ -168,7 +168,7 @@ struct FlatPlan {
   int stream_policy = 0;    // cache policy of the stream loads (kStreamPolicy*)
   bool can_finish = false;  // no row runs more than kFlatFinish non-zeros past the tile it starts in (plan-time probe)
   bool needs_fixup = true;  // true: every cut row is folded from carries by the fix-up kernel; false (only when
-                            // can_finish): tiles finish their cut rows themselves.  Chosen by timing, engine.cpp.
+                            // can_finish): tiles finish their cut rows themselves.  Chosen by timing, tuner.cpp.
   int max_tile_rows = 0;    // most rows any one tile (= workgroup) owns (plan-time probe)
   bool early_stream = false; // issue the tile's stream loads before the break point -> rowptr chain (small grids, timed)
   bool reverse = false;     // this launch walks the tiles in reverse order (zigzag, set per launch by the engine)

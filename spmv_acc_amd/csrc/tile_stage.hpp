@@ -21,7 +21,7 @@ namespace dev {
 // Slots of lds whose non-zero index is < a-block's-first-nnz or >= hi hold unspecified values; no
 // reader touches them.
 //
-// HINT (gather hints, engine.cpp ensure_hint): `cold` holds one bit per non-zero, set where the plan's column census found the
+// HINT (gather hints, tuner.cpp ensure_hint): `cold` holds one bit per non-zero, set where the plan's column census found the
 // x line of that non-zero outside the set of hot lines that fit an L2.  Cold gathers are issued non-temporal, so the lines they
 // bring do not displace the hot ones (skewed_gather_bench.hip: 66 -> 74-76 G gathers/s on R-MAT columns; non-temporal for ALL
 // gathers: 43).  The bits only steer the cache policy: stale or arbitrary bits cannot change a sum.

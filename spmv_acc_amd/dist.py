@@ -107,6 +107,12 @@ class RowShardedSpmv:
         # the pipelined step alternates its chunks' kernels over two streams: consecutive chunks are independent, and on ONE stream
         # each kernel waits for its predecessor's last wavefront (one rank, headline matrix, C = 8: 0.245 ms against 0.156 for C = 1)
         self.chunk_streams = [self.compute_stream, torch.cuda.Stream(device=device)] if self._gpu else None
+        self.exchange_stream = torch.cuda.Stream(device=device) if self._gpu else None
+        # where a pipelined step's chunk kernels run: "two" (alternating over the two chunk streams: consecutive chunks overlap their tails; the
+        # step pays two cross-stream hand-overs) or "current" (the caller's stream, back to back: no hand-over, but every kernel -> event ->
+        # kernel boundary on one stream is a ~13 us bubble).  One rank, headline matrix, dependent step, C = 1 / 2 / 4 / 8:
+        # two 0.159 / 0.186 / 0.194 / 0.201 ms, current 0.159 / 0.178 / 0.204 / 0.251 ms (round 3: 0.156 / 0.190 / 0.208 / 0.245)
+        self.chunk_stream_mode = "two"
         self.spmv_done = None  # event behind the latest local SpMV (GPU only)
         self.exchange_issued_after_spmv = None  # for tests: did the latest exchange wait for that event?
 
@@ -158,12 +164,42 @@ class RowShardedSpmv:
         for k, (a, b, rp, ci, v, nnz, h_rp) in enumerate(self._chunk_arrays(depth)):
             if b <= a:
                 continue
-            if self._gpu and depth > 1:  # on the stream the chunk's kernels will use
+            if self._gpu and depth > 1 and self.chunk_stream_mode == "two":  # on the stream the chunk's kernels will use
                 with self.torch.cuda.stream(self.chunk_streams[k & 1]):
                     ms += spmv_acc_amd.prepare(b - a, self.n, nnz, rp, ci, v, x, strategy=self.strategy, h_rowptr=h_rp, beta=beta)
             else:
                 ms += spmv_acc_amd.prepare(b - a, self.n, nnz, rp, ci, v, x, strategy=self.strategy, h_rowptr=h_rp, beta=beta)
         return ms
+
+    def _hip_chunks(self, alpha, beta, x, own, y_in, depth, streams):
+        """The compute side of a pipelined step in ONE library call (spmv_acc_csr_spmv_chunks): every chunk's kernels on its chunk
+        stream, an event behind each.  Per-chunk Python calls cost ~12 us apiece -- 8 chunks of a 160 us step took 245 us with the
+        GPU waiting for the host.  Returns the chunks' events (torch events, recorded once at first use so that their handles exist)."""
+        import ctypes
+
+        torch = self.torch
+        key = ("hip", depth)
+        if key not in self._chunks:
+            chunks = self._chunk_arrays(depth)
+            cuts = [chunks[0][0]] + [c[1] for c in chunks]
+            ends = [c[5] for c in chunks]
+            evs = []
+            for k in range(len(chunks)):
+                e = torch.cuda.Event()
+                e.record(streams[k & 1])  # (torch creates the underlying hipEvent_t at the first record)
+                evs.append(e)
+            self._chunks[key] = dict(
+                n=len(chunks), cuts=(ctypes.c_int * len(cuts))(*cuts), ends=(ctypes.c_int * len(ends))(*ends),
+                events=(ctypes.c_void_p * len(evs))(*[int(e.cuda_event) for e in evs]), torch_events=evs)
+        C = self._chunks[key]
+        lib = spmv_acc_amd.load_library()
+        rc = lib.spmv_acc_csr_spmv_chunks(spmv_acc_amd.strategy_id(self.strategy), alpha, beta, self.n, C["n"], C["cuts"], C["ends"],
+                                          self.rowptr.data_ptr(), self.cols.data_ptr(), self.vals.data_ptr(), x.data_ptr(),
+                                          0 if y_in is None else y_in.data_ptr(), own.data_ptr(),
+                                          (ctypes.c_void_p * 2)(streams[0].cuda_stream, streams[1].cuda_stream), C["events"])
+        if rc != 0:
+            raise spmv_acc_amd.SpmvAccError(lib.spmv_acc_last_error_string().decode())
+        return C["torch_events"]
 
     def _hip_spmv(self, alpha, beta, x, y_out, y_in, chunk):
         a, b, rp, ci, v, nnz, h_rp = chunk
@@ -216,20 +252,36 @@ class RowShardedSpmv:
                 if not solo:
                     works = self._issue_exchange(cur, group)
             else:
-                for q in self.chunk_streams:
-                    q.wait_stream(cur_stream)
                 self.wait()  # (the pipelined exchange starts during this step: the previous one must have ended)
-                events = []
-                for k, ch in enumerate(chunks):  # all kernels go out at once, alternating over the two chunk streams
-                    q = self.chunk_streams[k & 1]
-                    with torch.cuda.stream(q):
-                        local(ch)
-                        events.append(q.record_event())
+                two = self.chunk_stream_mode == "two"
+                if two:
+                    for q in self.chunk_streams:
+                        q.wait_stream(cur_stream)
+                if self.local_spmv == self._hip_spmv:
+                    # ONE library call for all chunks; their kernels alternate over the two chunk streams (default) or run back to back on
+                    # the current stream (chunk_stream_mode, see __init__)
+                    events = self._hip_chunks(alpha, beta, x, own, y_in, depth, (self.chunk_streams if two else [cur_stream, cur_stream]))
+                else:
+                    events = []
+                    for k, ch in enumerate(chunks):  # all kernels go out at once, alternating over the two chunk streams
+                        q = self.chunk_streams[k & 1]
+                        with torch.cuda.stream(q):
+                            local(ch)
+                            events.append(q.record_event())
                 self.spmv_done = events[-1]
-                for (c0, c1), ev in zip(self.chunk_bounds(depth), events):
-                    cur_stream.wait_event(ev)  # chunk c travels as soon as ITS kernel has finished, while chunk c+1 computes
-                    if not solo:
-                        works += self._issue_exchange(cur, group, rows=(c0, c1))
+                if two or self.local_spmv != self._hip_spmv:
+                    for (c0, c1), ev in zip(self.chunk_bounds(depth), events):
+                        cur_stream.wait_event(ev)  # chunk c travels as soon as ITS kernel has finished, while chunk c+1 computes
+                        if not solo:
+                            works += self._issue_exchange(cur, group, rows=(c0, c1))
+                elif not solo:
+                    # kernels on the current stream: each chunk's exchange is issued from the exchange stream behind that chunk's event, so it
+                    # is ordered after chunk c and not after the chunks enqueued behind it; the caller's stream meets the exchanges in wait()
+                    xs = self.exchange_stream
+                    with torch.cuda.stream(xs):
+                        for (c0, c1), ev in zip(self.chunk_bounds(depth), events):
+                            xs.wait_event(ev)
+                            works += self._issue_exchange(cur, group, rows=(c0, c1))
                 self.exchange_issued_after_spmv = True
         else:
             self.wait()

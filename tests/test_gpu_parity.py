@@ -1381,7 +1381,7 @@ def test_giant_rows(torch_dev):
 
 def test_hypersparse_rows(torch_dev, hiplib):
     """Five million rows, 3000 non-zeros: every non-zero falls into one or two flat tiles, which would own millions of (empty)
-    rows each -- flat hands such matrices to the fixed row blocks (engine.cpp kFlatMaxTileRows).  All strategies against a
+    rows each -- flat hands such matrices to the fixed row blocks (dispatch.cpp kFlatMaxTileRows).  All strategies against a
     device-side evaluation; beta != 0 so every empty row must still be scaled."""
     import time
 

@@ -1180,3 +1180,65 @@ def test_first_call_is_bounded_and_later_calls_finish_the_timings(torch_dev, ora
     finally:
         lib.spmv_acc_reset_tunables()
         spmv_acc_amd.release_plans(drp)
+
+
+def test_chunks_entry_equals_per_chunk_calls(torch_dev, oracle, hiplib):
+    """spmv_acc_csr_spmv_chunks (round 4): row sub-ranges of one matrix as consecutive launches alternating over two streams, an event behind
+    each, in ONE host call -- the compute side of the pipelined sharded step.  Same bits as one call per chunk on un-rebased views; rows outside
+    the cuts untouched; every event is recorded behind its chunk; the calling thread's library stream is left alone; ragged and empty chunks."""
+    import ctypes
+
+    torch = torch_dev
+    m, n = 120_000, 90_000
+    rowptr, cols, vals = synth.random_csr(m, n, 8, seed=5, kind="powerlaw")
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(2)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    cuts = [1000, 1000, 31000, 31007, 90000, 119999]  # an empty chunk, a 7-row chunk, rows [0, 1000) and the last row left out
+    ends = [int(rowptr[c]) for c in cuts[1:]]
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    evs = []
+    for k in range(len(cuts) - 1):
+        e = torch.cuda.Event()
+        e.record((s0, s1)[k & 1])
+        evs.append(e)
+    torch.cuda.synchronize()
+    before = hiplib.spmv_acc_get_stream()
+    try:
+        for strat in ("adaptive", "flat", "line_enhance"):
+            for alpha, beta in ((1.0, 1.0), (0.5, 0.0)):
+                # per-chunk reference on settled plans
+                want = dy0.clone()
+                for k in range(len(cuts) - 1):
+                    a, b = cuts[k], cuts[k + 1]
+                    if b > a:
+                        spmv_acc_amd.prepare(b - a, n, ends[k], drp[a:], dci, dv, dx, strategy=strat, beta=beta)
+                        spmv_acc_amd.csr_spmv(alpha, beta, b - a, n, ends[k], drp[a:], dci, dv, dx, want[a:], strategy=strat)
+                torch.cuda.synchronize()
+                got = dy0.clone()
+                torch.cuda.synchronize()
+                rc = hiplib.spmv_acc_csr_spmv_chunks(spmv_acc_amd.strategy_id(strat), alpha, beta, n, len(cuts) - 1, (ctypes.c_int * len(cuts))(*cuts),
+                                                     (ctypes.c_int * len(ends))(*ends), drp.data_ptr(), dci.data_ptr(), dv.data_ptr(), dx.data_ptr(), 0,
+                                                     got.data_ptr(), (ctypes.c_void_p * 2)(s0.cuda_stream, s1.cuda_stream),
+                                                     (ctypes.c_void_p * len(evs))(*[int(e.cuda_event) for e in evs]))
+                assert rc == 0, hiplib.spmv_acc_last_error_string()
+                for e in evs:
+                    e.synchronize()  # (each event sits behind its chunk's kernels: waiting for all of them is waiting for the step)
+                assert torch.equal(got, want), (strat, alpha, beta)
+                assert torch.equal(got[:1000], dy0[:1000]) and torch.equal(got[119999:], dy0[119999:])
+                assert hiplib.spmv_acc_get_stream() == before
+        ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+        y = dy0.clone()
+        full_cuts = [0, 40000, 80000, m]
+        torch.cuda.synchronize()
+        rc = hiplib.spmv_acc_csr_spmv_chunks(-1, 1.0, 1.0, n, 3, (ctypes.c_int * 4)(*full_cuts), (ctypes.c_int * 3)(*[int(rowptr[c]) for c in full_cuts[1:]]),
+                                             drp.data_ptr(), dci.data_ptr(), dv.data_ptr(), dx.data_ptr(), 0, y.data_ptr(),
+                                             (ctypes.c_void_p * 2)(s0.cuda_stream, s1.cuda_stream), None)
+        torch.cuda.synchronize()
+        assert rc == 0 and oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL
+        assert hiplib.spmv_acc_csr_spmv_chunks(-1, 1.0, 1.0, n, 2, None, None, drp.data_ptr(), dci.data_ptr(), dv.data_ptr(), dx.data_ptr(), 0, y.data_ptr(),
+                                               None, None) == 2  # SPMV_ACC_ERR_BAD_ARGUMENT
+    finally:
+        hiplib.spmv_acc_clear_error()
+        spmv_acc_amd.release_plans()
