@@ -286,7 +286,15 @@ void spmv_acc_set_stream(void *hip_stream); /* hipStream_t; NULL = the NULL stre
                                              * launches only and may be captured into a hipGraph; the first call on a matrix
                                              * (plan: allocations, synchronisation, timings) must run outside a capture: a call that
                                              * would need such work inside a capture enqueues nothing and reports
-                                             * SPMV_ACC_ERR_BAD_ARGUMENT (timed choices that are merely missing are skipped instead). */
+                                             * SPMV_ACC_ERR_BAD_ARGUMENT (timed choices that are merely missing are skipped instead).
+                                             * A thread that never set a stream launches on the NULL stream; if another thread HAS set
+                                             * one, the first such launch prints a one-time note on stderr (SPMV_ACC_QUIET=1: none).
+                                             * A plan remembers the stream of its latest call to order a call on another stream behind
+                                             * it: before destroying a stream, synchronise it or release the plans used on it.
+                                             * The first call on a matrix spends at most ~20 SpMV-equivalents on per-matrix timings
+                                             * (tunable first_call_budget) and the following calls finish them; until they have, two
+                                             * calls may run different kernels, i.e. sum in a different order -- spmv_acc_prepare
+                                             * settles everything up front, tunable deterministic times nothing at all. */
 void *spmv_acc_get_stream(void);
 
 int spmv_acc_last_error(void); /* 0 = ok; see enum below.  Per host thread, like errno. */

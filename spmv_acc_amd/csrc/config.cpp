@@ -60,7 +60,26 @@ thread_local unsigned t_plan_work = 0; // bumped by every once-per-matrix step (
 
 double last_prepare_us() { return t_last_prepare_us; }
 
-void set_stream(hipStream_t s) { t_stream = s; }
+// The library stream is per host thread.  A consumer written for a process-wide stream (round 2's semantics) that sets it once on its main
+// thread and calls from workers would launch on the NULL stream without any sign: the first such call says so, once per process, on stderr
+// (SPMV_ACC_QUIET=1 silences it).  Threads that mean the NULL stream call spmv_acc_set_stream(NULL) themselves.
+namespace detail {
+thread_local bool t_stream_was_set = false;
+std::atomic<bool> g_some_thread_set_a_stream{false};
+void note_stream_use() {
+  static std::atomic<bool> said{false};
+  if (t_stream_was_set || !g_some_thread_set_a_stream.load(std::memory_order_relaxed) || said.exchange(true)) return;
+  const char *quiet = std::getenv("SPMV_ACC_QUIET");
+  if (quiet && *quiet && *quiet != '0') return;
+  std::fprintf(stderr, "spmv_acc: a host thread that never called spmv_acc_set_stream is launching on the NULL stream while another thread has set a "
+                       "stream -- the library stream is per host thread (include/spmv_acc.h); call spmv_acc_set_stream in every calling thread\n");
+}
+} // namespace detail
+void set_stream(hipStream_t s) {
+  t_stream = s;
+  t_stream_was_set = true;
+  if (s) g_some_thread_set_a_stream.store(true, std::memory_order_relaxed);
+}
 hipStream_t get_stream() { return t_stream; }
 
 // ---- tunables (A/B switches for measurement; defaults are the shipped configuration) ----------------------

@@ -581,6 +581,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     }
   }
   hipStream_t st = t_stream;
+  note_stream_use();
   {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     t_capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cstdarg>
@@ -31,6 +32,7 @@ namespace detail {
 
 // ---- config.cpp: errors, stream, tunables ------------------------------------------------------------------------------------------------
 extern thread_local hipStream_t t_stream;
+void note_stream_use(); // one-time stderr note when a thread without a stream of its own launches while another thread has one
 extern std::mutex g_mu; // the plan cache's lock (never held together with a plan's own)
 bool hip_ok(hipError_t e, const char *what);
 int last_error_code_only();

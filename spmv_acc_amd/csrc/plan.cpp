@@ -132,7 +132,11 @@ bool tune_cache_enabled() {
   tune_load_locked();
   return !g_tune_path.empty();
 }
-unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *samples) {
+// What the adopted choices depend on, all of it in the key (round 4; until then: version string, device, shape, 64 rowptr samples, so that a
+// matrix with the same row structure and other columns, a changed tunable or a rebuilt library adopted stale choices -- correct, legality is
+// re-checked, but not re-timed): + 64 colindex samples (the column distribution decides hints, slab passes, adaptive's family), + the
+// tunables the timings were taken under, + the build's date and time.
+unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *samples, const int *col_samples) {
   unsigned long long h = 1469598103934665603ULL; // FNV-1a
   auto mix = [&h](const void *p, size_t bytes) {
     const unsigned char *c = static_cast<const unsigned char *>(p);
@@ -151,6 +155,14 @@ unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *sample
   mix(&n, sizeof(int));
   mix(&nnz, sizeof(int));
   mix(samples, sizeof(int) * kGuardSamples);
+  if (col_samples) mix(col_samples, sizeof(int) * kGuardSamples);
+  static const char kBuild[] = __DATE__ " " __TIME__;
+  mix(kBuild, sizeof(kBuild));
+  for (TunableId id : {kT_rowblock_target, kT_vector_target, kT_hint_budget_kb, kT_tune_protocol, kT_cache_ends_mb, kT_zigzag, kT_xcd_chunk, kT_xcd_chunk_tiles,
+                       kT_slab_whole_below, kT_rowlen, kT_legacy_kernels}) {
+    const int v = tun(id);
+    mix(&v, sizeof(int));
+  }
   return h ? h : 1;
 }
 
@@ -404,9 +416,14 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
     launch_guard_fill(t_stream, rp, m, const_cast<int *>(p->A.guard));
     if (!hip_ok(hipStreamSynchronize(t_stream), "record the plan guard")) return nullptr; // (a later call may use another stream)
     if (tune_cache_enabled() && !tun(kT_deterministic)) {
-      int samples[kGuardSamples];
-      if (hipMemcpy(samples, p->A.guard, sizeof(samples), hipMemcpyDeviceToHost) == hipSuccess) {
-        p->tune_key = tune_key_of(dev, m, n, nnz, samples);
+      int samples[kGuardSamples], col_samples[kGuardSamples] = {};
+      bool ok = hipMemcpy(samples, p->A.guard, sizeof(samples), hipMemcpyDeviceToHost) == hipSuccess;
+      // colindex[rowptr[0] + k * (extent - 1) / 63]: 64 four-byte reads, once per plan, only with the tune cache on
+      const long long first = samples[0], extent = static_cast<long long>(samples[kGuardSamples - 1]) - first;
+      for (int k = 0; ok && ci && extent > 0 && k < kGuardSamples; ++k)
+        ok = hipMemcpy(&col_samples[k], ci + first + k * (extent - 1) / (kGuardSamples - 1), sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+      if (ok) {
+        p->tune_key = tune_key_of(dev, m, n, nnz, samples, col_samples);
         tune_adopt(*p);
       }
       (void)hipGetLastError();

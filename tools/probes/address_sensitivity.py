@@ -2,7 +2,7 @@
 """Does the ranking of the stream cache policies depend on WHERE y lives?  Same matrix, same plan, pinned policy, several y
 buffers (fresh allocations separated by pads of different sizes)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import spmv_acc_amd
 from spmv_acc_amd import synth

@@ -3,7 +3,7 @@
 Lower-bound probe: per slab, the shipped kernels run the compacted sub-matrix into a compact y_s (beta = 0); the merge of y_s into y
 through the row ids is costed at its bytes (8 B y_s + 4 B row id + 16 B y read-modify-write per non-empty row) over 6 TB/s."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -4,7 +4,7 @@ falls in slab s ((line >> 0) & (S-1) interleaved, or contiguous column ranges), 
 sequential SpMVs of the shipped kernels.  Every phase gathers from 1/S of x, so each L2 holds a hot set S times deeper.
 Sub-matrices are built here with torch (a library version would build them once per plan)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

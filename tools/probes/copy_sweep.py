@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Streaming-copy ceiling vs footprint and cache policy (non-temporal vs default loads/stores)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, spmv_acc_amd
 lib = spmv_acc_amd.load_library()
 for mb in (16, 64, 128, 512, 2048, 8192):

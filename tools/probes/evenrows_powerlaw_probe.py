@@ -2,7 +2,7 @@
 """Matrices with EVEN row lengths and power-law columns (x beyond the caches): does the column-slab pass over run lists pay where the
 rows need no rescue?  line_enhance / adaptive / adaptive_plus as shipped against slab_segments forced."""
 import sys, numpy as np, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import spmv_acc_amd
 lib = spmv_acc_amd.load_library()
 for (m, n, per_row, power) in ((300_000, 16_000_000, 40, 6), (2_000_000, 33_000_000, 16, 6), (2_000_000, 33_000_000, 16, 3), (4_000_000, 16_000_000, 8, 12)):

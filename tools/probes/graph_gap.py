@@ -2,7 +2,7 @@
 """Back-to-back launches vs one hipGraph holding the same launches, on the small / medium sweep stand-ins: what the
 inter-kernel gap costs a launch-bound SpMV loop (steady-state calls are launches only, so they capture)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import spmv_acc_amd

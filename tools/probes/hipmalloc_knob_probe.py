@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """On arrays held in one hipMalloc each (all 2 MB-aligned: the placement a C / C++ caller gets), which engine knobs move the large sweep stand-ins?"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, spmv_acc_amd
 from spmv_acc_amd import synth
 lib = spmv_acc_amd.load_library()

@@ -2,7 +2,7 @@
 """Which array's position matters?  All five arrays of a stand-in in raw hipMalloc allocations (2 MB-aligned), then ONE of them shifted inside a
 padded allocation by an odd amount (1 MB + 68 KB + 256 B), line_enhance with every choice pinned, per-launch protocol, us."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, spmv_acc_amd
 from spmv_acc_amd import synth
 lib = spmv_acc_amd.load_library()

@@ -2,7 +2,7 @@
 """The same stand-in in torch's caching allocator (as bench.py holds it) and in one hipMalloc per array (spmv_acc_stage_csr: how the reference's harness and
 any C / C++ caller hold a matrix, cli/utils.hpp:104-114), in a process that also holds the headline matrix.  adaptive / flat, per-launch protocol, us."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, spmv_acc_amd
 from spmv_acc_amd import synth
 lib = spmv_acc_amd.load_library()

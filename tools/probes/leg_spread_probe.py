@@ -2,7 +2,7 @@
 """How much of a bench leg's figure is WHERE its vectors and plan tables happen to lie: one stand-in, one strategy, N fresh (y, plan) pairs in one process --
 (a) y re-cloned and the plan rebuilt each time, as bench.py's legs do; (b) one y kept, plan rebuilt; (c) y re-cloned, plan kept.  Per-launch protocol, median of 60."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, spmv_acc_amd
 from spmv_acc_amd import synth
 name = sys.argv[1] if len(sys.argv) > 1 else "Bump_2911"

@@ -2,7 +2,7 @@
 """Strategies on a matrix of 70 M rows (more than 2^26: a grid of one wavefront per row would be 2^32 work-items, HIP's limit per launch) with few non-zeros:
 every strategy and the slab modes against an independent device evaluation."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import spmv_acc_amd
 lib = spmv_acc_amd.load_library()

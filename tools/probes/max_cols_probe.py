@@ -2,7 +2,7 @@
 """The column-count limit: n = 2,147,483,000 (x = 17 GB), 1 M rows of 8 sorted random columns each -- column arithmetic (slab widths, byte offsets of the
 gathers, the census' line index) next to INT_MAX.  Every strategy + the slab modes against an independent device evaluation."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, spmv_acc_amd
 lib = spmv_acc_amd.load_library()
 m, n, per_row = 1_000_000, 2_147_483_000, 8

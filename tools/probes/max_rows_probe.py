@@ -2,7 +2,7 @@
 """The row-count and non-zero-count limits at once: 2,147,400,000 rows with one non-zero each (+ one row of 5001), nnz = 2,147,405,000 (the int32
 tile arithmetic allows INT_MAX - 65536), y in closed form -- every strategy that makes sense on one-element rows, and the run-list build."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, spmv_acc_amd
 lib = spmv_acc_amd.load_library()
 m, n, extra = 2_147_400_000, 1 << 20, 5000

@@ -3,7 +3,7 @@
 Each large sweep stand-in as generated, then the SAME arrays cloned into allocations of their own (what a caller that hipMallocs each array holds --
 the reference's harness does, cli/utils.hpp:104-114), adaptive and flat, per-launch protocol, in a process that also holds the headline matrix."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, spmv_acc_amd
 from spmv_acc_amd import synth
 head = synth.hardesty3_like_torch(device="cuda")

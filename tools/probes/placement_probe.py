@@ -2,7 +2,7 @@
 """Does WHERE the matrix lives matter?  The same stand-in generated several times in one process behind pads of different sizes (so its
 arrays land at different virtual -- and physical -- addresses), the same pinned plan each time; back-to-back and per-launch times."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import spmv_acc_amd

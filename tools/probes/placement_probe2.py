@@ -2,7 +2,7 @@
 """placement_probe.py with knobs: for each placement of one stand-in, back-to-back time under several pinned variants -- does any of
 them recover what an unlucky placement loses?"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import spmv_acc_amd
