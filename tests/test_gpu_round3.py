@@ -508,7 +508,8 @@ def test_shard_handle_api_on_a_one_rank_communicator(torch_dev, oracle, hiplib):
     """spmv_acc_shard_create / _step / _destroy with a communicator from spmv_acc_rccl_comm_init_all (ncclCommInitAll bound at run
     time, as spmv-cli --gpus N uses it): the step computes this rank's rows straight into the gathered vector -- in place
     (dy_in NULL) and out of place (old slice elsewhere, untouched) -- and exchanges in place: one allgather (pipeline 1) or the
-    chunked point-to-point form (pipeline 4, rebased chunk rowptrs, second stream, events).  One rank is all this box allows; every
+    chunked point-to-point form (pipeline 4: chunks as un-rebased row sub-ranges, their kernels alternating over two streams of the shard's own,
+    an exchange stream, events); spmv_acc_shard_prepare settles every chunk's plan first.  One rank is all this box allows; every
     RCCL call that a one-rank communicator makes is made."""
     import ctypes
 
@@ -532,12 +533,18 @@ def test_shard_handle_api_on_a_one_rank_communicator(torch_dev, oracle, hiplib):
                                                   drp.data_ptr(), dci.data_ptr(), dv.data_ptr(), pipeline)
                 assert rc == 0, hiplib.spmv_acc_last_error_string()
                 assert hiplib.spmv_acc_shard_pipeline(shard) == pipeline
+                # round 4: every chunk's plan built and tuned up front, outside any collective -- the steps below find nothing left to prepare
+                assert hiplib.spmv_acc_shard_prepare(shard, beta, dx.data_ptr()) == 0, hiplib.spmv_acc_last_error_string()
+                assert hiplib.spmv_acc_shard_prepare(shard, beta, None) == 2 and hiplib.spmv_acc_shard_prepare(None, beta, dx.data_ptr()) == 2
+                hiplib.spmv_acc_clear_error()
                 ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
                 # out of place: the old slice stays where it is
                 y_full = torch.zeros(pad, dtype=torch.float64, device="cuda")
                 torch.cuda.synchronize()
                 assert hiplib.spmv_acc_shard_step(shard, alpha, beta, dx.data_ptr(), dy0.data_ptr(), y_full.data_ptr()) == 0, \
                     hiplib.spmv_acc_last_error_string()
+                assert hiplib.spmv_acc_last_prepare_us() == 0.0, (pipeline, strat, "a prepared shard's step did plan work")
+                assert hiplib.spmv_acc_get_stream() == side.cuda_stream  # (the chunks ran on the shard's own streams; the caller's is back)
                 side.synchronize()
                 got = y_full.cpu().numpy()
                 assert oracle.scaled_error(got[:m], ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL, (pipeline, strat)

@@ -101,15 +101,22 @@ for case in range(cases):
                 ("adaptive", {"guard_full": 1}), ("light", {}), ("block_row_ordinary", {}), ("light", {"oop": 1}),
                 ("flat", {"flat_rowblock": 1}), ("flat", {"flat_rowblock": 0}), ("line_enhance", {"rowblock_target": 1900}),
                 # column-slab passes over run lists, forced (rows whose columns do not ascend take the ordinary path)
-                ("line_enhance", {"slab_segments": 4}), ("adaptive", {"slab_segments": 16}), ("flat", {"slab_segments": 2, "oop": 1})]
-    for strat, knobs in variants:
+                ("line_enhance", {"slab_segments": 4}), ("adaptive", {"slab_segments": 16}), ("flat", {"slab_segments": 2, "oop": 1}),
+                # round 4: the first-call budget (several calls on one plan: every state of the lazily finished timings must be right -- "calls" is this
+                # script's switch), the unbounded first call, the two-class run lists at both extremes
+                ("adaptive", {"calls": 5}), ("flat", {"calls": 5}), ("adaptive_plus", {"calls": 4}), ("line_enhance", {"calls": 3, "oop": 1}),
+                ("adaptive", {"first_call_budget": 0}), ("adaptive", {"first_call_budget": 1, "later_call_budget": 1, "calls": 6}),
+                ("line_enhance", {"slab_segments": 8, "slab_whole_below": 0}), ("adaptive", {"slab_segments": 4, "slab_whole_below": 1 << 30}),
+                ("flat", {"slab_segments": 3, "slab_whole_below": 5, "calls": 2})]
+    for strat, knobs in [(s_, dict(k_, call=c_)) for s_, k_ in variants for c_ in range(k_.get("calls", 1))]:
         lib.spmv_acc_reset_tunables()
         oop = bool(knobs.get("oop"))
         for k_, v_ in knobs.items():
-            if k_ != "oop":
+            if k_ not in ("oop", "calls", "call"):
                 assert lib.spmv_acc_set_tunable(k_.encode(), v_) == 0
-        if knobs:
+        if len(knobs) > 1 and knobs["call"] == 0:  # (a later call of a "calls" variant continues on the plan its first call made)
             spmv_acc_amd.release_plans(rp32[r0:])
+        knobs = {k_: v_ for k_, v_ in knobs.items() if not (k_ == "call" and "calls" not in knobs)}
         y = y0.clone()
         if oop:  # y_out = alpha*A*x + beta*y_in: the old slice is read from a second vector, which must come back untouched
             y_in = y0.clone()
