@@ -11,7 +11,7 @@ def free(): torch.cuda.synchronize(); return torch.cuda.mem_get_info()[0]
 f0=None
 lib = spmv_acc_amd.load_library()
 # (round 3: the opt-in modes too -- run lists, slab-major copies, the full row-pointer digest, LIGHT's counter, a second stream's ordering event)
-side = torch.cuda.Stream()
+side = torch.cuda.Stream(); side2 = torch.cuda.Stream()
 for it in range(300):
     for s in ("adaptive","flat","adaptive_plus","line_enhance","vector_row","default","light","thread_row"):
         spmv_acc_amd.csr_spmv(1.0,0.0,20000,20000,nnz,drp,dci,dv,x,y,strategy=s)
@@ -19,6 +19,19 @@ for it in range(300):
         for k, val in knobs.items(): lib.spmv_acc_set_tunable(k.encode(), val)
         spmv_acc_amd.csr_spmv(1.0,0.0,20000,20000,nnz,drp,dci,dv,x,y,strategy="flat" if "col16" in knobs else "line_enhance")
         lib.spmv_acc_reset_tunables()
+    # round 4: lazily finished timings (several calls per plan), the two-class run lists, spmv_acc_prepare, the chunks entry on two streams
+    for _ in range(4):
+        spmv_acc_amd.csr_spmv(1.0,1.0,20000,20000,nnz,drp,dci,dv,x,y,strategy="adaptive")
+    spmv_acc_amd.prepare(20000,20000,nnz,drp,dci,dv,x,strategy="flat")
+    lib.spmv_acc_set_tunable(b"slab_segments", 8); lib.spmv_acc_set_tunable(b"slab_whole_below", 6)
+    spmv_acc_amd.csr_spmv(1.0,1.0,20000,20000,nnz,drp,dci,dv,x,y,strategy="line_enhance")
+    lib.spmv_acc_reset_tunables()
+    import ctypes
+    cuts=[0,7000,7000,20000]; ends=[int(rowptr[c]) for c in cuts[1:]]
+    lib.spmv_acc_csr_spmv_chunks(-1,1.0,0.0,20000,3,(ctypes.c_int*4)(*cuts),(ctypes.c_int*3)(*ends),drp.data_ptr(),dci.data_ptr(),dv.data_ptr(),x.data_ptr(),0,y.data_ptr(),
+                                 (ctypes.c_void_p*2)(side.cuda_stream, side2.cuda_stream), None)
+    for a_,b_ in zip(cuts[:-1],cuts[1:]):
+        if b_>a_: spmv_acc_amd.release_plans(drp[a_:])
     lib.spmv_acc_set_stream(side.cuda_stream)
     spmv_acc_amd.csr_spmv(1.0,0.0,20000,20000,nnz,drp,dci,dv,x,y,strategy="flat")
     lib.spmv_acc_set_stream(None)
