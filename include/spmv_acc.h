@@ -279,6 +279,10 @@ int spmv_acc_query_plan_beta0(const int *d_rowptr, int m);
  * 0 = the plan runs the named strategy's own kernel; -2 = no such plan.  No reference counterpart: the reference has one path per
  * strategy (strategy_picker.cpp:19-65). */
 int spmv_acc_query_plan_slab_passes(const int *d_rowptr, int m);
+/* 1: the latest call on this plan left none of its per-matrix timings open -- the plan is settled, calls are launches only and bitwise stable;
+ * 0: the first-call budget (tunable first_call_budget) deferred some, the next calls resume them (or call spmv_acc_prepare); -2 = no such plan.
+ * No reference counterpart (the reference times nothing). */
+int spmv_acc_query_plan_settled(const int *d_rowptr, int m);
 
 void spmv_acc_set_stream(void *hip_stream); /* hipStream_t; NULL = the NULL stream (reference behaviour).  The stream belongs to the
                                              * CALLING HOST THREAD, like HIP's current device: N threads driving N GPUs each set

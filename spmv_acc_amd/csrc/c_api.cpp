@@ -343,6 +343,10 @@ int spmv_acc_query_plan_slab_passes(const int *d_rowptr, int m) {
   PlanInfo info;
   return query_plan(d_rowptr, m, &info) ? info.slab_passes : -2;
 }
+int spmv_acc_query_plan_settled(const int *d_rowptr, int m) {
+  PlanInfo info;
+  return query_plan(d_rowptr, m, &info) ? info.settled : -2;
+}
 
 void spmv_acc_set_stream(void *hip_stream) { set_stream(static_cast<hipStream_t>(hip_stream)); }
 void *spmv_acc_get_stream(void) { return static_cast<void *>(get_stream()); }

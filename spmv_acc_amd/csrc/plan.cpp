@@ -503,6 +503,7 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->flat_fixup = p.flat_tiles > 0 ? (p.flat.needs_fixup ? 1 : 0) : -1;
       out->adaptive_family = afam;
       out->adaptive_family_beta0 = p.adaptive_family[0];
+      out->settled = p.calls > 0 && !p.tuning_open ? 1 : 0;
       out->slab_passes = p.seg_state == 1 && (tun(kT_slab_segments) >= 2 || (tun(kT_slab_segments) < 0 && p.seg_choice == 1)) ? p.seg_slabs - (p.seg_rest_below > 0 ? 1 : 0) : 0; // (column slabs: the whole-row pass of the two-class form is not counted)
       return true;
     }

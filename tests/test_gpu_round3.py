@@ -1165,13 +1165,16 @@ def test_first_call_is_bounded_and_later_calls_finish_the_timings(torch_dev, ora
             unbounded = calls(3, strat)
             lib.spmv_acc_reset_tunables()
             spmv_acc_amd.release_plans(drp)
-            bounded = calls(14, strat)
+            first = calls(1, strat)
+            settled_after_first = spmv_acc_amd.query_plan(drp, m)["settled"]
+            bounded = first + calls(13, strat)
+            assert settled_after_first == (sum(1 for w in bounded[1:] if w > 0) == 0), (strat, bounded)  # open timings <=> later plan work
             assert bounded[0] > 0 and unbounded[0] > 0
             assert bounded[0] < 0.8 * unbounded[0], (strat, bounded[0], unbounded[0])  # the first call does less ...
             assert sum(1 for w in bounded[1:] if w > 0) >= 1, (strat, bounded)          # ... later calls do the rest ...
             assert bounded[-1] == 0.0 and bounded[-2] == 0.0, (strat, bounded)          # ... and then it is over
             info = spmv_acc_amd.query_plan(drp, m)
-            assert info["stream_policy"] in (0, 1, 3)
+            assert info["stream_policy"] in (0, 1, 3) and info["settled"]  # (spmv_acc_query_plan_settled: nothing left open)
             if strat == "adaptive":
                 assert info["adaptive_family"] in (0, 1, 2) and info["flat_tiles"] > 0 and info["plus_blocks"] > 0  # every family was looked at
             # everything up front instead

@@ -265,6 +265,7 @@ def test_round3_switches_and_entry_points_without_a_gpu(hiplib, tmp_path):
     # the slab-major copy is opt-in; SPMV_ACC_TUNABLES seeds any of them for a process that cannot call the setter
     assert [hiplib.spmv_acc_get_tunable(n) for n in (b"guard_full", b"slab_segments", b"col_slabs", b"legacy_kernels", b"rowblock_target")] == [0, -1, 0, 1, 1500]
     assert hiplib.spmv_acc_query_plan_slab_passes(None, 5) == -2  # no such plan
+    assert hiplib.spmv_acc_query_plan_settled(None, 5) == -2
     code = "import spmv_acc_amd as s; l = s.load_library(); print(l.spmv_acc_get_tunable(b'slab_segments'), l.spmv_acc_get_tunable(b'guard_full'))"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, SPMV_ACC_TUNABLES="slab_segments=0,guard_full=1", PYTHONPATH=ROOT))
