@@ -320,7 +320,22 @@ int run_multi_gpu(const Options &o, HostCsr &A, HostVectors &v) {
   int have = 0;
   HIP_CHECK(hipGetDeviceCount(&have));
   const int N = o.gpus;
-  if (N > have) {
+  // TEST HOOKS (tests/test_gpu_round3.py, with a mock RCCL behind SPMV_ACC_RCCL_LIB: RCCL itself refuses two ranks on one device):
+  // SPMV_CLI_ONE_DEVICE=1 puts every rank's thread on device 0; SPMV_CLI_FAIL=<rank>:<prepare|step> makes that rank's call fail (a NULL x) in the
+  // named phase, so that what the OTHER ranks do about it can be watched.
+  const char *one_dev = std::getenv("SPMV_CLI_ONE_DEVICE");
+  const bool one_device = one_dev && *one_dev && *one_dev != '0';
+  int fail_rank = -1;
+  std::string fail_phase;
+  if (const char *f = std::getenv("SPMV_CLI_FAIL")) {
+    const std::string spec(f);
+    const size_t colon = spec.find(':');
+    if (colon != std::string::npos) {
+      fail_rank = std::atoi(spec.substr(0, colon).c_str());
+      fail_phase = spec.substr(colon + 1);
+    }
+  }
+  if (N > have && !one_device) {
     std::fprintf(stderr, "--gpus %d: only %d device(s) visible\n", N, have);
     return 2;
   }
@@ -347,7 +362,7 @@ int run_multi_gpu(const Options &o, HostCsr &A, HostVectors &v) {
       std::fprintf(stderr, "rank %d: %s: %s\n", r, what, spmv_acc_last_error_string());
       rcs[r] = 5;
     };
-    HIP_CHECK(hipSetDevice(r));
+    HIP_CHECK(hipSetDevice(one_device ? 0 : r));
     hipStream_t st;
     HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     spmv_acc_set_stream(st); // this thread's library stream
@@ -367,17 +382,20 @@ int run_multi_gpu(const Options &o, HostCsr &A, HostVectors &v) {
       bail("spmv_acc_shard_create");
       ok = false;
     }
+    int steps_made = 0;
     auto step = [&] {
       // (a rank whose step has failed keeps calling: the library still takes part in the step's exchanges, so the peers, which
       // learn about the failure only at the next barrier, are not left waiting inside this phase)
-      if (shard && spmv_acc_shard_step(shard, o.alpha, o.beta, d_x, d_y0, d_full) != 0 && ok) {
+      const bool sabotage = r == fail_rank && fail_phase == "step" && steps_made == 2;
+      ++steps_made;
+      if (shard && spmv_acc_shard_step(shard, o.alpha, o.beta, sabotage ? nullptr : d_x, d_y0, d_full) != 0 && ok) {
         bail("spmv_acc_shard_step");
         ok = false;
       }
     };
     // Plans first, outside any collective: every chunk's plan is built and tuned here (allocations, device-wide synchronisations,
     // timed launches), so that a step only enqueues kernels and exchanges.
-    if (ok && spmv_acc_shard_prepare(shard, o.beta, d_x) != 0) {
+    if (ok && spmv_acc_shard_prepare(shard, o.beta, r == fail_rank && fail_phase == "prepare" ? nullptr : d_x) != 0) {
       bail("spmv_acc_shard_prepare");
       ok = false;
     }

@@ -15,6 +15,7 @@
 #include "engine.hpp"
 
 #include <string>
+#include <cstdint>
 
 using namespace spmv_acc;
 
@@ -23,6 +24,48 @@ using namespace spmv_acc;
 // stream, all five transfers in flight together; arrays that cannot be registered (e.g. read-only mappings) go
 // through a pinned double buffer instead.  One synchronisation at the end.
 namespace {
+// hipHostRegister is per process, not per thread: N host threads staging N shards of ONE host matrix (spmv-cli --gpus N) all pin the same x, and
+// neighbouring shards' slices of colindex / values share a page at their common edge.  Two threads that both "succeed" in registering one range --
+// or one that unregisters what another still copies from -- abort inside the runtime ("Memobj map does not have ptr"; found in round 4 by the
+// first run of the N > 1 driver, over the mock communicator of tests/cxx/mock_rccl.cpp).  So registrations go through one table: an identical
+// range is shared (reference-counted), a range that overlaps another one page-wise is not registered at all (its owner takes the bounce buffers).
+struct PinTable {
+  std::mutex mu;
+  struct Range { uintptr_t lo, hi; int refs; };
+  std::vector<Range> ranges;
+  static constexpr uintptr_t kPage = 4096;
+  bool pin(void *p, size_t bytes) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p), lo = a & ~(kPage - 1), hi = (a + bytes + kPage - 1) & ~(kPage - 1);
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &r : ranges) {
+      if (r.lo == a && hi <= ((r.hi + kPage - 1) & ~(kPage - 1))) { // the same array (or a prefix of it): share
+        ++r.refs;
+        return true;
+      }
+      if (lo < ((r.hi + kPage - 1) & ~(kPage - 1)) && (r.lo & ~(kPage - 1)) < hi) return false; // shares a page with another registration
+    }
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    ranges.push_back({a, a + bytes, 1});
+    return true;
+  }
+  void unpin(void *p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < ranges.size(); ++i) {
+      if (ranges[i].lo != a) continue;
+      if (--ranges[i].refs == 0) {
+        (void)hipHostUnregister(p);
+        ranges.erase(ranges.begin() + static_cast<long>(i));
+      }
+      return;
+    }
+  }
+};
+PinTable g_pins;
+
 struct Stager {
   static constexpr size_t kChunk = 32u << 20; // 32 MiB per pinned bounce buffer (fallback path only)
   void *pinned[2] = {nullptr, nullptr};
@@ -32,7 +75,7 @@ struct Stager {
   bool ok = true;
   Stager() { ok = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) == hipSuccess; }
   ~Stager() {
-    for (void *p : registered) (void)hipHostUnregister(p);
+    for (void *p : registered) g_pins.unpin(p);
     for (int i = 0; i < 2; ++i) {
       if (done[i]) (void)hipEventDestroy(done[i]);
       if (pinned[i]) (void)hipHostFree(pinned[i]);
@@ -48,11 +91,10 @@ struct Stager {
     return true;
   }
   bool upload(void *dst, const void *src, size_t bytes) {
-    if (hipHostRegister(const_cast<void *>(src), bytes, hipHostRegisterDefault) == hipSuccess) {
+    if (g_pins.pin(const_cast<void *>(src), bytes)) {
       registered.push_back(const_cast<void *>(src));
       return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, copy) == hipSuccess;
     }
-    (void)hipGetLastError();
     // fallback: memcpy into one pinned buffer while the other one is in flight
     if (!ensure_bounce()) return false;
     size_t off = 0;

@@ -213,6 +213,62 @@ def test_cli_multi_gpu_driver_on_one_gpu(cli, tmp_path, pipeline):
     assert r.returncode == 2 and "visible" in r.stderr
 
 
+@pytest.fixture(scope="module")
+def mock_rccl(tmp_path_factory):
+    """tests/cxx/mock_rccl.cpp built into a shared object: N ranks = N host threads of one process on ONE device (test infrastructure: RCCL
+    itself refuses two ranks on one device, and no round had a box with more than one GPU)."""
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path_factory.mktemp("mock") / "libmock_rccl.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tests", "cxx", "mock_rccl.cpp"), "-o", out],
+                   check=True, capture_output=True, timeout=600)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,pipeline", [(2, 1), (2, 3), (3, 1), (4, 4), (8, 2)])
+def test_cli_several_ranks_on_one_gpu_over_a_mock_rccl(cli, mock_rccl, tmp_path, ranks, pipeline):
+    """The N > 1 logic of the C / C++ sharded step, which one-rank RCCL runs cannot reach: spmv-cli --gpus N with N host threads on ONE device
+    (SPMV_CLI_ONE_DEVICE) over the mock communicator (SPMV_ACC_RCCL_LIB): nnz-balanced shards of unequal row counts padded to one length, the
+    in-place allgather at every rank's offset (pipeline 1), the chunked point-to-point fan-out with every rank paired with every other at every
+    position (pipeline C: chunk sizes that do not divide the shards), spmv_acc_shard_prepare ahead of the first collective, and the reference
+    CLI's verdict on rank 0's gathered y.  What the mock cannot show is RCCL itself (its transports, its stream semantics): see its header."""
+    m = 60_000 + 7 * ranks
+    rowptr, cols, vals = synth.random_csr(m, m, 9, seed=31 + ranks, kind="powerlaw")
+    p = str(tmp_path / "m.bin2")
+    write_bin2(p, m, m, rowptr, cols, vals)
+    env = dict(os.environ, SPMV_ACC_RCCL_LIB=mock_rccl, SPMV_CLI_ONE_DEVICE="1", MOCK_RCCL_TIMEOUT_S="30")
+    for strat in ("adaptive", "flat"):
+        r = subprocess.run([cli, p, "-f", "bin2", "--gpus", str(ranks), "--pipeline", str(pipeline), "--strategy", strat], capture_output=True, text=True,
+                           env=env, timeout=300)
+        assert r.returncode == 0, (strat, r.stdout[-600:], r.stderr[-1200:])
+        assert f"Congratulation, pass {m} validation!" in r.stdout and f"gpus:{ranks} pipeline:{pipeline}" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("phase", ["prepare", "step"])
+@pytest.mark.parametrize("pipeline", [1, 3])
+def test_a_failing_rank_does_not_hang_its_peers(cli, mock_rccl, tmp_path, phase, pipeline):
+    """a rank whose local SpMV fails must not leave its peers blocked in a collective.  Three ranks over the mock
+    communicator; rank 1's call is sabotaged (a NULL x) in spmv_acc_shard_prepare or in its third step.  The failing rank still takes part in the
+    step's exchanges (spmv_acc_shard_step), the ranks agree at the barrier behind the phase and all stop: the process ends by itself -- well inside
+    the mock's own timeout, which would turn a missing peer into an error after 30 s -- with the driver's failure code and the failing rank named."""
+    import time
+
+    m = 40_000
+    rowptr, cols, vals = synth.random_csr(m, m, 7, seed=77, kind="powerlaw")
+    p = str(tmp_path / "m.bin2")
+    write_bin2(p, m, m, rowptr, cols, vals)
+    env = dict(os.environ, SPMV_ACC_RCCL_LIB=mock_rccl, SPMV_CLI_ONE_DEVICE="1", MOCK_RCCL_TIMEOUT_S="30", SPMV_CLI_FAIL=f"1:{phase}")
+    t0 = time.time()
+    r = subprocess.run([cli, p, "-f", "bin2", "--gpus", "3", "--pipeline", str(pipeline)], capture_output=True, text=True, env=env, timeout=200)
+    took = time.time() - t0
+    assert r.returncode == 5, (r.returncode, r.stdout[-400:], r.stderr[-800:])
+    assert "rank 1: spmv_acc_shard_" + ("prepare" if phase == "prepare" else "step") in r.stderr
+    assert "rank 0:" not in r.stderr and "rank 2:" not in r.stderr  # (the peers' exchanges all completed: nobody timed out waiting for rank 1)
+    assert took < 25, took
+
+
 # ---- readers pinned against the REFERENCE's own readers ----------------------------------------------------------------------------
 def _read_dump(path):
     with open(path, "rb") as f:
