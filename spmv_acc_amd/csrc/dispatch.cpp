@@ -364,8 +364,9 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
   // configuration -- the rule's cache policy and block size, no hints: nothing timed for it -- and the kernel's own choices (three block
   // sizes, three cache policies, hints: eight trial launches of 7-8 ms each on R-MAT 25, 60 of the 145 ms its first call took) are only
   // timed when the passes do not win clearly.  Clearly = by 15 %: tuned and hinted, this kernel gains up to ~12 % on its coarse form.
-  if (slabs_auto && p.seg_choice < 0 && !t_capturing && !by_rule() && tun(kT_gather_hint) != 0) {
+  if (slabs_auto && p.seg_choice < 0 && !p.seg_early_tried && !t_capturing && !by_rule() && tun(kT_gather_hint) != 0) {
     if (!ensure_hint(p, st)) return false;
+    p.seg_early_tried = true; // (once per plan: an undecided outcome leaves the question to the comparison against the TUNED kernel below)
     if (p.hint_state == 1) {
       const bool was_coarse = t_coarse_tuning;
       t_coarse_tuning = t_no_policy_timing = true;
@@ -454,8 +455,6 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
   // spend (the first call times fixed row blocks at least; the others follow, one per later call if need be), and until all three are in, the
   // best of the measured ones serves.
   float *ms = p.adaptive_ms[cls];
-  bool unmeasured = false;
-  for (int f = 0; f < 3; ++f) unmeasured = unmeasured || (ms[f] > 1e29f && !p.adaptive_skipped[cls][f]);
   const bool open = p.adaptive_family[cls] < 0 || p.adaptive_provisional[cls];
   if (open && !t_capturing && !(p.adaptive_family[cls] >= 0 && defer_tuning())) {
     ++t_plan_work;
@@ -474,15 +473,11 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
     for (int f = 0; f < 3; ++f) any_measured = any_measured || ms[f] < 1e29f;
     for (int f = 0; ok && f < 3; ++f) {
       if (ms[f] < 1e29f || p.adaptive_skipped[cls][f]) continue;
-      // (at least one family is timed whatever the budget: the call needs a kernel.  A further one is only started while most of the budget is
-      // left: building a family's plan is structural work of unknown size -- the row-block analysis, its tables and their allocations took 4 ms on
-      // the headline matrix, 25 SpMVs' worth)
-      // Every call that gets here times at least ONE family more (progress is guaranteed whatever the budget).
-      if (any_measured && timed_here > 0 && (defer_tuning() || budget_spent_fraction() > 0.25)) {
-        t_tuning_deferred = true;
-        break;
-      }
-      if (any_measured && timed_here == 0 && p.calls <= 1 && (defer_tuning() || budget_spent_fraction() > 0.25)) { // (the FIRST call: one family is enough)
+      // At least one family is timed whatever the budget -- the first call needs a kernel, and every later call that gets here must make
+      // progress.  A further one is only started while most of the budget is left: building a family's plan is structural work of unknown
+      // size (the row-block analysis, its tables and their allocations took 4 ms on the headline matrix, 25 SpMVs' worth).
+      const bool must_progress = timed_here == 0 && (!any_measured || p.calls > 1);
+      if (!must_progress && (defer_tuning() || budget_spent_fraction() > 0.25)) {
         t_tuning_deferred = true;
         break;
       }
@@ -496,7 +491,7 @@ bool run_adaptive_timed(hipStream_t st, Plan &p, const int *h_rowptr, double alp
       any_measured = any_measured || ok;
       ++timed_here;
     }
-    unmeasured = false;
+    bool unmeasured = false;
     for (int f = 0; f < 3; ++f) unmeasured = unmeasured || (ms[f] > 1e29f && !p.adaptive_skipped[cls][f]);
     // second look at every family within 8 % of the fastest: the choice is kept for the life of the plan, and two families
     // 3 % apart changed places from process to process on single timings (the headline matrix ran fixed row blocks in one

@@ -172,6 +172,7 @@ struct Plan {
   // (ordinary path), 1 built for seg_slabs slabs
   int seg_state = -1, seg_slabs = 0;
   int seg_choice = -1; // automatic mode: -1 not timed, 0 the row-block-plus kernel stays, 1 the slab passes
+  bool seg_early_tried = false; // the comparison against the COARSE row-block-plus kernel (dispatch.cpp::run_plus) has been made
   // per slab: one entry per run (or piece of a long run): its row, its first non-zero, its place in the pass's virtual non-zero
   // order (entries + 1 prefix sums of the lengths); and the first entry of every workgroup (blocks + 1)
   std::vector<int *> seg_row, seg_begin, seg_vptr, seg_blk;
