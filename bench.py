@@ -535,6 +535,9 @@ def compact_line(full):
         line["sweep"] = {k: [row["flat"]["frac"], row["adaptive"]["frac"]] for k, row in full["sweep"].items()}
         line["sweep_summary"] = {s: _pick(v, ("ge_0.70", "ge_0.70_in_process", "median_frac", "min_frac", "median_frac_in_process"))
                                  for s, v in full["sweep_summary"].items() if s in ("flat", "adaptive")}
+        # (`flat` as shipped runs the row-block kernel on balanced rows where the plan-time timing prefers it: flat's own tile kernel ALONE beside it)
+        if "flat_tile_kernel" in full["sweep_summary"]:
+            line["sweep_summary"]["flat"]["ge_0.70_tile_kernel_alone"] = full["sweep_summary"]["flat_tile_kernel"]["ge_0.70"]
     if "rmat25" in full:  # configs[3]
         le = full["rmat25"]["line_enhance"]
         line["rmat25"] = {"us": le["us"], "frac": le["frac"], "nnz": full["rmat25"]["nnz"]}

@@ -318,7 +318,8 @@ enum spmv_acc_error {
  * replaces: hip::timer::event_timer around the L1 call (benchmark/utils/timer_utils.h:16-51,
  * benchmark/csr_spmv.hpp:67-74).  Runs `iters` SpMVs with `strategy`; each is bracketed by hipEvents on
  * the library stream, y is restored from d_y0 (device, m doubles, may be NULL) outside the timed region.
- * ms_out receives iters per-launch durations in milliseconds.  Returns 0 or an error code. */
+ * ms_out receives iters per-launch durations in milliseconds.  Returns 0 or an error code.  What is timed is a SETTLED plan: the helpers
+ * first finish whatever per-matrix timings the first-call budget left open (spmv_acc_prepare_beta: at least one untimed SpMV into a scratch y). */
 int spmv_acc_time_spmv(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
                        const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
                        const double *dx, double *dy, const double *d_y0, float *ms_out);
