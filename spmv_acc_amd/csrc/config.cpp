@@ -193,19 +193,13 @@ Tunable g_tunables[] = {
                                // non-zeros is a 12-B list entry, a y read-modify-write and a part-used line of each stream: 5.30 -> 5.19 ms, first call 152 ->
                                // 135 ms (thresholds 8 / 16 / 24 / 32 / 48 / 64 / 128 / 256: 5.33 / 5.28 / 5.19 / 5.19 / 5.21 / 5.25 / 5.29 / 5.79,
                                // profiles/r04_rmat25_hub_windows_and_two_class.txt); 0 = every row is cut (round 3)
-    {"slab_short_below", 32, 32},  // slab passes, per-class slab counts (round 4): rows of [slab_whole_below, slab_short_below) non-zeros are cut into
-    {"slab_short_slabs", 2, 2},    // slab_short_slabs column slabs, rows of [slab_short_below, slab_mid_below) into slab_mid_slabs, the longer ones into
-    {"slab_mid_below", 128, 128},  // slab_segments (automatic: 8) -- passes of their own, 16 in all at most (beyond that the explicit slab_segments wins and
-    {"slab_mid_slabs", 4, 4},      // every shorter row is whole).  An empty range (e.g. slab_short_below <= slab_whole_below) has no passes.  R-MAT 25 by
-                               // class (profiles/r04_rmat_class_probe.txt): below 32 non-zeros 2 slabs are fastest (1.12 ms against 1.35 whole, 1.49 at 8),
-                               // 32-128 four (0.80 against 0.94 at 8), above that 8
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 // (the count alone does not catch two entries in the wrong order -- round 4 ran an afternoon with first_call_budget reading slab_whole_below's
 // value: the table's last names are checked against their ids once, at the first tunable lookup)
 inline bool tunable_order_ok() {
   return std::strcmp(g_tunables[kT_first_call_budget].name, "first_call_budget") == 0 && std::strcmp(g_tunables[kT_later_call_budget].name, "later_call_budget") == 0 &&
-         std::strcmp(g_tunables[kT_slab_whole_below].name, "slab_whole_below") == 0 && std::strcmp(g_tunables[kT_slab_mid_slabs].name, "slab_mid_slabs") == 0 && std::strcmp(g_tunables[kT_vector_target].name, "vector_target") == 0 &&
+         std::strcmp(g_tunables[kT_slab_whole_below].name, "slab_whole_below") == 0 && std::strcmp(g_tunables[kT_vector_target].name, "vector_target") == 0 &&
          std::strcmp(g_tunables[kT_slab_segments].name, "slab_segments") == 0 && std::strcmp(g_tunables[kT_deterministic].name, "deterministic") == 0 &&
          std::strcmp(g_tunables[kT_zigzag].name, "zigzag") == 0 && std::strcmp(g_tunables[kT_xcd_remap].name, "xcd_remap") == 0;
 }

@@ -48,7 +48,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kT_slab_segments, kT_vector_target, kT_first_call_budget, kT_later_call_budget, kT_slab_whole_below, kT_slab_short_below, kT_slab_short_slabs, kT_slab_mid_below, kT_slab_mid_slabs, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kT_slab_segments, kT_vector_target, kT_first_call_budget, kT_later_call_budget, kT_slab_whole_below, kTunableCount
 };
 extern Tunable g_tunables[];
 void apply_env_tunables();
@@ -178,11 +178,9 @@ struct Plan {
   std::vector<int *> seg_row, seg_begin, seg_vptr, seg_blk;
   std::vector<int> seg_entries, seg_blocks, seg_pieces; // seg_pieces[s] != 0: the slab holds runs cut into pieces (merge kernel needed)
   double *d_seg_ys = nullptr; // one partial sum per entry of the longest list
-  int seg_cols = 0;            // column slabs of the class of the longest rows (what query_plan reports); seg_slabs counts the planes of all classes
-  unsigned long long seg_classes_sig = 0; // the class table the lists were built for (tuner.cpp::slab_classes_of)
+  int seg_rest_below = 0;      // two-class form: rows of fewer non-zeros than this are whole runs in the last plane (0: every row is cut by slab)
   void free_segments() {
-    seg_cols = 0;
-    seg_classes_sig = 0;
+    seg_rest_below = 0;
     for (auto *list : {&seg_row, &seg_begin, &seg_vptr, &seg_blk}) {
       for (int *q : *list)
         if (q) (void)hipFree(q);

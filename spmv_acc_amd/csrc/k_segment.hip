@@ -46,18 +46,12 @@ constexpr int kSegEntries = 512;
 static_assert(kSegCost + kSegPiece <= kSegTile && (kSegCost + kSegPiece) / kSegMinCost <= kSegEntries, "a workgroup's entries fit one tile");
 static_assert(kNnzPerThread == 8, "the owner map is scanned 8 elements per lane (one 16-B LDS word)");
 
-__device__ __forceinline__ int slab_class_of(const SlabClasses &C, int len) {
-  int k = 0;
-#pragma unroll
-  for (int i = 0; i < kSlabClasses - 1; ++i) k += len < C.at_least[i] ? 1 : 0; // (unused slots hold 0: never counted)
-  return k;
-}
-
-// cnt[s][row] (S x (m + 1), entry m zeroed for the scans), beg[s][row] (same shape): first non-zero of plane s's run in row `row`
-__global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__restrict__ rp, const int *__restrict__ ci, int m, SlabClasses C,
+// cnt[s][row] (S x (m + 1), entry m zeroed for the scans), beg[s][row] (same shape): first non-zero of slab s's run in row `row`
+__global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__restrict__ rp, const int *__restrict__ ci, int m, SlabBounds B,
                                                                  int S, int *__restrict__ cnt, int *__restrict__ beg,
-                                                                 int *__restrict__ not_monotone) {
+                                                                 int *__restrict__ not_monotone, int rest_below) {
   const int lane = threadIdx.x & (kWave - 1);
+  const int SC = rest_below > 0 ? S - 1 : S; // column slabs; with rest_below the last plane (S - 1) lists the rows of < rest_below non-zeros WHOLE
   // One wavefront per row; beyond kMaxGridBlocks * 4 rows the wavefronts stride over the rows -- by a PRIME number of workgroups: a stride of 2^16
   // wavefronts gave wavefront 0 the rows k * 2^16, on R-MAT (a row's length falls with the number of set bits in its index) all hubs, 6.6 M
   // non-zeros walked by one wavefront: 96 ms for the kernel, where the longest row alone takes 9
@@ -65,37 +59,37 @@ __global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__re
        row += static_cast<long long>(gridDim.x) * (kThreads / kWave)) {
     const int j0 = rp[row], j1 = rp[row + 1];
     if (j1 - j0 <= kSegShortRow) continue; // (wave-uniform: short rows are counted 64 to a wavefront by segment_count_short_kernel)
-    const int k = slab_class_of(C, j1 - j0);
-    const int p0 = C.base[k], np = C.count[k], width = C.width[k];
-    if (np == 1) { // a class of whole rows: one run, all columns (they need no order)
+    if (j1 - j0 < rest_below) { // a short row of the two-class form: one run, all columns, in the last plane (its columns need no order)
       if (lane < S) {
-        cnt[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row] = lane == p0 ? j1 - j0 : 0;
+        cnt[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row] = lane == S - 1 ? j1 - j0 : 0;
         beg[static_cast<size_t>(lane) * (static_cast<size_t>(m) + 1) + row] = j0;
       }
       continue;
     }
     int acc = 0;
-    int prev_last = 0; // plane of the last non-zero of the previous step
+    int prev_last = 0; // slab of the last non-zero of the previous step
     bool bad = false;
     for (int base = j0; base < j1; base += kWave) {
       const int j = base + lane;
       const bool live = j < j1;
-      int slab = S; // (dead lanes: above every plane, so the order test passes)
+      int slab = S; // (dead lanes: above every slab, so the order test passes)
       if (live) {
-        const int q = ci[j] / width;
-        slab = p0 + (q < np - 1 ? q : np - 1);
+        const int c = ci[j];
+        slab = 0;
+#pragma unroll
+        for (int b = 0; b < 15; ++b) slab += (b < SC - 1 && c >= B.first[b]) ? 1 : 0; // first[b] = first column of slab b + 1
       }
       const int left = __shfl_up(slab, 1, kWave);
       bad = bad || (live && slab < (lane == 0 ? prev_last : left));
       const int last_live = (j1 - base < kWave ? j1 - base : kWave) - 1;
       prev_last = __shfl(slab, last_live, kWave);
-      for (int s = p0; s < p0 + np; ++s) {
+      for (int s = 0; s < S; ++s) {
         const unsigned long long mask = __ballot(slab == s);
         if (lane == s) acc += __popcll(mask);
       }
     }
     if (__ballot(bad) != 0ULL && lane == 0) atomicOr(not_monotone, 1);
-    // exclusive prefix of the counts over lanes 0 .. S-1 (S <= 16; the planes of the other classes hold 0)
+    // exclusive prefix of the counts over lanes 0 .. S-1 (S <= 16)
     int incl = lane < S ? acc : 0;
 #pragma unroll
     for (int off = 1; off < 16; off <<= 1) {
@@ -111,10 +105,11 @@ __global__ __launch_bounds__(kThreads) void segment_count_kernel(const int *__re
 
 // The same for rows of at most kSegShortRow non-zeros, one LANE per row (power-law matrices: 33.5 M rows of R-MAT 25 average 16 non-zeros, and one
 // wavefront per row spent 89 ms on them; neighbouring lanes read neighbouring rows, i.e. the same cache lines).  Counts are packed 8 bits per
-// plane into two 64-bit words (a row of <= 32 non-zeros cannot overflow a field).
-__global__ __launch_bounds__(kThreads) void segment_count_short_kernel(const int *__restrict__ rp, const int *__restrict__ ci, int m, SlabClasses C,
+// slab into two 64-bit words (a row of <= 32 non-zeros cannot overflow a field).
+__global__ __launch_bounds__(kThreads) void segment_count_short_kernel(const int *__restrict__ rp, const int *__restrict__ ci, int m, SlabBounds B,
                                                                        int S, int *__restrict__ cnt, int *__restrict__ beg,
-                                                                       int *__restrict__ not_monotone) {
+                                                                       int *__restrict__ not_monotone, int rest_below) {
+  const int SC = rest_below > 0 ? S - 1 : S;
   const long long row = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
   if (row == m) { // (the grid covers m + 1 entries: the scans' closing zeros)
     for (int s = 0; s < S; ++s) cnt[static_cast<size_t>(s) * (static_cast<size_t>(m) + 1) + m] = 0;
@@ -122,31 +117,31 @@ __global__ __launch_bounds__(kThreads) void segment_count_short_kernel(const int
   if (row >= m) return;
   const int j0 = rp[row], j1 = rp[row + 1];
   if (j1 - j0 > kSegShortRow) return; // a long row: segment_count_kernel
-  const int k = slab_class_of(C, j1 - j0);
-  const int p0 = C.base[k], np = C.count[k], width = C.width[k];
-  if (np == 1) { // a class of whole rows
+  if (j1 - j0 < rest_below) { // two-class form: the whole row is one run of the last plane
     for (int s = 0; s < S; ++s) {
-      cnt[static_cast<size_t>(s) * (static_cast<size_t>(m) + 1) + row] = s == p0 ? j1 - j0 : 0;
+      cnt[static_cast<size_t>(s) * (static_cast<size_t>(m) + 1) + row] = s == S - 1 ? j1 - j0 : 0;
       beg[static_cast<size_t>(s) * (static_cast<size_t>(m) + 1) + row] = j0;
     }
     return;
   }
-  unsigned long long w0 = 0ULL, w1 = 0ULL; // planes 0-7, 8-15
+  unsigned long long p0 = 0ULL, p1 = 0ULL; // slabs 0-7, 8-15
   int prev = 0;
   bool bad = false;
   for (int j = j0; j < j1; ++j) {
-    const int q = ci[j] / width;
-    const int slab = p0 + (q < np - 1 ? q : np - 1);
+    const int c = ci[j];
+    int slab = 0;
+#pragma unroll
+    for (int b = 0; b < 15; ++b) slab += (b < SC - 1 && c >= B.first[b]) ? 1 : 0;
     bad = bad || slab < prev;
     prev = slab;
     const unsigned long long inc = 1ULL << (8 * (slab & 7));
-    if (slab < 8) w0 += inc;
-    else w1 += inc;
+    if (slab < 8) p0 += inc;
+    else p1 += inc;
   }
   if (bad) atomicOr(not_monotone, 1);
   int at = j0;
   for (int s = 0; s < S; ++s) {
-    const int n = static_cast<int>(((s < 8 ? w0 : w1) >> (8 * (s & 7))) & 0xFFULL);
+    const int n = static_cast<int>(((s < 8 ? p0 : p1) >> (8 * (s & 7))) & 0xFFULL);
     cnt[static_cast<size_t>(s) * (static_cast<size_t>(m) + 1) + row] = n;
     beg[static_cast<size_t>(s) * (static_cast<size_t>(m) + 1) + row] = at;
     at += n;
@@ -313,15 +308,15 @@ __global__ __launch_bounds__(kThreads) void segment_merge_kernel(int entries, co
 
 } // namespace
 
-void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabClasses &C, int S, int *cnt, int *beg, int *not_monotone) {
+void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone, int rest_below) {
   if (A.m <= 0) return;
   long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row ...
   if (blocks > kMaxGridBlocks) blocks = kMaxGridBlocks;                                               // ... up to what a launch holds
-  hipLaunchKernelGGL(segment_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, C, S, cnt,
-                     beg, not_monotone);
+  hipLaunchKernelGGL(segment_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S, cnt,
+                     beg, not_monotone, rest_below);
   const long long short_blocks = (static_cast<long long>(A.m) + 1 + kThreads - 1) / kThreads; // m + 1: the closing zeros
-  hipLaunchKernelGGL(segment_count_short_kernel, dim3(static_cast<unsigned>(short_blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, C, S,
-                     cnt, beg, not_monotone);
+  hipLaunchKernelGGL(segment_count_short_kernel, dim3(static_cast<unsigned>(short_blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S,
+                     cnt, beg, not_monotone, rest_below);
 }
 void launch_segment_pieces(hipStream_t stream, const int *cnt_s, int m, int piece_max, int *pieces) {
   const long long blocks = (static_cast<long long>(m) + 1 + kThreads - 1) / kThreads;

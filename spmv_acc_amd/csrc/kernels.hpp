@@ -33,19 +33,12 @@ constexpr int kGuardSamples = 64; // rowptr[k * m / 63], k = 0 .. 63 (includes r
 void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard);
 void launch_guard_check(hipStream_t stream, const CsrDev &A); // the check alone, for paths whose SpMV kernels run on derived matrices
 // column-slab blocking without a copy (k_segment.hip, tunable slab_segments): cnt S x (m + 1), beg S x (m + 1); *not_monotone pre-zeroed
-// Rows are classed by LENGTH and every class is cut into its own number of equal column slabs (round 4: on R-MAT 25 the rows below 32 non-zeros
-// are fastest in 2 slabs, those up to 128 in 4, the longer ones in 8 -- profiles/r04_rmat_class_probe.txt).  Class k holds the rows of at least
-// at_least[k] non-zeros that are in no earlier class (descending; the last class used has 0, and so have the unused slots); its slabs are the planes
-// base[k] .. base[k] + count[k] - 1, `width[k]` columns each (the last takes the rest).  count[k] == 1: the rows are WHOLE runs (no column order needed).
-constexpr int kSlabClasses = 4;
-constexpr int kSlabPlanes = 16; // planes of all classes together (the short-row count kernel packs 16 8-bit counters)
-struct SlabClasses {
-  int at_least[kSlabClasses];
-  int base[kSlabClasses];
-  int count[kSlabClasses];
-  int width[kSlabClasses];
+struct SlabBounds {
+  int first[15]; // first[b] = first column of slab b + 1 (ascending); slab of column c = number of entries <= c among the first S - 1
 };
-void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabClasses &C, int S, int *cnt, int *beg, int *not_monotone);
+// rest_below > 0 (two-class form): S counts one plane more than there are column slabs; rows of fewer than rest_below non-zeros are ONE run each, all
+// columns, in that last plane (they are not cut by column at all), the longer rows are cut into the S - 1 column slabs as usual
+void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone, int rest_below = 0);
 void launch_segment_pieces(hipStream_t stream, const int *cnt_s, int m, int piece_max, int *pieces);
 void launch_segment_compact(hipStream_t stream, const int *cnt_s, const int *beg_s, const int *pos, int m, int piece_max, int *seg_row,
                             int *seg_begin, int *seg_len, int *has_pieces); // *has_pieces pre-zeroed: set when some run was cut

@@ -159,7 +159,7 @@ unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *sample
   static const char kBuild[] = __DATE__ " " __TIME__;
   mix(kBuild, sizeof(kBuild));
   for (TunableId id : {kT_rowblock_target, kT_vector_target, kT_hint_budget_kb, kT_tune_protocol, kT_cache_ends_mb, kT_zigzag, kT_xcd_chunk, kT_xcd_chunk_tiles,
-                       kT_slab_whole_below, kT_slab_short_below, kT_slab_short_slabs, kT_slab_mid_below, kT_slab_mid_slabs, kT_rowlen, kT_legacy_kernels}) {
+                       kT_slab_whole_below, kT_rowlen, kT_legacy_kernels}) {
     const int v = tun(id);
     mix(&v, sizeof(int));
   }
@@ -504,7 +504,7 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->adaptive_family = afam;
       out->adaptive_family_beta0 = p.adaptive_family[0];
       out->settled = p.calls > 0 && !p.tuning_open ? 1 : 0;
-      out->slab_passes = p.seg_state == 1 && (tun(kT_slab_segments) >= 2 || (tun(kT_slab_segments) < 0 && p.seg_choice == 1)) ? p.seg_cols : 0; // (the column slabs of the longest rows' class: the shorter classes' passes are not counted)
+      out->slab_passes = p.seg_state == 1 && (tun(kT_slab_segments) >= 2 || (tun(kT_slab_segments) < 0 && p.seg_choice == 1)) ? p.seg_slabs - (p.seg_rest_below > 0 ? 1 : 0) : 0; // (column slabs: the whole-row pass of the two-class form is not counted)
       return true;
     }
   }

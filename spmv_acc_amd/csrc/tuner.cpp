@@ -653,57 +653,20 @@ bool ensure_slabs(Plan &p, int S, hipStream_t st) {
 }
 
 // Column-slab blocking without a copy (tunable slab_segments): the per-slab run lists of k_segment.hip.  Structure only; built once.
-// The class table of the run lists (kernels.hpp::SlabClasses) from the tunables: the longest rows in S_cols slabs, then the classes of
-// slab_mid_* / slab_short_*, then the whole rows; empty ranges are dropped, and when the planes would not fit kSlabPlanes every class but
-// the first collapses into ONE of whole rows (round 4's first two-class form)
-static int slab_classes_of(int S_cols, int n, SlabClasses *C, unsigned long long *sig) {
-  const int whole = tun(kT_slab_whole_below) > 1 ? tun(kT_slab_whole_below) : 0;
-  const int short_below = std::max(tun(kT_slab_short_below), whole), mid_below = std::max(tun(kT_slab_mid_below), short_below);
-  struct Want { int at_least, count; };
-  // (short_below and mid_below are clamped upwards, so the classes present have strictly descending thresholds and the last one's is 0 or `whole`)
-  auto build = [&](bool collapse) {
-    std::vector<Want> w;
-    w.push_back({collapse ? whole : mid_below, S_cols});
-    if (!collapse && mid_below > short_below) w.push_back({short_below, std::max(tun(kT_slab_mid_slabs), 1)});
-    if (!collapse && short_below > whole) w.push_back({whole, std::max(tun(kT_slab_short_slabs), 1)});
-    if (whole > 1) w.push_back({0, 1});
-    return w;
-  };
-  auto planes_of = [](const std::vector<Want> &w) {
-    int planes = 0;
-    for (const Want &c : w) planes += c.count;
-    return planes;
-  };
-  std::vector<Want> w = build(false);
-  if (planes_of(w) > kSlabPlanes) w = build(true);
-  const int planes = planes_of(w);
-  *C = SlabClasses();
-  *sig = 1469598103934665603ULL;
-  int base = 0;
-  for (size_t k = 0; k < w.size(); ++k) {
-    C->at_least[k] = w[k].at_least;
-    C->base[k] = base;
-    C->count[k] = w[k].count;
-    C->width[k] = std::max((n + w[k].count - 1) / w[k].count, 1);
-    base += w[k].count;
-    for (int v : {w[k].at_least, w[k].count}) *sig = (*sig ^ static_cast<unsigned long long>(v + 1)) * 1099511628211ULL;
-  }
-  for (size_t k = w.size(); k < static_cast<size_t>(kSlabClasses); ++k) C->base[k] = base, C->count[k] = 1, C->width[k] = 1; // (never selected)
-  return planes;
-}
-
 bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
-  // per-class slab counts (tunables slab_whole_below / slab_short_* / slab_mid_*): only the longest rows are cut into S_cols column slabs; the shorter
-  // classes have fewer slabs and passes of their own behind those, the shortest rows are ONE run each, all columns
-  SlabClasses classes;
-  unsigned long long sig = 0;
-  const int S = slab_classes_of(S_cols, p.A.n, &classes, &sig); // planes
-  if (p.seg_state >= 0 && (p.seg_state == 0 || (p.seg_slabs == S && p.seg_classes_sig == sig))) return true;
+  // two-class form (tunable slab_whole_below): only the rows of at least that many non-zeros are cut by column slab; every shorter row is ONE run,
+  // all columns, in a pass of its own (plane S_cols)
+  const int rest_below = tun(kT_slab_whole_below) > 1 ? tun(kT_slab_whole_below) : 0;
+  const int S = S_cols + (rest_below > 0 ? 1 : 0); // planes
+  if (p.seg_state >= 0 && (p.seg_state == 0 || (p.seg_slabs == S && p.seg_rest_below == rest_below))) return true;
   if (!plan_work_allowed("building the column-slab run lists")) return false;
   ++t_plan_work;
   p.free_segments();
   const CsrDev &A = p.A;
   const size_t m1 = static_cast<size_t>(A.m) + 1;
+  const int width = (A.n + S_cols - 1) / S_cols > 0 ? (A.n + S_cols - 1) / S_cols : 1;
+  SlabBounds bounds;
+  for (int b = 0; b < 15; ++b) bounds.first[b] = static_cast<int>(std::min<long long>(static_cast<long long>(width) * (b + 1), INT_MAX));
   // (equal column ranges.  Unequal ones were tried on R-MAT 25 through an environment hook since removed -- the hot eighth split in two
   // or four, the cold half kept whole, 4 to 8 slabs in all: 5.53-5.92 ms against 5.30 for eight equal slabs, profiles/r03_slab_segments.txt)
   int *cnt = nullptr, *beg = nullptr, *pieces = nullptr, *pos = nullptr, *flag = nullptr;
@@ -718,7 +681,7 @@ bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
             hip_ok(hipMemsetAsync(flag, 0, sizeof(int), st), "memset order flag");
   int unordered = 0;
   if (ok) {
-    launch_segment_count(st, A, classes, S, cnt, beg, flag);
+    launch_segment_count(st, A, bounds, S, cnt, beg, flag, rest_below);
     ok = hip_ok(hipMemcpyAsync(&unordered, flag, sizeof(int), hipMemcpyDeviceToHost, st), "read order flag") &&
          hip_ok(hipStreamSynchronize(st), "sync run counts");
   }
@@ -793,8 +756,7 @@ bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
     } else if (ok) {
       p.seg_state = 1;
       p.seg_slabs = S;
-      p.seg_cols = S_cols;
-      p.seg_classes_sig = sig;
+      p.seg_rest_below = rest_below;
     }
   }
   for (void *q : {static_cast<void *>(cnt), static_cast<void *>(beg), static_cast<void *>(pieces), static_cast<void *>(pos), static_cast<void *>(flag), tmp})

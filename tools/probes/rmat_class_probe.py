@@ -23,9 +23,9 @@ classes = [(0, 32), (32, 128), (128, 512), (512, 2048), (2048, 1 << 30)]
 if os.environ.get("CLASS_ONLY"):  # e.g. CLASS_ONLY=2048: that class alone (for a rocprofv3 run), S = 8 only
     lo_only = int(os.environ["CLASS_ONLY"])
     classes = [c for c in classes if c[0] == lo_only]
-variants = [("one kernel", {"slab_segments": 0})] + [(f"S={S}", {"slab_segments": S, "slab_whole_below": 0, "slab_short_below": 0, "slab_mid_below": 0}) for S in (2, 4, 8, 12, 15)]
+variants = [("one kernel", {"slab_segments": 0})] + [(f"S={S}", {"slab_segments": S, "slab_whole_below": 0}) for S in (2, 4, 8, 12, 15)]
 if os.environ.get("CLASS_ONLY"):
-    variants = [("S=8", {"slab_segments": 8, "slab_whole_below": 0, "slab_short_below": 0, "slab_mid_below": 0})]
+    variants = [("S=8", {"slab_segments": 8, "slab_whole_below": 0})]
 if len(sys.argv) > 2:  # a second strategy beside line_enhance, un-slabbed (e.g. wf_row: one wavefront per row, 16-B loads, no tile machinery)
     variants.append((sys.argv[2] + " (no slabs)", {"slab_segments": 0, "__strategy": sys.argv[2]}))
 best_sum = 0.0
