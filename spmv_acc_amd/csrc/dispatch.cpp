@@ -665,7 +665,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
 
   if (tun(kT_slab_segments) >= 2 && !t_in_slab) {
     // column-slab blocking without a copy: S passes over the plan's run lists (k_segment.hip), whatever the strategy name
-    const int S = tun(kT_slab_segments) > 15 ? 15 : tun(kT_slab_segments); // (+ one plane for the short rows of the two-class form: 16 in all)
+    const int S = tun(kT_slab_segments) > 16 ? 16 : tun(kT_slab_segments); // (ensure_segments takes one off when the whole-row plane of the two-class form needs it: 16 planes in all)
     if (last_error_code_only() == kOk && !t_capturing && !ensure_segments(*p, S, st)) {
       // (no room for the lists or their S x (m + 1) build temporaries: the passes are an optimisation, the strategy's own kernel runs)
       (void)hipGetLastError();

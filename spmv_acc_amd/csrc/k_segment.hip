@@ -308,8 +308,9 @@ __global__ __launch_bounds__(kThreads) void segment_merge_kernel(int entries, co
 
 } // namespace
 
-void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone, int rest_below) {
-  if (A.m <= 0) return;
+bool launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone, int rest_below) {
+  if (S < 1 || S > kSegMaxPlanes) return false; // (one counter per plane in 16 lanes / 16 packed bytes)
+  if (A.m <= 0) return true;
   long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row ...
   if (blocks > kMaxGridBlocks) blocks = kMaxGridBlocks;                                               // ... up to what a launch holds
   hipLaunchKernelGGL(segment_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S, cnt,
@@ -317,6 +318,7 @@ void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds 
   const long long short_blocks = (static_cast<long long>(A.m) + 1 + kThreads - 1) / kThreads; // m + 1: the closing zeros
   hipLaunchKernelGGL(segment_count_short_kernel, dim3(static_cast<unsigned>(short_blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S,
                      cnt, beg, not_monotone, rest_below);
+  return true;
 }
 void launch_segment_pieces(hipStream_t stream, const int *cnt_s, int m, int piece_max, int *pieces) {
   const long long blocks = (static_cast<long long>(m) + 1 + kThreads - 1) / kThreads;

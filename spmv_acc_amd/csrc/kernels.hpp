@@ -36,9 +36,10 @@ void launch_guard_check(hipStream_t stream, const CsrDev &A); // the check alone
 struct SlabBounds {
   int first[15]; // first[b] = first column of slab b + 1 (ascending); slab of column c = number of entries <= c among the first S - 1
 };
+constexpr int kSegMaxPlanes = 16; // planes a build may count (column slabs + the whole-row plane): launch_segment_count refuses more
 // rest_below > 0 (two-class form): S counts one plane more than there are column slabs; rows of fewer than rest_below non-zeros are ONE run each, all
 // columns, in that last plane (they are not cut by column at all), the longer rows are cut into the S - 1 column slabs as usual
-void launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone, int rest_below = 0);
+bool launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone, int rest_below = 0);
 void launch_segment_pieces(hipStream_t stream, const int *cnt_s, int m, int piece_max, int *pieces);
 void launch_segment_compact(hipStream_t stream, const int *cnt_s, const int *beg_s, const int *pos, int m, int piece_max, int *seg_row,
                             int *seg_begin, int *seg_len, int *has_pieces); // *has_pieces pre-zeroed: set when some run was cut

@@ -657,6 +657,10 @@ bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
   // two-class form (tunable slab_whole_below): only the rows of at least that many non-zeros are cut by column slab; every shorter row is ONE run,
   // all columns, in a pass of its own (plane S_cols)
   const int rest_below = tun(kT_slab_whole_below) > 1 ? tun(kT_slab_whole_below) : 0;
+  // (kSegMaxPlanes planes in all: the count kernels keep one counter per plane in 16 lanes / 16 packed bytes.  The automatic slab count reaches
+  // 16 from x = 496 MB on, and until this clamp the whole-row plane was then a 17th: rows of exactly 32 non-zeros -- the only ones the one-lane count
+  // kernel cuts by slab -- had slab 8's run filed twice.  Found by tools/probes/rmat26_check.py, 130,277 wrong rows on R-MAT 26)
+  if (S_cols > kSegMaxPlanes - (rest_below > 0 ? 1 : 0)) S_cols = kSegMaxPlanes - (rest_below > 0 ? 1 : 0);
   const int S = S_cols + (rest_below > 0 ? 1 : 0); // planes
   if (p.seg_state >= 0 && (p.seg_state == 0 || (p.seg_slabs == S && p.seg_rest_below == rest_below))) return true;
   if (!plan_work_allowed("building the column-slab run lists")) return false;
@@ -681,8 +685,9 @@ bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
             hip_ok(hipMemsetAsync(flag, 0, sizeof(int), st), "memset order flag");
   int unordered = 0;
   if (ok) {
-    launch_segment_count(st, A, bounds, S, cnt, beg, flag, rest_below);
-    ok = hip_ok(hipMemcpyAsync(&unordered, flag, sizeof(int), hipMemcpyDeviceToHost, st), "read order flag") &&
+    ok = launch_segment_count(st, A, bounds, S, cnt, beg, flag, rest_below);
+    if (!ok) set_error(kErrBadArgument, "slab run lists: more planes than the count kernels hold");
+    ok = ok && hip_ok(hipMemcpyAsync(&unordered, flag, sizeof(int), hipMemcpyDeviceToHost, st), "read order flag") &&
          hip_ok(hipStreamSynchronize(st), "sync run counts");
   }
   if (ok && unordered) {

@@ -996,6 +996,36 @@ def test_slab_passes_two_class_form(torch_dev, oracle, hiplib, whole_below):
         spmv_acc_amd.release_plans()
 
 
+@pytest.mark.parametrize("slabs,whole_below", [(16, 32), (16, 0), (15, 32), (40, 32)])
+def test_slab_planes_never_exceed_what_the_count_kernels_hold(torch_dev, oracle, hiplib, slabs, whole_below):
+    """Regression (round 4, found by tools/probes/rmat26_check.py on R-MAT 26): 16 column slabs -- what the automatic mode picks once x reaches 496 MB --
+    plus the whole-row plane of the two-class form made 17 planes, one more than the count kernels keep counters for; rows of EXACTLY 32 non-zeros (the
+    only ones the one-lane count kernel cuts by slab) then had one slab's run filed twice.  The build now gives the whole-row plane one of the 16; the
+    matrix here is mostly such rows, spread over all columns."""
+    torch = torch_dev
+    m, n = 40000, 90000
+    rng = np.random.default_rng(77)
+    lens = rng.choice([32, 32, 32, 31, 33, 7, 64, 200], size=m)
+    rowptr, cols, vals = synth.csr_from_row_lengths(lens, n, rng, locality=20000, far_fraction=0.3)
+    cols, vals = _sorted_rows(rowptr, cols, vals)
+    nnz = int(rowptr[-1])
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    try:
+        hiplib.spmv_acc_set_tunable(b"slab_segments", slabs)
+        hiplib.spmv_acc_set_tunable(b"slab_whole_below", whole_below)
+        for strat in ("line_enhance", "flat"):
+            ref = oracle.host_spmv(0.5, -2.0, rowptr, cols, vals, x, y0)
+            y = dy0.clone()
+            spmv_acc_amd.csr_spmv(0.5, -2.0, m, n, nnz, drp, dci, dv, dx, y, strategy=strat)
+            torch.cuda.synchronize()
+            assert oracle.scaled_error(y.cpu().numpy(), ref, 0.5, -2.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, (strat, slabs, whole_below)
+            assert spmv_acc_amd.query_plan(drp, m)["slab_passes"] == min(slabs, 16 - (1 if whole_below > 1 else 0))
+    finally:
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans()
+
+
 def test_slab_segments_replay_from_a_graph_and_are_bitwise_stable(torch_dev, oracle, hiplib):
     """The passes are ordinary launches over plan-resident lists: captured after one warm-up call they replay, and two runs give the
     same bits (whole runs add straight into y, the pieces of a long run are added in entry order by one thread: no atomics)."""
