@@ -308,7 +308,7 @@ void run_segments(hipStream_t st, Plan &p, double alpha, double beta, const doub
   for (int s = 0; s < p.seg_slabs; ++s) {
     if (p.seg_entries[s] == 0) continue;
     launch_segment_tiles(st, p.seg_blocks[s], alpha, p.seg_blk[s], p.seg_row[s], p.seg_begin[s], p.seg_vptr[s], p.A.ci, p.A.v, x, p.d_seg_ys, y);
-    if (p.seg_pieces[s]) launch_segment_merge(st, p.seg_entries[s], p.seg_row[s], p.d_seg_ys, y);
+    if (p.seg_pieces[s]) launch_segment_merge(st, p.seg_pieces[s], p.seg_cut[s], p.seg_entries[s], p.seg_row[s], p.d_seg_ys, y);
   }
 }
 // automatic mode: slabs of about 32 MB of x (R-MAT scale 25, x = 256 MB, S = 4 / 8 / 12 / 16: 5.92 / 5.31 / 5.59 / 6.08 ms, 7.27 without;

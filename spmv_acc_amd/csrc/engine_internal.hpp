@@ -175,13 +175,13 @@ struct Plan {
   bool seg_early_tried = false; // the comparison against the COARSE row-block-plus kernel (dispatch.cpp::run_plus) has been made
   // per slab: one entry per run (or piece of a long run): its row, its first non-zero, its place in the pass's virtual non-zero
   // order (entries + 1 prefix sums of the lengths); and the first entry of every workgroup (blocks + 1)
-  std::vector<int *> seg_row, seg_begin, seg_vptr, seg_blk;
-  std::vector<int> seg_entries, seg_blocks, seg_pieces; // seg_pieces[s] != 0: the slab holds runs cut into pieces (merge kernel needed)
+  std::vector<int *> seg_row, seg_begin, seg_vptr, seg_blk, seg_cut; // seg_cut[s]: first entries of the slab's cut runs (seg_pieces[s] of them)
+  std::vector<int> seg_entries, seg_blocks, seg_pieces; // seg_pieces[s]: runs of the slab that were cut into pieces (> 0: merge kernel needed)
   double *d_seg_ys = nullptr; // one partial sum per entry of the longest list
   int seg_rest_below = 0;      // two-class form: rows of fewer non-zeros than this are whole runs in the last plane (0: every row is cut by slab)
   void free_segments() {
     seg_rest_below = 0;
-    for (auto *list : {&seg_row, &seg_begin, &seg_vptr, &seg_blk}) {
+    for (auto *list : {&seg_row, &seg_begin, &seg_vptr, &seg_blk, &seg_cut}) {
       for (int *q : *list)
         if (q) (void)hipFree(q);
       list->clear();

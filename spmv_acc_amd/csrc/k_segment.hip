@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kThreads) void segment_compact_kernel(const int *__
   int at = beg_s[r];
   // a run cut into pieces: its entries carry the row with the top bit set (their sums go through ys and the merge kernel)
   const int tag = left > piece_max ? static_cast<int>(static_cast<unsigned>(r) | 0x80000000u) : static_cast<int>(r);
-  if (left > piece_max) *has_pieces = 1; // idempotent store
+  if (left > piece_max) atomicAdd(has_pieces, 1); // (a count: the merge list is sized from it)
   for (int i = pos[r]; left > 0; ++i) { // (a hub row writes a few hundred entries)
     const int len = left < piece_max ? left : piece_max;
     seg_row[i] = tag;
@@ -174,6 +174,14 @@ __global__ __launch_bounds__(kThreads) void segment_compact_kernel(const int *__
     at += len;
     left -= len;
   }
+}
+
+// the pass's cut runs, for the merge kernel: cut[k] = first entry of a run that was cut into pieces.  In whatever order the atomic hands out the
+// places: every cut run is merged by itself, so the order of the list does not reach the sums
+__global__ __launch_bounds__(kThreads) void segment_cut_list_kernel(const int *__restrict__ cnt_s, const int *__restrict__ pos, int m, int piece_max,
+                                                                    int *__restrict__ counter, int *__restrict__ cut) {
+  const long long r = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
+  if (r < m && cnt_s[r] > piece_max) cut[atomicAdd(counter, 1)] = pos[r];
 }
 
 // cost[i] = max(len[i], kSegMinCost) for the workgroup cut; both arrays get a closing zero for the scans
@@ -292,18 +300,26 @@ __global__ __launch_bounds__(kThreads) void segment_tile_kernel(double alpha, co
   }
 }
 
-// the pieces of long runs: y[row] += their partial sums, added in entry order by the run's first piece (pieces of one run are
-// consecutive entries with the same tagged row: deterministic, no atomics)
-__global__ __launch_bounds__(kThreads) void segment_merge_kernel(int entries, const int *__restrict__ seg_row, const double *__restrict__ ys,
-                                                                 double *__restrict__ y) {
-  const long long i = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
-  if (i >= entries) return;
-  const int r = seg_row[i];
-  if (r >= 0) return; // a whole run: the tile kernel has added it
-  if (i > 0 && seg_row[i - 1] == r) return;
-  double sum = ys[i];
-  for (long long j = i + 1; j < entries && seg_row[j] == r; ++j) sum += ys[j];
-  y[static_cast<int>(static_cast<unsigned>(r) & 0x7FFFFFFFu)] += sum;
+// the pieces of long runs: y[row] += their partial sums.  One WAVEFRONT per cut run (the plan's list of them): lane l adds the pieces l, l + 64, ...
+// in that order, a fixed butterfly adds the lanes -- the same order every run: deterministic, no atomics.  (Until round 4 one THREAD per entry looked
+// for first pieces and added its run's pieces one by one: 18 us per pass on R-MAT 25 just to read 5 M tags, and 30-90 ms on a matrix whose single
+// giant row is 586 K pieces -- profiles/r04_extreme_shapes_check.txt.)
+__global__ __launch_bounds__(kThreads) void segment_merge_kernel(int ncut, const int *__restrict__ cut, int entries, const int *__restrict__ seg_row,
+                                                                 const double *__restrict__ ys, double *__restrict__ y) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long k = static_cast<long long>(blockIdx.x) * (kThreads / kWave) + threadIdx.x / kWave;
+  if (k >= ncut) return; // (wave-uniform)
+  const int first = cut[k];
+  const int r = seg_row[first];
+  double sum = 0.0;
+  for (long long base = first;; base += kWave) { // the run's pieces are consecutive entries with the same tagged row
+    const long long j = base + lane;
+    const bool mine = j < entries && seg_row[j] == r;
+    if (mine) sum += ys[j];
+    if (__ballot(mine) != ~0ULL) break;
+  }
+  sum = group_sum<64>(sum);
+  if (lane == 0) y[static_cast<int>(static_cast<unsigned>(r) & 0x7FFFFFFFu)] += sum;
 }
 
 } // namespace
@@ -345,10 +361,15 @@ void launch_segment_tiles(hipStream_t stream, int nblocks, double alpha, const i
   if (nblocks <= 0) return;
   hipLaunchKernelGGL(segment_tile_kernel, dim3(nblocks), dim3(kThreads), 0, stream, alpha, blk_first, seg_row, seg_begin, vptr, ci, v, x, ys, y);
 }
-void launch_segment_merge(hipStream_t stream, int entries, const int *seg_row, const double *ys, double *y) {
-  if (entries <= 0) return;
-  const long long blocks = (static_cast<long long>(entries) + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(segment_merge_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, entries, seg_row, ys, y);
+void launch_segment_cut_list(hipStream_t stream, const int *cnt_s, const int *pos, int m, int piece_max, int *counter, int *cut) {
+  if (m <= 0) return;
+  const long long blocks = (static_cast<long long>(m) + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(segment_cut_list_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, cnt_s, pos, m, piece_max, counter, cut);
+}
+void launch_segment_merge(hipStream_t stream, int ncut, const int *cut, int entries, const int *seg_row, const double *ys, double *y) {
+  if (ncut <= 0) return;
+  const long long blocks = (static_cast<long long>(ncut) + (kThreads / kWave) - 1) / (kThreads / kWave);
+  hipLaunchKernelGGL(segment_merge_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, ncut, cut, entries, seg_row, ys, y);
 }
 
 } // namespace spmv_acc

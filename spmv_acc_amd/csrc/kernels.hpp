@@ -42,14 +42,16 @@ constexpr int kSegMaxPlanes = 16; // planes a build may count (column slabs + th
 bool launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds &B, int S, int *cnt, int *beg, int *not_monotone, int rest_below = 0);
 void launch_segment_pieces(hipStream_t stream, const int *cnt_s, int m, int piece_max, int *pieces);
 void launch_segment_compact(hipStream_t stream, const int *cnt_s, const int *beg_s, const int *pos, int m, int piece_max, int *seg_row,
-                            int *seg_begin, int *seg_len, int *has_pieces); // *has_pieces pre-zeroed: set when some run was cut
+                            int *seg_begin, int *seg_len, int *has_pieces); // *has_pieces pre-zeroed: counts the runs that were cut
+// cut[0 .. *counter): first entries of the pass's cut runs (any order); *counter pre-zeroed, cut sized from launch_segment_compact's count
+void launch_segment_cut_list(hipStream_t stream, const int *cnt_s, const int *pos, int m, int piece_max, int *counter, int *cut);
 constexpr int kSegPiece = 512; // longer runs are cut into pieces (entries of their own)
 void launch_segment_cost(hipStream_t stream, int entries, int *seg_len, int *cost); // both entries + 1 long; closes them with a zero
 int segment_block_count(long long total_cost);
 void launch_segment_blocks(hipStream_t stream, int entries, int nblocks, const int *cptr, int *blk_first); // blk_first: nblocks + 1
 void launch_segment_tiles(hipStream_t stream, int nblocks, double alpha, const int *blk_first, const int *seg_row, const int *seg_begin,
                           const int *vptr, const int *ci, const double *v, const double *x, double *ys, double *y);
-void launch_segment_merge(hipStream_t stream, int entries, const int *seg_row, const double *ys, double *y);
+void launch_segment_merge(hipStream_t stream, int ncut, const int *cut, int entries, const int *seg_row, const double *ys, double *y);
 // opt-in full check (k_guard.hip, tunable guard_full): one partial digest of rowptr[0 .. m] per workgroup into part[0 .. parts);
 // then ONE workgroup adds them up and either writes the digest to digest_out (plan build) or compares it with `expected` and raises `stale`
 constexpr int kDigestMaxParts = 1024;

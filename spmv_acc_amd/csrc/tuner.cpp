@@ -694,7 +694,7 @@ bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
     p.seg_state = 0; // some row's columns do not ascend across a slab boundary: its slab parts are not runs
     tune_log("m %d nnz %d: slab_segments: rows are not ordered by column slab, ordinary path", A.m, A.nnz);
   } else if (ok) {
-    for (auto *list : {&p.seg_row, &p.seg_begin, &p.seg_vptr, &p.seg_blk}) list->assign(S, nullptr);
+    for (auto *list : {&p.seg_row, &p.seg_begin, &p.seg_vptr, &p.seg_blk, &p.seg_cut}) list->assign(S, nullptr);
     p.seg_entries.assign(S, 0);
     p.seg_blocks.assign(S, 0);
     p.seg_pieces.assign(S, 0);
@@ -737,6 +737,20 @@ bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
              hip_ok(hipMemcpyAsync(&last[1], p.seg_vptr[s] + entries, sizeof(int), hipMemcpyDeviceToHost, st), "read pass size") &&
              hip_ok(hipStreamSynchronize(st), "sync run scans");
         total_cost = last[0];
+      }
+      if (ok && p.seg_pieces[s] > 0) { // the merge kernel's list: one wavefront per cut run (cnt_s / pos are still this slab's)
+        int listed = 0;
+        ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p.seg_cut[s]), sizeof(int) * static_cast<size_t>(p.seg_pieces[s])), "hipMalloc cut runs") &&
+             hip_ok(hipMemsetAsync(flag, 0, sizeof(int), st), "memset cut-run counter");
+        if (ok) {
+          launch_segment_cut_list(st, cnt_s, pos, A.m, kSegPiece, flag, p.seg_cut[s]);
+          ok = hip_ok(hipMemcpyAsync(&listed, flag, sizeof(int), hipMemcpyDeviceToHost, st), "read cut-run count") &&
+               hip_ok(hipStreamSynchronize(st), "sync cut runs");
+          if (ok && listed != p.seg_pieces[s]) {
+            set_error(kErrHip, "slab run lists: the cut-run list disagrees with the compaction");
+            ok = false;
+          }
+        }
       }
       if (ok) {
         const int nblocks = segment_block_count(total_cost);
