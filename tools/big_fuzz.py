@@ -47,7 +47,8 @@ for case in range(cases):
         lens = (lens.double() * (1.5e8 / total)).long()
     rp = torch.zeros(m + 1, dtype=torch.int64, device="cuda"); torch.cumsum(lens, 0, out=rp[1:])
     nnz = int(rp[-1].item())
-    n = int(rng.choice([m, max(1, m // 7), 3 * m + 5, 1000]))
+    # (the last two: x of 0.64 / 2.6 GB whatever m is -- what the automatic slab count and the hint rules key on; R-MAT 26 showed a fault only x >= 496 MB reaches)
+    n = int(rng.choice([m, max(1, m // 7), 3 * m + 5, 1000, m, 3 * m + 5, 80_000_000, 320_000_000]))
     rows = torch.repeat_interleave(torch.arange(m, device="cuda"), lens, output_size=nnz)
     cols_law = rng.choice(["near", "clusters", "uniform", "powerlaw"])
     if cols_law == "uniform":
