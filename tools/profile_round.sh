@@ -14,7 +14,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "[profile_round] kernel trace"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py "$@" --no-cpu-baseline --no-sensitivity > $OUT/bench_under_trace.json 2> $OUT/trace.log || exit 1
-S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
+# (bench.py measures its extra legs in child processes and rocprofv3 writes one summary per process: the parent's -- the lowest pid -- holds the timed region)
+S=$(find $OUT/trace -name "*kernel_stats.csv" | awk -F/ '{f=$NF; sub(/_kernel_stats.csv/,"",f); print f+0, $0}' | sort -n | head -1 | cut -d" " -f2-)
 { head -1 $S; grep -E "spmv_acc" $S; } > $OUT/kernel_stats_spmv.csv
 # The counter passes serialise and perturb the kernels, which is enough to tip the per-matrix timings between near-equal
 # candidates: they run with the cache policy the (unperturbed) trace pass settled on, so all three passes profile one kernel.
