@@ -34,6 +34,7 @@ struct HostCsr {
   std::vector<int> colidx;
   std::vector<double> values;
   std::vector<double> x; // only the .csr text format carries the dense vector
+  int valtype = 3;       // what the file declared: 1 pattern, 2 integer, 3 real, 4 complex (real parts kept) -- the bin2 header's code
 };
 
 // Structural checks every reader ends with: a file that fails them would send the kernels out of bounds (the reference's
@@ -115,6 +116,7 @@ inline HostCsr read_bin2(const std::string &path) {
   const int32_t valtype = hdr[2];
   if (valtype < 1 || valtype > 4) throw std::runtime_error(path + ": unsupported value type");
   HostCsr A;
+  A.valtype = valtype;
   A.rows = hdr[3];
   A.cols = hdr[4];
   A.nnz = hdr[5];
@@ -233,19 +235,33 @@ inline HostCsr read_matrix_market(const std::string &path) {
     throw std::runtime_error(path + ": expected " + std::to_string(declared) + " entries, found " + std::to_string(seen));
   if (e.size() > static_cast<size_t>(kMaxEntries)) throw std::runtime_error(path + ": more non-zeros than one call can take");
   HostCsr A = coo_to_csr(static_cast<int>(rows), static_cast<int>(cols), e);
+  A.valtype = pattern ? 1 : (field == "integer" ? 2 : (complex_field ? 4 : 3));
   validate_csr(path, A);
   return A;
 }
 
-// ---- writers (tests, tools) --------------------------------------------------------------------------------------------
+// ---- writer: the bin2 file the reference's converter makes ------------------------------------------------------------
+// What `suitesparse-dl conv` writes for a MatrixMarket file (tools/suitesparse-dl/conv/conv.go:92-150, little-endian): magic, version 2, the
+// value type of the source, rows, cols, nnz, rowptr, colindex, then the values as the type says -- none for a pattern matrix, int32 for an
+// integer one (conv.go:176-186 converts by truncation, as here), f64 otherwise.  The reference's csr_binary_reader.hpp and read_bin2 above
+// read it back.  (The reference's tool is Go; this is its one function a user of spmv-cli needs: `spmv-cli in.mtx -f mtx --convert-bin2 out.bin2`.)
 inline void write_bin2(const std::string &path, const HostCsr &A) {
   std::ofstream f(path, std::ios::out | std::ios::binary);
   if (!f) throw std::runtime_error("cannot write " + path);
-  const int32_t hdr[6] = {0x20211015, 2, 3, A.rows, A.cols, A.nnz};
+  const int32_t valtype = A.valtype >= 1 && A.valtype <= 4 ? A.valtype : 3;
+  const int32_t hdr[6] = {0x20211015, 2, valtype, A.rows, A.cols, A.nnz};
   f.write(reinterpret_cast<const char *>(hdr), sizeof(hdr));
   f.write(reinterpret_cast<const char *>(A.rowptr.data()), static_cast<std::streamsize>(sizeof(int32_t) * A.rowptr.size()));
   f.write(reinterpret_cast<const char *>(A.colidx.data()), static_cast<std::streamsize>(sizeof(int32_t) * A.colidx.size()));
-  f.write(reinterpret_cast<const char *>(A.values.data()), static_cast<std::streamsize>(sizeof(double) * A.values.size()));
+  if (valtype == 2) {
+    std::vector<int32_t> iv(A.values.size());
+    for (size_t i = 0; i < iv.size(); ++i) iv[i] = static_cast<int32_t>(A.values[i]);
+    f.write(reinterpret_cast<const char *>(iv.data()), static_cast<std::streamsize>(sizeof(int32_t) * iv.size()));
+  } else if (valtype != 1) {
+    f.write(reinterpret_cast<const char *>(A.values.data()), static_cast<std::streamsize>(sizeof(double) * A.values.size()));
+  }
+  f.flush();
+  if (!f) throw std::runtime_error("write failed: " + path);
 }
 
 } // namespace spmv_cli

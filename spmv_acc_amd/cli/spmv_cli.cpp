@@ -9,6 +9,8 @@
 //                                                     hipMemcpyAsync, one RCCL communicator per GPU from ncclCommInitAll, every
 //                                                     step = local SpMV + exchange of the y slices (spmv_acc_shard_step), the
 //                                                     gathered y of rank 0 verified like the single-GPU run)
+//   spmv-cli <matrix> -f ... --convert-bin2 OUT      (tools/suitesparse-dl/conv/conv.go:92-150, the reference's Go converter, for one file: the
+//                                                     matrix as the bin2 file that tool writes; no device needed)
 //   ... --device-verify                               (the reference's -DDEVICE_SIDE_VERIFY_FLAG=ON build, config.cmake:9 +
 //                                                     cli/verification.cpp:81-112: the expected y comes from rocSPARSE on
 //                                                     the device instead of host_spmv; rocSPARSE is loaded with dlopen only
@@ -117,7 +119,7 @@ VerifyResult verify_y(const double *dy, const double *hy, int n) {
 }
 
 struct Options {
-  std::string path, format = "csr", strategy, dump;
+  std::string path, format = "csr", strategy, dump, convert;
 #ifndef SPMV_CLI_DEVICE_VERIFY_DEFAULT
 #define SPMV_CLI_DEVICE_VERIFY_DEFAULT 0 // -DDEVICE_SIDE_VERIFY_FLAG=ON (CMakeLists.txt) makes --device-verify the default
 #endif
@@ -148,6 +150,8 @@ bool parse_args(int argc, char **argv, Options &o) {
       o.stats = true;
     } else if (a == "--dump-bin") {
       if (!need(o.dump)) return false;
+    } else if (a == "--convert-bin2") {
+      if (!need(o.convert)) return false;
     } else if (a == "--gpus" || a == "--pipeline") {
       std::string s;
       if (!need(s)) return false;
@@ -564,12 +568,17 @@ int run_benchmark(const Options &o, HostCsr &A, HostVectors &v) {
 int main(int argc, char **argv) {
   Options o;
   if (!parse_args(argc, argv, o)) {
-    std::cerr << "usage: spmv-cli <mtx_path> [-f|--format csr|mtx|bin2] [--strategy NAME] [--benchmark] [--no-gpu] [--device-verify] [--gpus N [--pipeline C]] [--print-stats] [--dump-bin OUT] "
+    std::cerr << "usage: spmv-cli <mtx_path> [-f|--format csr|mtx|bin2] [--strategy NAME] [--benchmark] [--no-gpu] [--device-verify] [--gpus N [--pipeline C]] [--print-stats] [--dump-bin OUT] [--convert-bin2 OUT.bin2] "
                  "[--alpha A] [--beta B]\n";
     return 2;
   }
   try {
     HostCsr A = load(o);
+    if (!o.convert.empty()) { // the reference's `suitesparse-dl conv` for one file: any readable format -> bin2 (matrix_io.hpp::write_bin2)
+      spmv_cli::write_bin2(o.convert, A);
+      std::printf("CONVERTED %s -> %s rows=%d cols=%d nnz=%d valtype=%d\n", o.path.c_str(), o.convert.c_str(), A.rows, A.cols, A.nnz, A.valtype);
+      return 0;
+    }
     if (!o.dump.empty()) { // reader check: the parsed matrix, raw (int32 rows, cols, nnz, x_len; rowptr; colindex; values; x)
       FILE *f = std::fopen(o.dump.c_str(), "wb");
       if (!f) throw std::runtime_error("cannot write " + o.dump);

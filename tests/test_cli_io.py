@@ -300,6 +300,71 @@ def test_readers_match_reference_goldens(cli, tmp_path):
             assert np.array_equal(x, g[f"{name}__x"]), name
 
 
+def test_convert_bin2_writes_what_the_reference_converter_writes(cli, tmp_path, oracle):
+    """`spmv-cli in.mtx -f mtx --convert-bin2 out.bin2` = the reference's Go converter for one file (tools/suitesparse-dl/conv/conv.go:92-150 +
+    mm_parser.go:205-245, restated here in numpy): off-diagonals of symmetric / hermitian files mirrored, entries sorted by (row, column), little-endian
+    header magic / version 2 / value type / rows / cols / nnz, rowptr, colindex, then no values (pattern), int32 (integer) or f64 (real; complex keeps
+    the real part).  Byte for byte; and the reference's own compiled reader gets the same matrix back from the converted file (real / pattern: its
+    integer branch overruns its buffer)."""
+    import struct
+
+    rng = np.random.default_rng(31)
+    cases = [("real", "general"), ("real", "symmetric"), ("integer", "general"), ("pattern", "symmetric"), ("complex", "hermitian"), ("integer", "symmetric")]
+    for k, (field, sym) in enumerate(cases):
+        m = int(rng.integers(5, 120))
+        n = m if sym != "general" else int(rng.integers(5, 150))
+        pairs = set()
+        while len(pairs) < 4 * m:
+            r, c = int(rng.integers(1, m + 1)), int(rng.integers(1, n + 1))
+            if sym != "general" and c > r:
+                r, c = c, r  # lower triangle, as such files are stored
+            pairs.add((r, c))
+        pairs = sorted(pairs, key=lambda rc: (rc[1], rc[0]))  # column-major, as SuiteSparse files are
+        vals = rng.integers(-50, 50, len(pairs)).astype(np.float64) if field == "integer" else rng.standard_normal(len(pairs))
+        pm = str(tmp_path / f"c{k}.mtx")
+        with open(pm, "w") as f:
+            f.write(f"%%MatrixMarket matrix coordinate {field} {sym}\n% a comment\n{m} {n} {len(pairs)}\n")
+            for (r, c), v in zip(pairs, vals):
+                f.write({"pattern": f"{r} {c}\n", "integer": f"{r} {c} {int(v)}\n", "complex": f"{r} {c} {v:.17g} 0.25\n"}.get(field, f"{r} {c} {v:.17g}\n"))
+        # conv.go, restated
+        rows = [r - 1 for r, c in pairs] + [c - 1 for r, c in pairs if sym != "general" and r != c]
+        cols = [c - 1 for r, c in pairs] + [r - 1 for r, c in pairs if sym != "general" and r != c]
+        v = list(vals) + [x for (r, c), x in zip(pairs, vals) if sym != "general" and r != c]
+        if field == "pattern":
+            v = [1.0] * len(rows)
+        order = sorted(range(len(rows)), key=lambda i: (rows[i], cols[i]))
+        rows, cols, v = np.array(rows)[order], np.array(cols, dtype="<i4")[order], np.array(v)[order]
+        rowptr = np.zeros(m + 1, dtype="<i4")
+        np.add.at(rowptr, rows + 1, 1)
+        rowptr = np.cumsum(rowptr).astype("<i4")
+        valtype = {"pattern": 1, "integer": 2, "real": 3, "complex": 4}[field]
+        body = b"" if valtype == 1 else (v.astype("<i4").tobytes() if valtype == 2 else v.astype("<f8").tobytes())
+        want = struct.pack("<6i", 0x20211015, 2, valtype, m, n, len(rows)) + rowptr.tobytes() + cols.tobytes() + body
+        pb = str(tmp_path / f"c{k}.bin2")
+        r = subprocess.run([cli, pm, "-f", "mtx", "--convert-bin2", pb], capture_output=True, text=True)
+        assert r.returncode == 0 and f"nnz={len(rows)} valtype={valtype}" in r.stdout, (field, sym, r.stdout, r.stderr)
+        assert open(pb, "rb").read() == want, (field, sym)
+        # read back: the same matrix as the .mtx gives (this CLI) ...
+        d1, d2 = pm + ".dump", pb + ".dump"
+        assert subprocess.run([cli, pm, "-f", "mtx", "--dump-bin", d1], capture_output=True).returncode == 0
+        assert subprocess.run([cli, pb, "-f", "bin2", "--dump-bin", d2], capture_output=True).returncode == 0
+        a, b = _read_dump(d1), _read_dump(d2)
+        assert a[:3] == b[:3] and all(np.array_equal(p_, q_) for p_, q_ in zip(a[3:6], b[3:6])), (field, sym)
+        # ... and as the reference's compiled reader gets from the converted file
+        if oracle.ref_readers() is not None and valtype != 2:
+            ref = oracle.ref_read_matrix(pb, "bin2")
+            assert ref[:3] == b[:3] and all(np.array_equal(p_, q_) for p_, q_ in zip(ref[3:6], b[3:6])), (field, sym, "reference reader")
+    # a .csr text file and a bin2 file convert too (real values); an unwritable target is an error, not a crash
+    rowptr, cols, vals = synth.random_csr(40, 30, 4, seed=9, kind="uniform")
+    pc = str(tmp_path / "t.csr")
+    write_csr_text(pc, rowptr, cols, vals, rng.standard_normal(30))
+    out = str(tmp_path / "t.bin2")
+    assert subprocess.run([cli, pc, "-f", "csr", "--convert-bin2", out], capture_output=True).returncode == 0
+    want = struct.pack("<6i", 0x20211015, 2, 3, 40, 30, int(rowptr[-1])) + rowptr.astype("<i4").tobytes() + cols.astype("<i4").tobytes() + vals.astype("<f8").tobytes()
+    assert open(out, "rb").read() == want
+    assert subprocess.run([cli, pc, "-f", "csr", "--convert-bin2", "/nonexistent-dir/x.bin2"], capture_output=True).returncode == 3
+
+
 def test_readers_match_compiled_reference_random(cli, tmp_path, oracle):
     if oracle.ref_readers() is None:
         pytest.skip("oracle/_ref/libref_readers.so not built (no /root/reference on this machine)")
