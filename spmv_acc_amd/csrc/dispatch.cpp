@@ -301,13 +301,51 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
 
 thread_local bool t_in_slab = false; // this thread is running one slab of a column-slab SpMV (no nesting)
 bool ensure_segments(Plan &p, int S, hipStream_t st);
+// The whole-row pass of the two-class lists (rows below slab_whole_below, each ONE run over all columns) gathers from all of x like the one-kernel
+// path, and like there the plan's gather hints pay: R-MAT 24 / 25 / 26: -1.8 / -2.7 / -3.3 % of the whole SpMV (2.35 -> 2.30, 5.10 -> 4.97, 11.31 ->
+// 10.93 ms).  Inside the column-slab passes they cost 10-30 % (the census' hot set is x-wide: inside a 32 MB slab almost every gather is "cold", and
+// non-temporal gathers forfeit the slab's own reuse) -- profiles/r04_seg_hint_ab.txt.  Timed once per plan, this pass alone, hinted against plain;
+// -1 undecided (then: hinted, the rule), 0 plain, 1 hinted.  Returns false on a HIP error only.
+thread_local bool t_in_segment_timing = false;
+static bool decide_whole_pass_hint(hipStream_t st, Plan &p, const double *x) {
+  const int s = p.seg_slabs - 1;
+  if (p.seg_rest_below <= 0 || p.seg_entries[s] == 0 || tun(kT_gather_hint) == 0 || static_cast<long long>(p.A.n) * 8 >= (1LL << 32)) return true;
+  // (the census: once per plan, not inside a capture; ensure_hint keeps its own rules -- an x below 96 MB has nothing to protect)
+  if (p.hint_state < 0 && !t_capturing && !ensure_hint(p, st)) return false;
+  if (p.hint_state != 1 || !p.d_cold) return true;
+  if (p.seg_whole_hint >= 0 || t_capturing || by_rule()) return true;
+  double *scratch = nullptr;
+  if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
+  ++t_plan_work;
+  TuneTimer timer; // (no y reset: the pass adds into whatever the scratch holds)
+  float ms[2] = {0.f, 0.f};
+  bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
+  for (int h = 0; ok && h < 2; ++h)
+    ok = timer.time(st, [&] {
+      launch_segment_tiles(st, p.seg_blocks[s], 1.0, p.seg_blk[s], p.seg_row[s], p.seg_begin[s], p.seg_vptr[s], p.A.ci, p.A.v, x, p.d_seg_ys, scratch,
+                           h ? p.d_cold : nullptr);
+    }, &ms[h]);
+  if (!ok) return false;
+  p.seg_whole_hint = ms[1] < 0.985f * ms[0] ? 1 : 0;
+  tune_log("m %d nnz %d: slab passes, whole-row pass: plain gathers %.1f us, hinted %.1f us -> %s", p.A.m, p.A.nnz, ms[0] * 1e3f, ms[1] * 1e3f,
+           p.seg_whole_hint ? "hinted" : "plain");
+  return true;
+}
+
 // the S passes over the plan's run lists (k_segment.hip); p.seg_state == 1
 void run_segments(hipStream_t st, Plan &p, double alpha, double beta, const double *x, double *y) {
+  const int whole = p.seg_rest_below > 0 ? p.seg_slabs - 1 : -1; // the whole-row pass of the two-class lists
+  // (a call that is itself a trial launch of a timing phase decides nothing: time_against_segments has asked before it started its clock)
+  if (!t_in_segment_timing && !decide_whole_pass_hint(st, p, x)) return;
+  const bool whole_hinted = whole >= 0 && p.hint_state == 1 && p.d_cold && p.seg_whole_hint != 0 && tun(kT_gather_hint) != 0 &&
+                            static_cast<long long>(p.A.n) * 8 < (1LL << 32);
+  const unsigned char *whole_cold = whole_hinted ? p.d_cold : nullptr;
   launch_guard_check(st, p.A); // (the passes read run lists, not rowptr: the caller's rowptr is checked here)
   if (beta != 1.0 || p.A.yin) launch_scale_y(st, p.A.m, beta, y, p.A.yin);
   for (int s = 0; s < p.seg_slabs; ++s) {
     if (p.seg_entries[s] == 0) continue;
-    launch_segment_tiles(st, p.seg_blocks[s], alpha, p.seg_blk[s], p.seg_row[s], p.seg_begin[s], p.seg_vptr[s], p.A.ci, p.A.v, x, p.d_seg_ys, y);
+    launch_segment_tiles(st, p.seg_blocks[s], alpha, p.seg_blk[s], p.seg_row[s], p.seg_begin[s], p.seg_vptr[s], p.A.ci, p.A.v, x, p.d_seg_ys, y,
+                         s == whole ? whole_cold : nullptr);
     if (p.seg_pieces[s]) launch_segment_merge(st, p.seg_pieces[s], p.seg_cut[s], p.seg_entries[s], p.seg_row[s], p.d_seg_ys, y);
   }
 }
@@ -352,8 +390,11 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
     bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
     const double *keep_yin = p.A.yin;
     p.A.yin = nullptr; // (the trial runs update the scratch vector in place)
+    ok = ok && decide_whole_pass_hint(st, p, x); // (the passes' own choice first, outside the clock of the comparison)
+    t_in_segment_timing = true;
     ok = ok && timer.time(st, [&] { launch_here(1.0, trial_beta(), scratch); }, &ms[0], /*at_least=*/2) &&
          timer.time(st, [&] { run_segments(st, p, 1.0, trial_beta(), x, scratch); }, &ms[1], /*at_least=*/2);
+    t_in_segment_timing = false;
     p.A.yin = keep_yin;
     *timed = ok;
     return ok;

@@ -179,8 +179,10 @@ struct Plan {
   std::vector<int> seg_entries, seg_blocks, seg_pieces; // seg_pieces[s]: runs of the slab that were cut into pieces (> 0: merge kernel needed)
   double *d_seg_ys = nullptr; // one partial sum per entry of the longest list
   int seg_rest_below = 0;      // two-class form: rows of fewer non-zeros than this are whole runs in the last plane (0: every row is cut by slab)
+  int seg_whole_hint = -1;     // that plane's gathers with the plan's hints: -1 not timed (then: hinted), 0 plain, 1 hinted (dispatch.cpp::decide_whole_pass_hint)
   void free_segments() {
     seg_rest_below = 0;
+    seg_whole_hint = -1;
     for (auto *list : {&seg_row, &seg_begin, &seg_vptr, &seg_blk, &seg_cut}) {
       for (int *q : *list)
         if (q) (void)hipFree(q);

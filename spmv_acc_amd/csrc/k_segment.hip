@@ -208,10 +208,12 @@ __global__ __launch_bounds__(kThreads) void segment_blocks_kernel(int entries, i
 }
 
 // one pass: y[row] += alpha * sum over the run (ys[e] = alpha * sum for the pieces of a long run), a workgroup per kSegCost of cost
+template <bool HINT>
 __global__ __launch_bounds__(kThreads) void segment_tile_kernel(double alpha, const int *__restrict__ blk_first, const int *__restrict__ seg_row,
                                                                 const int *__restrict__ seg_begin, const int *__restrict__ vptr,
                                                                 const int *__restrict__ ci, const double *__restrict__ v,
-                                                                const double *__restrict__ x, double *__restrict__ ys, double *__restrict__ y) {
+                                                                const double *__restrict__ x, double *__restrict__ ys, double *__restrict__ y,
+                                                                const unsigned char *__restrict__ cold) {
   __shared__ __attribute__((aligned(16))) double tile[kSegTile];
   // the owner map lives in the tile's first 4 KB: it is read into registers (and a barrier passed) before the first product is
   // written.  21.9 KB of LDS per workgroup = 7 workgroups per CU, like the other tile kernels (28 KB with a map of its own: 5)
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(kThreads) void segment_tile_kernel(double alpha, co
   // stage: virtual non-zero k = i * 256 + t lives at run start + offset within the run; all stream loads, then all gathers
   int cc[kNnzPerThread];
   double aa[kNnzPerThread];
+  unsigned cb = 0; // HINT: bit i = the plan's cold bit of this lane's i-th non-zero
 #pragma unroll
   for (int i = 0; i < kNnzPerThread; ++i) {
     const int k = i * kThreads + t;
@@ -271,12 +274,14 @@ __global__ __launch_bounds__(kThreads) void segment_tile_kernel(double alpha, co
       const int at = s_begin[e] + (k - s_ofs[e]);
       cc[i] = load_stream(ci + at);
       aa[i] = load_stream(v + at);
+      if (HINT) cb |= ((static_cast<unsigned>(cold[at >> 3]) >> (at & 7)) & 1u) << i;
     }
   }
   __syncthreads(); // every lane has read its owners: the map's place becomes tile
+  const XGather xr = make_xgather(x, HINT);
 #pragma unroll
   for (int i = 0; i < kNnzPerThread; ++i)
-    if (cc[i] >= 0) tile[i * kThreads + t] = aa[i] * x[cc[i]];
+    if (cc[i] >= 0) tile[i * kThreads + t] = aa[i] * (HINT ? gather_hinted(xr, cc[i], (cb >> i) & 1u) : x[cc[i]]);
   __syncthreads();
   // sums: w lanes per entry, up to 256 entries per round
   for (int r0 = 0; r0 < ne; r0 += kThreads) { // (workgroup-uniform)
@@ -357,9 +362,12 @@ void launch_segment_blocks(hipStream_t stream, int entries, int nblocks, const i
   hipLaunchKernelGGL(segment_blocks_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, entries, nblocks, cptr, blk_first);
 }
 void launch_segment_tiles(hipStream_t stream, int nblocks, double alpha, const int *blk_first, const int *seg_row, const int *seg_begin,
-                          const int *vptr, const int *ci, const double *v, const double *x, double *ys, double *y) {
+                          const int *vptr, const int *ci, const double *v, const double *x, double *ys, double *y, const unsigned char *cold) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(segment_tile_kernel, dim3(nblocks), dim3(kThreads), 0, stream, alpha, blk_first, seg_row, seg_begin, vptr, ci, v, x, ys, y);
+  if (cold)
+    hipLaunchKernelGGL(segment_tile_kernel<true>, dim3(nblocks), dim3(kThreads), 0, stream, alpha, blk_first, seg_row, seg_begin, vptr, ci, v, x, ys, y, cold);
+  else
+    hipLaunchKernelGGL(segment_tile_kernel<false>, dim3(nblocks), dim3(kThreads), 0, stream, alpha, blk_first, seg_row, seg_begin, vptr, ci, v, x, ys, y, cold);
 }
 void launch_segment_cut_list(hipStream_t stream, const int *cnt_s, const int *pos, int m, int piece_max, int *counter, int *cut) {
   if (m <= 0) return;

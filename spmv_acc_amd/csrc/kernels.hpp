@@ -50,7 +50,7 @@ void launch_segment_cost(hipStream_t stream, int entries, int *seg_len, int *cos
 int segment_block_count(long long total_cost);
 void launch_segment_blocks(hipStream_t stream, int entries, int nblocks, const int *cptr, int *blk_first); // blk_first: nblocks + 1
 void launch_segment_tiles(hipStream_t stream, int nblocks, double alpha, const int *blk_first, const int *seg_row, const int *seg_begin,
-                          const int *vptr, const int *ci, const double *v, const double *x, double *ys, double *y);
+                          const int *vptr, const int *ci, const double *v, const double *x, double *ys, double *y, const unsigned char *cold = nullptr);
 void launch_segment_merge(hipStream_t stream, int ncut, const int *cut, int entries, const int *seg_row, const double *ys, double *y);
 // opt-in full check (k_guard.hip, tunable guard_full): one partial digest of rowptr[0 .. m] per workgroup into part[0 .. parts);
 // then ONE workgroup adds them up and either writes the digest to digest_out (plan build) or compares it with `expected` and raises `stale`

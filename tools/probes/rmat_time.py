@@ -2,7 +2,7 @@ import sys, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 import spmv_acc_amd
 from spmv_acc_amd import synth
-for scale in (25, 26):
+for scale in (24, 25, 26):
     m, n, nnz, rp, ci, v = synth.rmat_torch(scale, device="cuda", seed=0xC4)
     x = torch.rand(n, device="cuda", dtype=torch.float64) * 2 - 1
     y0 = torch.rand(m, device="cuda", dtype=torch.float64)
