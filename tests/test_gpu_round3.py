@@ -1026,6 +1026,38 @@ def test_slab_planes_never_exceed_what_the_count_kernels_hold(torch_dev, oracle,
         spmv_acc_amd.release_plans()
 
 
+@pytest.mark.parametrize("deterministic", [1, 0])
+def test_whole_row_pass_with_gather_hints(torch_dev, oracle, hiplib, deterministic):
+    """Round 4: the whole-row pass of the slab lists (rows below slab_whole_below) takes the plan's gather hints -- cold gathers through the raw-buffer
+    non-temporal path -- where a timing of that pass alone says they pay (on an x far larger than the caches: R-MAT 25 1.14 -> 1.02 ms).  At test
+    size nothing pays, so `gather_hint = 1` builds the hints whatever n is and `deterministic` takes the rule (hinted) instead of the timing; without
+    it the timed choice runs, whichever way it falls.  Same sums either way, to the oracle's tolerance, for in-place and out-of-place calls."""
+    torch = torch_dev
+    m, n = 60000, 200000
+    rowptr, cols, vals = synth.random_csr(m, n, 9, seed=33, kind="powerlaw")
+    cols, vals = _sorted_rows(rowptr, cols, vals)
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(12)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    try:
+        for k, val in (("slab_segments", 4), ("gather_hint", 1), ("deterministic", deterministic)):
+            assert hiplib.spmv_acc_set_tunable(k.encode(), val) == 0
+        for alpha, beta in ((1.0, 1.0), (-0.5, 0.0), (2.0, 3.0)):
+            ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+            y = dy0.clone()
+            spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y, strategy="line_enhance")
+            y_in, y_out = dy0.clone(), torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+            spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y_out, strategy="line_enhance", y_in=y_in)
+            torch.cuda.synchronize()
+            assert oracle.scaled_error(y.cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL, (alpha, beta)
+            assert oracle.scaled_error(y_out.cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL, (alpha, beta, "out of place")
+        assert spmv_acc_amd.query_plan(drp, m)["slab_passes"] == 4
+    finally:
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans()
+
+
 def test_slab_segments_replay_from_a_graph_and_are_bitwise_stable(torch_dev, oracle, hiplib):
     """The passes are ordinary launches over plan-resident lists: captured after one warm-up call they replay, and two runs give the
     same bits (whole runs add straight into y, the pieces of a long run are added in entry order by one thread: no atomics)."""

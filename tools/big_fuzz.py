@@ -108,7 +108,9 @@ for case in range(cases):
                 ("adaptive", {"calls": 5}), ("flat", {"calls": 5}), ("adaptive_plus", {"calls": 4}), ("line_enhance", {"calls": 3, "oop": 1}),
                 ("adaptive", {"first_call_budget": 0}), ("adaptive", {"first_call_budget": 1, "later_call_budget": 1, "calls": 6}),
                 ("line_enhance", {"slab_segments": 8, "slab_whole_below": 0}), ("adaptive", {"slab_segments": 4, "slab_whole_below": 1 << 30}),
-                ("flat", {"slab_segments": 3, "slab_whole_below": 5, "calls": 2})]
+                ("flat", {"slab_segments": 3, "slab_whole_below": 5, "calls": 2}),
+                # ... and the whole-row pass with the plan's gather hints (built whatever n is; the rule takes them, the timing may or may not)
+                ("line_enhance", {"slab_segments": 8, "gather_hint": 1, "deterministic": 1}), ("adaptive", {"slab_segments": 5, "gather_hint": 1, "calls": 2})]
     for strat, knobs in [(s_, dict(k_, call=c_)) for s_, k_ in variants for c_ in range(k_.get("calls", 1))]:
         lib.spmv_acc_reset_tunables()
         oop = bool(knobs.get("oop"))
