@@ -68,7 +68,7 @@ def slab_passes(path):
         return None
     spmvs = rows[checks[0]][0]
     total = sum(n * kb for k, (n, kb) in rows.items() if any(s in k for s in ("segment_tile", "segment_merge", "guard_check", "scale_y")))
-    return (f"{tiles[0]} x {rows[tiles[0]][0] // spmvs} passes per SpMV (+ merge)", spmvs, total / spmvs)
+    return (f"spmv_acc::segment_tile_kernel x {sum(rows[k][0] for k in tiles) // spmvs} passes per SpMV (+ merge)", spmvs, total / spmvs)
 f, w = dominant(f"{out}/pmc_FETCH_SIZE.summary.txt"), dominant(f"{out}/pmc_WRITE_SIZE.summary.txt")
 sf, sw = slab_passes(f"{out}/pmc_FETCH_SIZE.summary.txt"), slab_passes(f"{out}/pmc_WRITE_SIZE.summary.txt")
 if sf and sw:
