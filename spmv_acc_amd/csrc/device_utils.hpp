@@ -87,6 +87,11 @@ template <bool NT> __device__ __forceinline__ double2v load_stream_d2(const doub
 // into one plain load of a selected address; buffer loads carry the policy as an immediate operand of the builtin, so the two
 // calls stay two instructions (same destination register, complementary lanes, one wait at the first use).  Byte offsets are
 // 32 bits: the engine uses hints only where x is below 4 GB; out-of-range offsets read 0 instead of faulting.
+// (the cold gathers' cache policy is a build-time constant: an immediate operand.  1 = sc0, 2 = nt, 16 = sc1 and their sums exist for A/B builds --
+// make EXTRA=-DSPMV_ACC_COLD_AUX=17 OBJ_DIR=build_exp OUT_DIR=../lib_exp, tools/probes/far_gather_policy_ab.py)
+#ifndef SPMV_ACC_COLD_AUX
+#define SPMV_ACC_COLD_AUX 2
+#endif
 struct XGather {
   __amdgpu_buffer_rsrc_t rsrc;
 };
@@ -100,7 +105,7 @@ __device__ __forceinline__ double gather_hinted(const XGather &g, int col, unsig
   typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
   uint2v r;
   const int off = col << 3;
-  if (cold) r = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, off, 0, 2); // aux 2: nt
+  if (cold) r = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, off, 0, SPMV_ACC_COLD_AUX); // aux 2: nt
   else r = __builtin_amdgcn_raw_buffer_load_b64(g.rsrc, off, 0, 0);
   return __hiloint2double(static_cast<int>(r.y), static_cast<int>(r.x));
 }

@@ -81,7 +81,14 @@ __global__ __launch_bounds__(256) void hint_bits_kernel(const int *__restrict__ 
     for (int e = 0; e < 8; ++e) {
       if (j0 + e < nnz) {
         const int c = ci[j0 + e];
+#ifdef SPMV_ACC_HINT_BY_POSITION // A/B builds only: cold = a column far (> 4096) from both its neighbours in the stream, whatever its popularity
+        const long long j = j0 + e;
+        const int before = j > 0 ? ci[j - 1] : c, after = j + 1 < nnz ? ci[j + 1] : c;
+        const bool cold = (c < 0 || c >= ncols) || ((c > before ? c - before : before - c) > 4096 && (c > after ? c - after : after - c) > 4096);
+        (void)counts; (void)threshold;
+#else
         const bool cold = (c < 0 || c >= ncols) ? true : counts[c >> kHintLineShift] < threshold;
+#endif
         byte |= cold ? (1u << e) : 0u;
       }
     }
