@@ -295,6 +295,9 @@ void spmv_acc_set_stream(void *hip_stream); /* hipStream_t; NULL = the NULL stre
                                              * one, the first such launch prints a one-time note on stderr (SPMV_ACC_QUIET=1: none).
                                              * A plan remembers the stream of its latest call to order a call on another stream behind
                                              * it: before destroying a stream, synchronise it or release the plans used on it.
+                                             * Captured graphs bypass that ordering: a plan owns scratch its kernels write (flat's
+                                             * carries, the slab passes' partial sums, LIGHT's row counter), so two graphs that hold
+                                             * SpMVs of ONE matrix must not be replayed concurrently on two streams.
                                              * The first call on a matrix spends at most ~20 SpMV-equivalents on per-matrix timings
                                              * (tunable first_call_budget) and the following calls finish them; until they have, two
                                              * calls may run different kernels, i.e. sum in a different order -- spmv_acc_prepare
