@@ -341,6 +341,12 @@ int spmv_acc_time_spmv_events(int strategy, int iters, double alpha, double beta
 int spmv_acc_time_spmv_total(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
                              const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
                              const double *dx, double *dy, float *total_ms_out);
+/* The same region and NOTHING else (round 5): no plan work -- the caller settles the plan first (spmv_acc_prepare_beta) --, no allocation, the
+ * event pair is made once per host thread.  A wall clock around this call, between two device synchronisations, reads the K launches' own time
+ * (bench.py's `value` / `ms_per_step`: median over repeated regions, the reference's median rule, benchmark/utils/benchmark_time.cpp:23-43). */
+int spmv_acc_time_spmv_region(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
+                              const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
+                              const double *dx, double *dy, float *total_ms_out);
 /* Streaming-copy ceiling (GB/s, read + write bytes) with the kernels' 16-B non-temporal access shape;
  * replaces: the WITH_MEM_BANDWIDTH macros of src/acc/common/mem_bandwidth.hpp:13-38 as the yardstick. */
 double spmv_acc_copy_ceiling_gbs(void *d_dst, const void *d_src, long long bytes, int reps);

@@ -39,7 +39,7 @@ C_ABI_SYMBOLS = (
     "spmv_acc_last_prepare_us", "spmv_acc_sharded_spmv", "spmv_acc_shard_prepare", "spmv_acc_csr_spmv_chunks", "spmv_acc_query_plan_settled", "spmv_acc_csr_spmv_oop", "spmv_acc_check_plans",
     "spmv_acc_query_plan_beta0", "spmv_acc_query_plan_slab_passes", "spmv_acc_shard_create", "spmv_acc_shard_step", "spmv_acc_shard_pipeline",
     "spmv_acc_shard_destroy", "spmv_acc_rccl_comm_init_all", "spmv_acc_rccl_comm_destroy", "spmv_acc_set_tune_cache",
-    "spmv_acc_prepare_beta", "spmv_acc_time_spmv_events", "spmv_acc_refresh_values",
+    "spmv_acc_prepare_beta", "spmv_acc_time_spmv_events", "spmv_acc_refresh_values", "spmv_acc_time_spmv_region",
 )
 
 _lib = None
@@ -106,6 +106,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_get_tunable.argtypes = [ctypes.c_char_p]
     lib.spmv_acc_reset_tunables.restype = None
     lib.spmv_acc_time_spmv_total.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+    lib.spmv_acc_time_spmv_region.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.spmv_acc_copy_ceiling_gbs.argtypes = [vp, vp, ctypes.c_longlong, ci]
     lib.spmv_acc_copy_ceiling_gbs.restype = cd
     lib.spmv_acc_last_prepare_us.restype = cd
@@ -339,6 +340,26 @@ def time_spmv_total(strategy, iters: int, alpha: float, beta: float, m: int, n: 
     if rc != 0:
         raise SpmvAccError(f"time_spmv_total failed ({rc}): {lib.spmv_acc_last_error_string().decode()}")
     return float(out.value)
+
+
+def time_spmv_region(strategy, iters: int, alpha: float, beta: float, m: int, n: int, nnz: int, rowptr, colindex, value, x, y):
+    """`iters` back-to-back SpMVs between ONE hipEvent pair and nothing else (no plan work, no allocation: settle the plan with prepare() first).
+    Returns a closure: each call runs one region and returns its total milliseconds -- argument checking and pointer conversion happen HERE, once,
+    so that a wall clock around the closure reads the region itself."""
+    lib = load_library()
+    _csr_args(lib, m, n, nnz, rowptr, colindex, value, x, y)
+    out = ctypes.c_float(0.0)
+    args = (strategy_id(strategy), iters, alpha, beta, m, n, nnz, None, _ptr(rowptr), _ptr(colindex), _ptr(value), _ptr(x), _ptr(y),
+            ctypes.addressof(out))
+    fn = lib.spmv_acc_time_spmv_region
+
+    def run() -> float:
+        rc = fn(*args)
+        if rc != 0:
+            raise SpmvAccError(f"time_spmv_region failed ({rc}): {lib.spmv_acc_last_error_string().decode()}")
+        return float(out.value)
+
+    return run
 
 
 def copy_ceiling_gbs(dst, src, reps: int = 5) -> float:

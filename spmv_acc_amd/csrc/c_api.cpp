@@ -38,7 +38,8 @@ struct PinTable {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p), lo = a & ~(kPage - 1), hi = (a + bytes + kPage - 1) & ~(kPage - 1);
     std::lock_guard<std::mutex> lk(mu);
     for (auto &r : ranges) {
-      if (r.lo == a && hi <= ((r.hi + kPage - 1) & ~(kPage - 1))) { // the same array (or a prefix of it): share
+      if (r.lo == a && a + bytes <= r.hi) { // the same array or a true prefix of it: every byte was passed to hipHostRegister -- share
+        // (round 5: a longer request that merely ends inside the registration's last PAGE is not shared; it falls to the bounce buffers below)
         ++r.refs;
         return true;
       }
@@ -532,6 +533,39 @@ int spmv_acc_time_spmv_total(int strategy, int iters, double alpha, double beta,
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (rc != kOk) set_error(kErrHip, "spmv_acc_time_spmv_total: HIP failure while timing");
+  if (rc == kOk && last_error() != kOk) rc = last_error();
+  return rc;
+}
+
+// One timed REGION and nothing else (round 5; bench.py's `value`): `iters` back-to-back launches between one event pair -- no plan work (the caller
+// has settled the plan: spmv_acc_prepare), no allocation, no event creation (one event pair per host thread, made on first use) -- so that a
+// wall clock around this call, bracketed by device synchronisations, reads the launches' own time.  (spmv_acc_time_spmv_total settles the plan
+// itself, i.e. allocates and frees a scratch y inside the call: 0.4 ms of host time, 14 % of a 20-launch region on the headline matrix.)
+int spmv_acc_time_spmv_region(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
+                              const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
+                              const double *dx, double *dy, float *total_ms_out) {
+  if (iters <= 0 || !total_ms_out) {
+    set_error(kErrBadArgument, "spmv_acc_time_spmv_region: bad argument");
+    return kErrBadArgument;
+  }
+  thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+  thread_local int ev_device = -1;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || ((!ev[0] || ev_device != dev) &&
+                                           (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess))) {
+    set_error(kErrHip, "spmv_acc_time_spmv_region: hipEventCreate failed");
+    return kErrHip;
+  }
+  ev_device = dev;
+  hipStream_t st = get_stream();
+  clear_error();
+  (void)hipEventRecord(ev[0], st);
+  for (int i = 0; i < iters; ++i)
+    run_spmv(strategy, 0, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy);
+  (void)hipEventRecord(ev[1], st);
+  int rc = kOk;
+  if (hipEventSynchronize(ev[1]) != hipSuccess || hipEventElapsedTime(total_ms_out, ev[0], ev[1]) != hipSuccess) rc = kErrHip;
+  if (rc != kOk) set_error(kErrHip, "spmv_acc_time_spmv_region: HIP failure while timing");
   if (rc == kOk && last_error() != kOk) rc = last_error();
   return rc;
 }

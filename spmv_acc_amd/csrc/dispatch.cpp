@@ -38,12 +38,12 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
       !tun(kT_rescue_flat) && !t_coarse_tuning) {
     if (rb_mode > 0) {
       int vec = 1, rpb = kThreads;
-      pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
+      pick_rowblock_shape(p.A.m, p.A.count(), tun(kT_rowblock_target), &vec, &rpb);
       if (t_capturing ? (p.rowblock_ok == 1 && p.rowblock_rpb == rpb) : (probe_rowblock(p, rpb, st) && p.rowblock_ok == 1))
         return run_rowblock(st, p, nullptr, alpha, beta, x, y, false, 0);
     } else if (p.flat_rowblock_choice < 0 && !t_capturing && !by_rule()) {
       int vec = 1, rpb = kThreads;
-      pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
+      pick_rowblock_shape(p.A.m, p.A.count(), tun(kT_rowblock_target), &vec, &rpb);
       if (!probe_rowblock(p, rpb, st)) return false;
       p.flat_rowblock_choice = 0;
       if (p.rowblock_ok == 1) {
@@ -137,7 +137,7 @@ bool probe_rowblock(Plan &p, int rpb, hipStream_t st) {
   bool ok = hip_ok(hipMemsetAsync(d_max, 0, 2 * sizeof(int), st), "memset probe");
   if (ok) {
     const long long nblocks = (static_cast<long long>(p.A.m) + rpb - 1) / rpb;
-    const long long avg_block = nblocks > 0 ? p.A.nnz / nblocks : 0;
+    const long long avg_block = nblocks > 0 ? p.A.count() / nblocks : 0;
     launch_max_block_nnz(st, p.A.rp, p.A.m, rpb, static_cast<int>(avg_block), d_max);
     int h[2] = {0, 0};
     ok = hip_ok(hipMemcpyAsync(h, d_max, 2 * sizeof(int), hipMemcpyDeviceToHost, st), "read probe") &&
@@ -188,7 +188,7 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
 bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y,
                   bool allow_uneven_switch, int lanes_per_row) {
   int vec = 1, rpb = kThreads;
-  pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
+  pick_rowblock_shape(p.A.m, p.A.count(), tun(kT_rowblock_target), &vec, &rpb);
   // (THREAD_ROW: one lane per row whatever the row length, the rows per workgroup still from the tile target)
   if (lanes_per_row > 0) vec = lanes_per_row;
   const int forced = tun(kT_rowblock_vec);
@@ -213,7 +213,7 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
   const int want_lens = tun(kT_rowlen);
   // (auto: rows of <= 8 non-zeros on average, where rowptr is >= 3.5 % of the traffic; measured at 12.6 per row the scan costs
   // more than the bytes save -- largebasis-sized 17.8 vs 17.4 us)
-  if (want_lens > 0 || (want_lens < 0 && static_cast<long long>(p.A.nnz) <= 8LL * p.A.m)) {
+  if (want_lens > 0 || (want_lens < 0 && static_cast<long long>(p.A.count()) <= 8LL * p.A.m)) {
     // (inside a capture a digest that does not exist yet is simply not used: the kernel reads rowptr, same result)
     const bool have = p.digest.lens && p.digest.rpb == rpb;
     if (have || !t_capturing) {
@@ -223,9 +223,9 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
   }
   // blocks at each end of the grid whose streams stay cacheable (tunable cache_ends_mb; 12 B per non-zero of stream)
   int cache_ends = 0;
-  if (tun(kT_cache_ends_mb) > 0 && tun(kT_zigzag) && p.A.nnz > 0) {
+  if (tun(kT_cache_ends_mb) > 0 && tun(kT_zigzag) && p.A.count() > 0) {
     const long long nblocks = (static_cast<long long>(p.A.m) + rpb - 1) / rpb;
-    const double bytes_per_block = 12.0 * p.A.nnz / static_cast<double>(nblocks);
+    const double bytes_per_block = 12.0 * p.A.count() / static_cast<double>(nblocks);
     cache_ends = static_cast<int>(tun(kT_cache_ends_mb) * 1048576.0 / bytes_per_block);
   }
   const int chunk = tun(kT_xcd_chunk);
@@ -264,7 +264,7 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
     // by rule, and a pure function of the matrix whatever was called on it before: the balance probe of the row-block shape
     // decides (hub rows: the reference's 1024, the block size that wins on power-law matrices; else 1536)
     int vec = 1, rpb = kThreads;
-    pick_rowblock_shape(p.A.m, p.A.nnz, tun(kT_rowblock_target), &vec, &rpb);
+    pick_rowblock_shape(p.A.m, p.A.count(), tun(kT_rowblock_target), &vec, &rpb);
     return probe_rowblock(p, rpb, st) && ensure_plus(p, h_rowptr, st, p.rowblock_ok == 0 ? kPlusMinNnz : 1536);
   }
   if (p.plus_tuned_min > 0) return ensure_plus(p, h_rowptr, st, p.plus_tuned_min) && autotune_policy(p, kFamPlus, st, launch);
@@ -371,7 +371,7 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
     const int S_auto = seg_auto_slabs(p.A.n);
     if (p.seg_state < 0) {
       size_t free_b = 0, total_b = 0;
-      const size_t build_bytes = (2 * static_cast<size_t>(S_auto) + 4) * (static_cast<size_t>(p.A.m) + 1) * sizeof(int) + (static_cast<size_t>(p.A.nnz) / 4) * 12;
+      const size_t build_bytes = (2 * static_cast<size_t>(S_auto) + 4) * (static_cast<size_t>(p.A.m) + 1) * sizeof(int) + (static_cast<size_t>(p.A.count()) / 4) * 12;
       const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 2 * build_bytes;
       (void)hipGetLastError();
       if (room && last_error_code_only() == kOk && !ensure_segments(p, S_auto, st)) {
@@ -702,7 +702,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   } yin_scope{p->A};
   p->A.yin = beta != 0.0 ? dy_in : nullptr;
 
-  if (p->A.nnz == 0) {
+  if (p->A.count() == 0) {
     launch_scale_y(st, m, beta, dy, p->A.yin);
     return;
   }
@@ -757,7 +757,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     return;
   }
 
-  const long long avg = static_cast<long long>(p->A.nnz) / m;
+  const long long avg = static_cast<long long>(p->A.count()) / m;
   // a resident grid for the two persistent-style legacy kernels: CUs x 8 workgroups of 4 waves
   auto resident_blocks = [&]() {
     int cus = 0;
@@ -799,7 +799,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
       run_plus(st, *p, h_rowptr, alpha, beta, dx, dy);
     } else if (tile_form && p->rowblock_ok != 0) {
       // the reference's lane width per row (vector_row.cpp:15-27) on the tile machinery
-      const double a = static_cast<double>(p->A.nnz) / m;
+      const double a = static_cast<double>(p->A.count()) / m;
       auto launch = [&](int pol, double al, double be, double *yy) {
         launch_vector_tile(st, p->A, m, w, w, a, a, tun(kT_vector_target), tun(kT_xcd_chunk), pol, al, be, dx, yy,
                            next_reverse(*p));

@@ -118,7 +118,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
 
 // Drop cached plans (all, or those keyed on this rowptr).  Call when a matrix' structure changes in
 // place or its buffers are freed.
-void release_plans(const int *d_rowptr);
+void release_plans(const int *d_rowptr, int m_only = -1);
 
 // Introspection for tests / benchmarks.
 struct PlanInfo {

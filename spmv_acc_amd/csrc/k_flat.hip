@@ -25,11 +25,13 @@ namespace {
 using namespace dev;
 
 // ---- preprocessing: break points -------------------------------------------------------------------
-__global__ __launch_bounds__(256) void break_points_kernel(const int *__restrict__ rp, int m, int nnz, int stride,
+// tile0 (round 5): the table starts at absolute tile `tile0` (an un-rebased row sub-range whose first non-zero lies there): bp[j] is the break
+// point of tile j + tile0; entry 0 stays 0 (row 0 of the view) like the reference's bp[0].
+__global__ __launch_bounds__(256) void break_points_kernel(const int *__restrict__ rp, int m, int nnz, int stride, int tile0,
                                                            int *__restrict__ bp, int bp_len) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= bp_len) return;
-  const long long target = static_cast<long long>(j) * stride;
+  const long long target = (static_cast<long long>(j) + tile0) * stride;
   int out = 0;
   if (j > 0 && target <= nnz) {
     // p = first index in [0, m] with rp[p] >= target   (rp[0] = 0 < target <= rp[m])
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
                                                              const double *__restrict__ x, double *y, const double *yin,
                                                              double *__restrict__ head, double *__restrict__ tail,
                                                              int *__restrict__ tail_row, int *__restrict__ tail_end,
-                                                             int xcd_chunk, int reach,
+                                                             int xcd_chunk, int reach, int tile0,
                                                              const int *__restrict__ guard, int *__restrict__ stale,
                                                              Col16Dev c16, int reverse, int cache_ends,
                                                              const int4v *__restrict__ dig, const unsigned char *__restrict__ cold) {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
   }
   int t = reverse ? zigzag_block(blockIdx.x, ntiles) : static_cast<int>(blockIdx.x); // every other SpMV walks the tiles backwards
   if (xcd_chunk > 0) t = xcd_chunked_block(t, ntiles, xcd_chunk);
-  const int t0 = t * STRIDE; // host guarantees nnz + stride fits in int
+  const int t0 = (t + tile0) * STRIDE; // host guarantees nnz + stride fits in int
   const int t1 = (nnz - t0 > STRIDE) ? t0 + STRIDE : nnz;
 
   // EARLY (chosen by timing on small grids, tuner.cpp): the tile's stream loads go out before anything else, so the
@@ -301,10 +303,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
 // Plan time, one thread per tile: the tile's digest {first row, end row (exclusive), rowptr[end - 1], rowptr[end]} (zeros for
 // the extents of a tile that owns no rows).
 __global__ __launch_bounds__(256) void flat_digest_kernel(const int *__restrict__ rp, const int *__restrict__ bp, int ntiles, int m,
-                                                          int nnz, int stride, int4v *__restrict__ dig) {
+                                                          int nnz, int stride, int tile0, int4v *__restrict__ dig) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= ntiles) return;
-  const int t0 = t * stride;
+  const int t0 = (t + tile0) * stride;
   const int t1 = (nnz - t0 > stride) ? t0 + stride : nnz;
   int first = bp[t];
   first = first < m ? first : m;
@@ -321,11 +323,11 @@ __global__ __launch_bounds__(256) void flat_digest_kernel(const int *__restrict_
 // starts in (only then does the fix-up kernel have anything to fold);  flag[1] = the largest number of rows any tile owns
 // (a tile is one workgroup: tens of thousands of -- mostly empty -- rows in one tile serialise there).
 __global__ __launch_bounds__(256) void flat_needs_fixup_kernel(const int *__restrict__ rp, const int *__restrict__ bp,
-                                                               int ntiles, int m, int nnz, int stride,
+                                                               int ntiles, int m, int nnz, int stride, int tile0,
                                                                int *__restrict__ flag) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= ntiles) return;
-  const int t0 = t * stride;
+  const int t0 = (t + tile0) * stride;
   const int t1 = (nnz - t0 > stride) ? t0 + stride : nnz;
   int first = bp[t];
   first = first < m ? first : m;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256) void flat_needs_fixup_kernel(const int *__rest
 // One thread per tile that holds the START of a cut row: adds its tail carry and the head carries of
 // the following tiles in tile order, then applies alpha/beta once.  Everything it needs was written by
 // the tile kernel, so the dependent-load chain is one level deep.
-__global__ __launch_bounds__(256) void flat_fixup_kernel(int ntiles, int stride, double alpha, double beta,
+__global__ __launch_bounds__(256) void flat_fixup_kernel(int ntiles, int stride, int tile0, double alpha, double beta,
                                                          const double *__restrict__ head,
                                                          const double *__restrict__ tail,
                                                          const int *__restrict__ tail_row,
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void flat_fixup_kernel(int ntiles, int stride,
   if (r >= 0) {
     const long long b = tail_end[t];
     k0 = t + 1;                                            // heads of the tiles the row runs through:
-    k1 = static_cast<int>((b + stride - 1) / stride);      // ... up to the tile that holds its last non-zero
+    k1 = static_cast<int>((b + stride - 1) / stride) - tile0; // ... up to the tile that holds its last non-zero
     k1 = k1 < ntiles ? k1 : ntiles;
     s = tail[t];
   }
@@ -364,10 +366,13 @@ __global__ __launch_bounds__(256) void flat_fixup_kernel(int ntiles, int stride,
 
 } // namespace
 
-void launch_break_points(hipStream_t stream, const int *rp, int m, int nnz, int stride, int *bp, int bp_len) {
+void launch_break_points_from(hipStream_t stream, const int *rp, int m, int nnz, int stride, int tile0, int *bp, int bp_len) {
   if (bp_len <= 0) return;
-  hipLaunchKernelGGL(break_points_kernel, dim3((bp_len + 255) / 256), dim3(256), 0, stream, rp, m, nnz, stride, bp,
+  hipLaunchKernelGGL(break_points_kernel, dim3((bp_len + 255) / 256), dim3(256), 0, stream, rp, m, nnz, stride, tile0, bp,
                      bp_len);
+}
+void launch_break_points(hipStream_t stream, const int *rp, int m, int nnz, int stride, int *bp, int bp_len) {
+  launch_break_points_from(stream, rp, m, nnz, stride, 0, bp, bp_len);
 }
 
 namespace {
@@ -378,11 +383,11 @@ void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P,
   if (P.early_stream)
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
   else
     hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
 }
 // the segmented-scan reduction (reference option FLAT_SEGMENT_SUM_REDUCE): 2048-non-zero tiles, values / colindex under the plan's policy
 template <bool NTC, bool NTV>
@@ -391,7 +396,7 @@ void launch_flat_segsum(hipStream_t stream, const CsrDev &A, const FlatPlan &P, 
   const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
-                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
                      static_cast<const int4v *>(P.digest), nullptr);
 }
 // gather hints: 2048-non-zero tiles, break-point chain first
@@ -400,7 +405,7 @@ void launch_flat_hint(hipStream_t stream, const CsrDev &A, const FlatPlan &P, do
   const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
-                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
                      static_cast<const int4v *>(P.digest), A.cold);
 }
 // opt-in 16-bit columns: NPT 8 tiles (a multiple of the 256-non-zero chunk), values under the plan's cache policy
@@ -410,7 +415,7 @@ void launch_flat_col16(hipStream_t stream, const CsrDev &A, const FlatPlan &P, d
   const Col16Dev c = {P.col16->d16, P.col16->base, P.col16->esc_start, P.col16->esc_cols};
   hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, true, NTV, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
-                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, A.guard, A.stale, c, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, c, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
 }
 template <int NPT>
 void launch_flat_policy(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
@@ -427,13 +432,13 @@ void launch_flat_policy(hipStream_t stream, const CsrDev &A, const FlatPlan &P, 
 void launch_flat_digest(hipStream_t stream, const CsrDev &A, const FlatPlan &P) {
   if (P.ntiles <= 0) return;
   hipLaunchKernelGGL(flat_digest_kernel, dim3((P.ntiles + 255) / 256), dim3(256), 0, stream, A.rp, P.bp, P.ntiles, A.m, A.nnz, P.stride,
-                     static_cast<int4v *>(P.digest));
+                     P.tile0, static_cast<int4v *>(P.digest));
 }
 
 void launch_flat_needs_fixup(hipStream_t stream, const CsrDev &A, const FlatPlan &P, int *d_flag) {
   if (P.ntiles <= 0) return;
   hipLaunchKernelGGL(flat_needs_fixup_kernel, dim3((P.ntiles + 255) / 256), dim3(256), 0, stream, A.rp, P.bp, P.ntiles,
-                     A.m, A.nnz, P.stride, d_flag);
+                     A.m, A.nnz, P.stride, P.tile0, d_flag);
 }
 
 void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
@@ -463,7 +468,7 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
   else launch_flat_policy<8>(stream, A, P, alpha, beta, x, y);
   if (P.ntiles > 1 && P.needs_fixup) {
     hipLaunchKernelGGL(flat_fixup_kernel, dim3((P.ntiles - 1 + 255) / 256), dim3(256), 0, stream, P.ntiles, P.stride,
-                       alpha, beta, P.head, P.tail, P.tail_row, P.tail_end, y, A.yin ? A.yin : y);
+                       P.tile0, alpha, beta, P.head, P.tail, P.tail_row, P.tail_end, y, A.yin ? A.yin : y);
   }
 }
 

@@ -11,7 +11,9 @@ namespace spmv_acc {
 struct CsrDev {
   int m = 0;
   int n = 0;
-  int nnz = 0;
+  int nnz = 0;  // END offset of the view's non-zeros in ci / v: rowptr[m] (the non-zero COUNT only where rowptr[0] == 0)
+  int nnz0 = 0; // rowptr[0]: 0 for a whole matrix, the first non-zero of an un-rebased row sub-range (shard.cpp's chunk views, `rowptr + r0`)
+  int count() const { return nnz - nnz0; } // what every shape heuristic, tile range, census and budget reads (round 5; they read nnz until then)
   const int *rp = nullptr;
   const int *ci = nullptr;
   const double *v = nullptr;
@@ -160,6 +162,8 @@ void launch_col16_encode(hipStream_t stream, const int *ci, int nnz, int nchunks
 struct FlatPlan {
   int stride = 0;
   int ntiles = 0;
+  int tile0 = 0;            // the plan's first tile in absolute tile numbering: A.nnz0 / stride (0 unless the matrix is an un-rebased row sub-range);
+                            // tile t of the plan covers non-zeros [(t + tile0) * stride, ...): every per-tile table is indexed by t, only tile origins add it
   int *bp = nullptr;        // ntiles + 1 break points (reference semantics)
   double *head = nullptr;   // per tile: partial sum of the row that started in an earlier tile
   double *tail = nullptr;   // per tile: partial sum of the row that continues in the next tile
@@ -188,6 +192,7 @@ struct FlatPlan {
 // (by the finishing tile and by the next one), so the reach is kept small: <= 6% of a tile.  Measured with a reach of
 // 2048 the TSOPF-like matrix (424 nnz/row) lost 15%: ~10% extra traffic plus a serial tail per block.
 constexpr int kFlatFinish = 128;
+void launch_break_points_from(hipStream_t stream, const int *rp, int m, int nnz, int stride, int tile0, int *bp, int bp_len); // bp[j] for absolute tile j + tile0
 void launch_flat_digest(hipStream_t stream, const CsrDev &A, const FlatPlan &P); // after launch_break_points
 void launch_flat_needs_fixup(hipStream_t stream, const CsrDev &A, const FlatPlan &P, int *d_flag); // d_flag[2] pre-zeroed
 void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,

@@ -172,8 +172,11 @@ TuneRecord tune_snapshot(const Plan &p) {
   int k = 0;
   for (int f = 0; f < kFamilyCount; ++f)
     for (int c = 0; c < 2; ++c) r.v[k++] = p.stream_policy[f][c];
-  r.v[k++] = p.adaptive_family[0];
-  r.v[k++] = p.adaptive_family[1];
+  // a PROVISIONAL family (the best of the families timed so far under the call budget, dispatch.cpp::run_adaptive_timed) is not a choice yet:
+  // neither the flag nor the timings travel, so an adopting process would take it as final and never finish the comparison.  It is kept as
+  // "not timed" until the comparison is complete (a short process of one to three calls leaves nothing half-measured behind).
+  r.v[k++] = p.adaptive_provisional[0] ? -1 : p.adaptive_family[0];
+  r.v[k++] = p.adaptive_provisional[1] ? -1 : p.adaptive_family[1];
   r.v[k++] = p.flat_npt_choice;
   r.v[k++] = p.flat_early_choice ? 1 : 0;
   r.v[k++] = p.flat_geometry_tuned ? 1 : 0;
@@ -405,6 +408,15 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
   p->A.m = m;
   p->A.n = n;
   p->A.nnz = nnz;
+  {
+    // the view's first non-zero, rowptr[0] (round 5): 0 for a whole matrix; an un-rebased row sub-range (shard.cpp's chunk views) starts later, and
+    // `nnz` is then the END offset -- every shape heuristic reads A.count() = nnz - nnz0.  One 4-byte read per plan.
+    const int *hv = host_view(h_rowptr);
+    int first = 0;
+    if (hv) first = hv[0];
+    else if (!hip_ok(hipMemcpy(&first, rp, sizeof(int), hipMemcpyDeviceToHost), "read rowptr[0]")) return nullptr;
+    p->A.nnz0 = (first > 0 && first <= nnz) ? first : 0;
+  }
   p->A.rp = rp;
   p->A.ci = ci;
   p->A.v = v;
@@ -469,10 +481,12 @@ int check_plans() {
 }
 
 
-void release_plans(const int *d_rowptr) {
+// m_only >= 0: only the plans of that row count (a shard's chunk 0 is a view `rowptr + 0` of fewer rows: dropping it must not take the
+// caller's whole-shard plan on the same pointer with it)
+void release_plans(const int *d_rowptr, int m_only) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto it = g_plans.begin(); it != g_plans.end();) {
-    if (!d_rowptr || std::get<1>(it->first) == d_rowptr) {
+    if (!d_rowptr || (std::get<1>(it->first) == d_rowptr && (m_only < 0 || std::get<4>(it->first) == m_only))) {
       it = g_plans.erase(it);
     } else {
       ++it;
@@ -489,7 +503,7 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->nnz = p.A.nnz;
       out->adaptive_branch = p.have_samples ? adaptive_branch(m, p.samples) : 0;
       int rb_vec = 1, rb_rows = kThreads;
-      pick_rowblock_shape(m, p.A.nnz, tun(kT_rowblock_target), &rb_vec, &rb_rows);
+      pick_rowblock_shape(m, p.A.count(), tun(kT_rowblock_target), &rb_vec, &rb_rows);
       out->vec = rb_vec; // lanes per row of the row-block family for this matrix
       out->flat_tiles = p.flat_tiles;
       out->plus_blocks = p.plus_blocks;

@@ -181,7 +181,7 @@ int spmv_acc_shard_create(spmv_acc_shard_t *out, void *nccl_comm, int strategy, 
 int spmv_acc_shard_destroy(spmv_acc_shard_t S) {
   if (!S) return kOk;
   if (S->chunks.size() > 1)
-    for (auto &c : S->chunks) release_plans(c.rp); // (the chunk views' plans; the whole-shard plan, keyed on the caller's rowptr, is the caller's to release)
+    for (auto &c : S->chunks) release_plans(c.rp, c.b - c.a); // (the chunk views' plans, by (pointer, rows): chunk 0 shares its pointer with the whole-shard plan, which is the caller's to release)
   for (auto &q : S->chunk_stream)
     if (q) (void)hipStreamDestroy(q);
   for (auto &e : S->chunk_done)

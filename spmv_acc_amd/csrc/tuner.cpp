@@ -14,7 +14,10 @@ bool build_flat_plan(const CsrDev &A, int stride, hipStream_t stream, FlatPlan &
   ++t_plan_work;
   Plan::free_flat_plan(F);
   const int nnz = A.nnz;
-  const int tiles = nnz / stride + (nnz % stride ? 1 : 0);
+  // (round 5) an un-rebased row sub-range (rowptr[0] = A.nnz0 > 0) starts at tile A.nnz0 / stride: the tiles before it own no rows and are
+  // neither launched nor given table entries (chunk k of C used to launch up to C times the tiles it needed)
+  const int tile0 = A.nnz0 / stride;
+  const int tiles = nnz / stride + (nnz % stride ? 1 : 0) - tile0;
   const size_t n1 = static_cast<size_t>(tiles) + 1;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&F.bp), sizeof(int) * n1), "hipMalloc break points") ||
       !hip_ok(hipMalloc(reinterpret_cast<void **>(&F.head), sizeof(double) * n1), "hipMalloc head carries") ||
@@ -27,7 +30,8 @@ bool build_flat_plan(const CsrDev &A, int stride, hipStream_t stream, FlatPlan &
   }
   F.stride = stride;
   F.ntiles = tiles;
-  launch_break_points(stream, A.rp, A.m, nnz, stride, F.bp, static_cast<int>(n1));
+  F.tile0 = tile0;
+  launch_break_points_from(stream, A.rp, A.m, nnz, stride, tile0, F.bp, static_cast<int>(n1));
   launch_flat_digest(stream, A, F);
   // does this matrix need the carry fix-up kernel at all? (only rows longer than a tile's finishing reach do)
   int *d_flag = nullptr;
@@ -145,7 +149,7 @@ namespace detail {
 bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) {
   if (min_nnz < 256 || min_nnz > kTile) min_nnz = kPlusMinNnz;
   const int want_vec =
-      tun(kT_plus_ref_vec) ? plus_pick_vec(p.A.m, p.A.nnz) : plus_pick_vec_tuned(p.A.m, p.A.nnz, min_nnz);
+      tun(kT_plus_ref_vec) ? plus_pick_vec(p.A.m, p.A.count()) : plus_pick_vec_tuned(p.A.m, p.A.count(), min_nnz);
   if (p.plus_blocks >= 0 && p.plus_vec == want_vec && p.plus_min == min_nnz) return true;
   if (!plan_work_allowed("row-block analysis")) return false;
   ++t_plan_work;
@@ -221,7 +225,7 @@ int policy_for(const Plan &p, int fam) {
   if (forced >= 0) return forced & 3;
   // deterministic: the rule the timings follow on most matrices -- short rows (the vectors and rowptr are worth more cache than
   // the matrix) stream non-temporally, everything else with the default policy
-  if (tun(kT_deterministic)) return static_cast<long long>(p.A.nnz) <= 8LL * p.A.m ? kStreamPolicyNt : kStreamPolicyDefault;
+  if (tun(kT_deterministic)) return static_cast<long long>(p.A.count()) <= 8LL * p.A.m ? kStreamPolicyNt : kStreamPolicyDefault;
   const int c = t_beta_class;
   if (p.stream_policy[fam][c] >= 0) return p.stream_policy[fam][c];
   // not timed for this family in this class yet (adaptive's comparison of the families): the policy another family measured on
@@ -229,7 +233,7 @@ int policy_for(const Plan &p, int fam) {
   for (int f = 0; f < kFamilyCount; ++f)
     if (p.stream_policy[f][c] >= 0) return p.stream_policy[f][c];
   if (p.stream_policy[fam][c ^ 1] >= 0) return p.stream_policy[fam][c ^ 1];
-  return static_cast<long long>(p.A.nnz) <= 8LL * p.A.m ? kStreamPolicyNt : kStreamPolicyDefault; // (nothing measured yet: the rule)
+  return static_cast<long long>(p.A.count()) <= 8LL * p.A.m ? kStreamPolicyNt : kStreamPolicyDefault; // (nothing measured yet: the rule)
 }
 
 // While adaptive compares the families it runs each with its default sub-choices (flat: carries + fix-up unless pinned;
@@ -386,7 +390,7 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
     F.needs_fixup = F.mode_tuned[cls ^ 1] ? F.tuned_fixup[cls ^ 1] : false;
     return true;
   }
-  if (t_coarse_tuning && p.A.nnz >= kFlatSmallNnz) { // (small matrices: the timings are cheap and decide the comparison)
+  if (t_coarse_tuning && p.A.count() >= kFlatSmallNnz) { // (small matrices: the timings are cheap and decide the comparison)
     F.needs_fixup = true;
     return true;
   }
@@ -413,7 +417,7 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
 // the tile whenever that is legal (no second launch: what wins on short kernels).
 bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
   if (p.flat_geometry_tuned || tun(kT_col16) > 0 || flat_segment_sum() || t_capturing || by_rule()) return true;
-  if (p.A.nnz >= kFlatSmallNnz || p.flat.ntiles <= 1) {
+  if (p.A.count() >= kFlatSmallNnz || p.flat.ntiles <= 1) {
     p.flat_geometry_tuned = true;
     return true;
   }
@@ -479,7 +483,7 @@ bool ensure_hint(Plan &p, hipStream_t st) {
   p.hint_state = 0;
   const CsrDev &A = p.A;
   // hinted gathers address x by 32-bit byte offsets; a matrix whose x fits an L2 several times over has nothing to protect
-  if (mode == 0 || A.nnz < 8 || A.n <= 0 || static_cast<long long>(A.n) * 8 >= (1LL << 32)) return true;
+  if (mode == 0 || A.count() < 8 || A.n <= 0 || static_cast<long long>(A.n) * 8 >= (1LL << 32)) return true;
   // (and while x lives in the 256 MB Infinity Cache beside the rest of the working set a cold gather is a hit there, which a non-temporal
   // load forfeits: R-MAT scale 21 / 22 / 23, x = 16 / 32 / 64 MB: hinted 268 / 604 / 1343 us against 212 / 477 / 1250 plain; scale 24 / 25,
   // x = 128 / 256 MB: 3.03 / 7.2 ms against 3.38 / 8.2 -- the timed choice gets all five right, this bound just saves the census)
@@ -488,8 +492,9 @@ bool ensure_hint(Plan &p, hipStream_t st) {
   const auto census_t0 = std::chrono::steady_clock::now();
   const int nlines = (A.n + (1 << kHintLineShift) - 1) >> kHintLineShift;
   // (odd: an even stride on rows of one even length would sample the same position of every row -- with sorted rows always low columns)
-  const int stride = ((A.nnz + kHintSamples - 1) / kHintSamples) | 1;
-  const int samples = (A.nnz + stride - 1) / stride;
+  // (round 5: the census and the bits cover the view's own non-zeros [A.nnz0, A.nnz); the bitmap stays indexed by absolute position)
+  const int stride = ((A.count() + kHintSamples - 1) / kHintSamples) | 1;
+  const int samples = (A.count() + stride - 1) / stride;
   unsigned *counts = nullptr, *hist_lines = nullptr;
   unsigned long long *hist_hits = nullptr;
   std::vector<unsigned> h_lines(kHintBins);
@@ -513,7 +518,7 @@ bool ensure_hint(Plan &p, hipStream_t st) {
             hip_ok(hipMemsetAsync(hist_lines, 0, sizeof(unsigned) * kHintBins, st), "memset hint histogram") &&
             hip_ok(hipMemsetAsync(hist_hits, 0, sizeof(unsigned long long) * kHintBins, st), "memset hint histogram");
   if (ok) {
-    launch_hint_census(st, A.ci, A.nnz, A.n, stride, samples, counts);
+    launch_hint_census(st, A.ci + A.nnz0, A.count(), A.n, stride, samples, counts);
     launch_hint_hist(st, counts, nlines, hist_lines, hist_hits);
     ok = hip_ok(hipMemcpyAsync(h_lines.data(), hist_lines, sizeof(unsigned) * kHintBins, hipMemcpyDeviceToHost, st), "read hint histogram") &&
          hip_ok(hipMemcpyAsync(h_hits.data(), hist_hits, sizeof(unsigned long long) * kHintBins, hipMemcpyDeviceToHost, st), "read hint histogram") &&
@@ -549,7 +554,8 @@ bool ensure_hint(Plan &p, hipStream_t st) {
       const bool room = optional_alloc(reinterpret_cast<void **>(&p.d_cold), nbytes);
       ok = !room || hip_ok(hipMemsetAsync(p.d_cold, 0, nbytes, st), "memset hint bits");
       if (ok && room) {
-        launch_hint_bits(st, A.ci, A.nnz, A.n, counts, threshold, p.d_cold);
+        const int skip = A.nnz0 & ~7; // whole bitmap bytes before the view
+        launch_hint_bits(st, A.ci + skip, A.nnz - skip, A.n, counts, threshold, p.d_cold + skip / 8);
         ok = hip_ok(hipStreamSynchronize(st), "sync hint bits");
       }
       if (ok && room) p.hint_state = 1;
