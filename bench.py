@@ -13,7 +13,9 @@ the GPU -- the parent imports neither torch nor the library), relays rank 0's li
 Rank 0 prints ONE JSON line.
 
 value       = 2 * nnz_total * K / wall_seconds / 1e9  [GFLOP/s], wall-clock over exactly K back-to-back steps bracketed by
-              barrier + torch.cuda.synchronize() on both sides, max over ranks.
+              barrier + torch.cuda.synchronize() on both sides, max over ranks; the region is repeated REGION_REPS times inside the one
+              command and wall_seconds is the MEDIAN repetition (the reference reports medians, benchmark_time.cpp:23-43); the
+              event time of the same regions stands beside it (ms_per_step_events).
 roofline    = algorithmic bytes (12*nnz + 4*(m+1) + 8*n + 16*m) / launch duration under the REFERENCE HARNESS'S
               protocol (benchmark/csr_spmv.hpp:66-74, benchmark_time.cpp:23-43): y reset by a device copy before every launch,
               one hipEvent pair per launch on the stream the kernels run on, median.  The back-to-back mean (one event pair
@@ -35,6 +37,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+REGION_REPS = 7        # `value` / `ms_per_step`: median over this many repetitions of the K-step region (benchmark_time.cpp:23-43: the reference reports a median)
+T_START = time.perf_counter()
+
+
+def median_region(run, reps, sync_all, reduce_max=None):
+    """`reps` repetitions of ONE timed region -- `run()` = exactly K steps --, each bracketed by barrier + device synchronisation on both sides
+    (`sync_all`).  Returns (median wall seconds, the per-repetition wall seconds).  N > 1: `reduce_max` takes the MAX over ranks of every
+    repetition first, so that all ranks agree on the list and on its median."""
+    walls = []
+    for _ in range(reps):
+        sync_all()
+        t0 = time.perf_counter()
+        run()
+        sync_all()
+        walls.append(time.perf_counter() - t0)
+    if reduce_max is not None:
+        walls = reduce_max(walls)
+    return float(np.median(walls)), [float(w) for w in walls]
+
+
+def budget_left(budget_s):
+    """Seconds left of this process's wall-clock allowance (N > 1: SPMV_ACC_BENCH_BUDGET_S, default 420 -- the side legs of a multi-GPU run
+    are skipped rather than allowed to eat the driver's timeout when an exchange turns out slow)."""
+    return budget_s - (time.perf_counter() - T_START)
 
 
 def parse():
@@ -61,6 +87,7 @@ def parse():
                    help="N = 1: measure the extra legs inside this process instead of one child process per matrix (e.g. to see their kernels "
                         "in one rocprofv3 trace)")
     p.add_argument("--leg-child", default=None, help=argparse.SUPPRESS)  # internal: measure ONE leg and print its JSON (see extra_legs)
+    p.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)  # internal: the timed CPU runs over the arrays in this directory
     return p.parse_args()
 
 
@@ -90,31 +117,56 @@ def build_workload(args, torch, device, rank):
     raise SystemExit(f"unknown workload {w}")
 
 
-def cpu_baseline(W, x, y0, seconds):
-    """Oracle timed on the host cores (rank 0, N = 1 only).  Whole matrix, repeated for ~`seconds`."""
+def host_cpus():
+    """CPUs this process may really use: the affinity mask, cut by the cgroup's CPU quota where there is one (a box that shows 128 hardware
+    threads but grants 16 CPUs' worth of time throttles 128 busy threads -- one source of the 2x swings of earlier rounds)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(period) + 0.5))
+    except (OSError, ValueError):
+        pass
+    return (min(n, quota) if quota else n), n, quota
+
+
+def cpu_baseline_child(args):
+    """`python bench.py --cpu-baseline-child DIR`: the timed CPU runs, in a process of their own so that OMP_PROC_BIND / OMP_PLACES are in the
+    environment BEFORE the OpenMP runtime is loaded (this process never imports torch).  Prints one JSON line."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
-    rp = W["rp"].cpu().numpy()
-    ci = W["ci"].cpu().numpy()
-    v = W["v"].cpu().numpy()
-    hx = x.cpu().numpy()
-    hy0 = y0.cpu().numpy()
-    nnz = W["nnz"]
-    cores = min(oracle_lib.max_threads(), os.cpu_count() or 1)
-
-    def timed(fn, budget):
-        reps, best, t_start = 0, float("inf"), time.perf_counter()
-        while True:
-            y = hy0.copy()
-            t0 = time.perf_counter()
-            fn(y)
-            dt = time.perf_counter() - t0
-            best = min(best, dt)
-            reps += 1
-            if time.perf_counter() - t_start > budget or reps >= 50:
-                return best, reps
-
+    d = args.cpu_baseline_child
+    rp, ci, v, hx, hy0 = (np.load(os.path.join(d, f"{k}.npy"), mmap_mode="r") for k in ("rp", "ci", "v", "x", "y0"))
+    m, n, nnz = len(rp) - 1, len(hx), int(rp[-1])
+    seconds = args.cpu_seconds
+    threads, affinity, quota = host_cpus()
+    threads = int(os.environ.get("SPMV_ACC_CPU_THREADS", threads))
+    b_alg = 12 * nnz + 4 * (m + 1) + 8 * n + 16 * m
+    # one thread: the sequential form as the reference's verification path runs it (cli/verification.cpp:56-66)
+    t1 = float("inf")
+    y_seq = None
+    t_begin = time.perf_counter()
+    for _ in range(3):
+        y = np.array(hy0)
+        t0 = time.perf_counter()
+        oracle_lib.host_spmv_inplace(1.0, 1.0, rp, ci, v, hx, y)
+        t1 = min(t1, time.perf_counter() - t0)
+        y_seq = y
+        if time.perf_counter() - t_begin > 0.25 * seconds:
+            break
+    triad = oracle_lib.stream_triad_gbs(1 << 26, threads, 5)  # 3 x 512 MiB
+    # all threads: placed arrays (first touch by the reading threads), y restored before every run; three independent rounds
+    probe, _ = oracle_lib.host_spmv_bench(1.0, 1.0, rp, ci, v, hx, hy0, threads, 3)
+    per_round = max(5, min(200, int(0.2 * seconds / max(float(np.min(probe)), 1e-6))))
+    rounds, same = [], True
+    for _ in range(3):
+        secs, y_par = oracle_lib.host_spmv_bench(1.0, 1.0, rp, ci, v, hx, hy0, threads, per_round)
+        rounds.append(secs)
+        same = same and bool(np.array_equal(y_par, y_seq))  # every row is summed left to right in both forms: bitwise equal
+    best = float(min(np.min(r) for r in rounds))
+    meds = [float(np.median(r)) for r in rounds]
     cpu_model = "unknown CPU"
     try:
         for line in open("/proc/cpuinfo"):
@@ -123,14 +175,41 @@ def cpu_baseline(W, x, y0, seconds):
                 break
     except OSError:
         pass
-    t1, r1 = timed(lambda y: oracle_lib.host_spmv_inplace(1.0, 1.0, rp, ci, v, hx, y), seconds * 0.4)
-    tc, rc = timed(lambda y: oracle_lib.host_spmv_omp(1.0, 1.0, rp, ci, v, hx, y, cores), seconds * 0.6)
-    return {
-        "value": round(2.0 * nnz / tc / 1e9, 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
-        "sample": f"whole matrix ({W['m']} rows, {nnz} nnz), best of {rc} runs, OpenMP over nnz-balanced row ranges; 1 thread: best of {r1}",
-        "cpu_model": cpu_model,
-        "value_1thread": round(2.0 * nnz / t1 / 1e9, 3),
-    }
+    gf = lambda t: round(2.0 * nnz / t / 1e9, 3)  # noqa: E731
+    print(json.dumps({
+        "value": gf(best), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+        "sample": f"whole matrix ({m} rows, {nnz} nnz), best of 3 x {per_round} runs on {threads} pinned threads (OMP_PROC_BIND=close, "
+                  f"OMP_PLACES=cores), arrays first-touched by the threads that read them, y restored before every run; 1 thread: best of 3",
+        "cpu_model": cpu_model, "value_1thread": gf(t1),
+        "value_median_per_round": [gf(t) for t in meds], "spread_of_round_medians": round(max(meds) / min(meds) - 1.0, 4),
+        "achieved_gbs": round(b_alg / best / 1e9, 1), "stream_triad_gbs": round(triad, 1),
+        "frac_of_stream_triad": round(b_alg / best / 1e9 / triad, 4) if triad > 0 else None,
+        "hardware_threads": affinity, "cgroup_cpu_quota": quota, "bitwise_equal_to_sequential": same}))
+
+
+def cpu_baseline(W, x, y0, seconds):
+    """Oracle timed on the host cores (rank 0, N = 1 only): whole matrix, ~`seconds` of CPU work, in a CHILD process that never loads torch
+    and has the OpenMP placement variables in its environment from the start (cpu_baseline_child).  The arrays travel through /dev/shm."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="spmv_acc_cpu_baseline_", dir=base)
+    try:
+        for k, t in (("rp", W["rp"]), ("ci", W["ci"]), ("v", W["v"]), ("x", x), ("y0", y0)):
+            np.save(os.path.join(d, f"{k}.npy"), t.cpu().numpy())
+        threads = host_cpus()[0]
+        env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_NUM_THREADS=str(threads), OMP_DYNAMIC="false")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", d, "--cpu-seconds", str(seconds)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"value": None, "unit": "GFLOP/s", "cores": threads, "kind": "port", "sample": "failed",
+                    "error": (r.stderr or r.stdout)[-300:]}
+        return json.loads(lines[-1])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def pmc_traffic(workload, strategy, key="corrected_bytes"):
@@ -418,7 +497,7 @@ def extra_legs(torch, device, headline, in_process=False):
     return out
 
 
-def sharded_leg(torch, dist, args, W, x, y0, alpha, beta, rank, world, device, backend, force_dist, steps, warmup, bounds=None):
+def sharded_leg(torch, dist, args, W, x, y0, alpha, beta, rank, world, device, backend, force_dist, steps, warmup, bounds=None, time_left=None):
     """N > 1: one RowShardedSpmv over this rank's shard -- local SpMV on the engine's own stream, ONE exchange of the y slices
     per step (RCCL allgather or the point-to-point fan-out, whichever the timing on this communicator prefers).  Returns the
     max-over-ranks wall time of `steps` steps (barrier + synchronize on both sides) and the SpMV-only launch time."""
@@ -450,20 +529,29 @@ def sharded_leg(torch, dist, args, W, x, y0, alpha, beta, rank, world, device, b
     for _ in range(max(warmup, 1)):
         eng.step(alpha, beta, x, overlap=not args.no_overlap)
     eng.wait()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        eng.step(alpha, beta, x, overlap=not args.no_overlap)
-    eng.wait()
-    sync_all()
-    wall = time.perf_counter() - t0
+
+    def region():
+        for _ in range(steps):
+            eng.step(alpha, beta, x, overlap=not args.no_overlap)
+        eng.wait()
+
+    def max_over_ranks(values):
+        t = torch.tensor(values, dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
+    # the K-step region `reps` times (each bracketed by barrier + synchronize, MAX over ranks per repetition), median; a first repetition that
+    # already takes long (a slow exchange) is not repeated as often: the run must end inside the driver's timeout
+    wall1, _ = median_region(region, 1, sync_all, max_over_ranks)
+    reps = REGION_REPS if wall1 * REGION_REPS < 30.0 else 3
+    wall, walls = median_region(region, reps, sync_all, max_over_ranks)
+    extra["region_reps"] = reps
+    extra["ms_per_step_wall_all"] = [round(w / steps * 1e3, 6) for w in walls]
     # SpMV-only (no exchange) for the same shard, per-launch hipEvents
     y = y0.clone()
     ms = spmv_acc_amd.time_spmv(strat, min(steps, 50), alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y)
     ev_ms = float(np.mean(ms))
-    t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall, ev_ms_max = float(t[0].item()), float(t[1].item())
+    ev_ms_max = max_over_ranks([ev_ms])[0]
     extra["spmv_only_gflops_per_gpu"] = round(2.0 * nnz / (ev_ms * 1e-3) / 1e9, 3)
     extra["spmv_only_ms_max_over_ranks"] = round(ev_ms_max, 6)
     extra["spmv_plus_exchange_ms_per_step"] = round(wall / steps * 1e3, 6)
@@ -473,7 +561,8 @@ def sharded_leg(torch, dist, args, W, x, y0, alpha, beta, rank, world, device, b
     # cross-step overlap above (legal here only because x is fixed) does not exist for them.  What does: cutting the local rows
     # into C chunks and sending chunk c while chunk c+1 computes (RowShardedSpmv.step(pipeline=C)).  Timed with every step
     # waiting for its exchange; C = 1 is the serial kernel + exchange.
-    if backend == "nccl":
+    # (a collective decision: `time_left()` is the MINIMUM over ranks of what is left of the run's allowance -- every rank skips or none does)
+    if backend == "nccl" and (time_left is None or time_left() > 60.0):
         try:
             dep = eng.tune_pipeline(alpha, beta, x, candidates=(1, 2, 4, 8), warm=2, iters=max(3, min(steps, 10)))
             extra["dependent_step_ms_by_pipeline"] = {str(k): round(v, 6) for k, v in dep.items()}
@@ -538,7 +627,7 @@ def compact_line(full):
     Everything else (prose notes, the third timing column, opt-in legs, launch floor, sensitivity, RCCL log lines) lives in
     bench_full.json beside this script and on stderr."""
     line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                        "vs_baseline", "dtype", "data", "config"))
+                        "vs_baseline", "dtype", "data", "config", "region_reps", "ms_per_step_events"))
     r = full["roofline"]
     line["roofline"] = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_lower_bound",
                                  "algorithmic_bytes_per_launch", "launch_ms_mean"))
@@ -546,7 +635,8 @@ def compact_line(full):
     if "frac_of_copy_ceiling" in r:
         line["roofline"]["frac_of_copy_ceiling"] = r["frac_of_copy_ceiling"]
     cb = full.get("cpu_baseline")
-    line["cpu_baseline"] = None if not cb else _pick(cb, ("value", "unit", "cores", "kind", "sample", "cpu_model", "value_1thread"))
+    line["cpu_baseline"] = None if not cb else _pick(cb, ("value", "unit", "cores", "kind", "sample", "cpu_model", "value_1thread", "value_median_per_round",
+                                                                  "stream_triad_gbs", "frac_of_stream_triad"))
     line.update(_pick(full, ("copy_ceiling_gbs", "plan", "first_call_ms", "settle_rest_ms")))
     if "sweep" in full:  # configs[2]: name -> [flat frac, adaptive frac] under the per-launch protocol
         line["sweep"] = {k: [row["flat"]["frac"], row["adaptive"]["frac"]] for k, row in full["sweep"].items()}
@@ -568,7 +658,7 @@ def compact_line(full):
                              "spmv_plus_exchange_gflops_total", "allgather_bytes_per_rank_per_step", "dependent_step_ms_by_pipeline",
                              "pipeline_best", "exchanged_bytes_per_rank_per_step")))
     if "rccl" in full:
-        line["rccl"] = {"ranks": full["rccl"].get("nranks_seen")}
+        line["rccl"] = {"ranks": full["rccl"].get("nranks_seen"), "ranks_ok": full["rccl"].get("nranks_seen") == full.get("n_gpus")}
     if "banded" in full:
         b = full["banded"]
         line["banded"] = _pick(b, ("rows_per_gpu", "nnz_per_gpu", "steps", "exchange", "spmv_only_frac_of_hbm_peak", "spmv_only_gflops_per_gpu",
@@ -633,9 +723,10 @@ def self_launch(args):
 
 
 def dry_run(args):
-    """SPMV_ACC_BENCH_DRYRUN=1 (CPU test of the launch contract, no GPU): the ranks rendezvous over gloo, agree on the world
-    size with one all-reduce, and rank 0 prints one JSON line with the contract's keys -- everything about an N > 1 run except
-    the GPU work."""
+    """SPMV_ACC_BENCH_DRYRUN=1 (CPU test of the N > 1 contract, no GPU): the ranks rendezvous over gloo and run everything about an N > 1 run
+    except the GPU work -- the repeated K-step regions with their barriers and the MAX-over-ranks of every repetition (median_region), the
+    collective time-budget decision -- and rank 0 prints the ONE line through compact_line() from a record that carries EVERY key a real
+    N > 1 run produces (values are placeholders of realistic width), so that the line's length at N = 8 is tested on CPU."""
     import torch
     import torch.distributed as dist
 
@@ -646,10 +737,50 @@ def dry_run(args):
     t = torch.tensor([1.0 + rank])
     dist.barrier()
     dist.all_reduce(t)
+
+    def max_over_ranks(values):
+        v = torch.tensor(values, dtype=torch.float64)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return v.tolist()
+
+    def time_left():
+        v = torch.tensor([budget_left(float(os.environ.get("SPMV_ACC_BENCH_BUDGET_S", "420")))], dtype=torch.float64)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        return float(v.item())
+
+    # rank r's fake step takes (1 + r) ms: the MAX over ranks of every repetition is the slowest rank's
+    wall, walls = median_region(lambda: time.sleep(1e-3 * (1 + rank) * args.steps), 3, dist.barrier, max_over_ranks)
+    left = time_left()
     if rank == 0:
-        print(json.dumps({"metric": "dry run (launch contract only)", "value": 0.0, "unit": "GFLOP/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_sum": float(t.item()),
-                          "launched_by": "self" if os.environ.get("SPMV_ACC_BENCH_CHILD") == "1" else "external launcher"}), flush=True)
+        leg = {"exchange": "allgather", "exchange_ms": {"allgather": 1.2345, "p2p": 1.3456}, "spmv_only_gflops_per_gpu": 512.345,
+               "spmv_only_ms_max_over_ranks": 0.157912, "spmv_plus_exchange_ms_per_step": 1.234567, "spmv_plus_exchange_gflops_total": 4321.123,
+               "allgather_bytes_per_rank_per_step": 8 * 8217820 * (world - 1), "region_reps": 3,
+               "ms_per_step_wall_all": [round(w / args.steps * 1e3, 6) for w in walls],
+               "dependent_step_ms_by_pipeline": {"1": 1.234567, "2": 1.123456, "4": 1.012345, "8": 1.001234}, "pipeline_best": 4}
+        full = {"metric": "dry run (launch contract only)", "value": 0.0, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "Hardesty3-like (SuiteSparse Hardesty3 dims, synthetic stand-in)", "rows_per_gpu": 8217820, "cols": 7591564,
+                           "nnz_per_gpu": 40451632, "strategy": "adaptive", "alpha": 1.0, "beta": 1.0, "scale": 1.0,
+                           "parallelism": f"row-range shard x{world} + allgather(y) over gloo (dry run)"},
+                "roofline": {"bound": "hbm", "achieved": 4500.12, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.5625, "traffic": None,
+                             "traffic_lower_bound": None, "algorithmic_bytes_per_launch": 710508500, "launch_ms_mean": 0.157912,
+                             "back_to_back": {"launch_ms_mean": 0.157912, "achieved": 4500.12, "frac": 0.5625}, "frac_of_copy_ceiling": 0.7012},
+                "cpu_baseline": None, "copy_ceiling_gbs": 6400.1,
+                "plan": {"stream_policy": 0, "adaptive_family": 0, "flat_fixup": -1, "plus_blocks": -1, "flat_tiles": -1, "slab_passes": 0},
+                "rccl": {"nranks_seen": world, "debug_file": "/tmp/x", "debug_file_bytes": 12345, "lines": ["Init COMPLETE " + "w" * 140] * 8},
+                "banded": dict(leg, workload="banded " + "x" * 200, rows_per_gpu=32_000_000, nnz_per_gpu=255_999_993, steps=50,
+                               spmv_only_frac_of_hbm_peak=0.7123,
+                               halo_exchange={"what": "y" * 120, "ms_per_step": 0.712345, "gflops_total": 5432.123,
+                                              "exchanged_bytes_per_rank_per_step": 112, "ghost_columns": 7}),
+                "strong_scaling": dict(leg, workload="z" * 100, rows_this_rank=1027227, nnz_this_rank=5056454, steps=100,
+                                       gflops_total=3210.123, ms_per_step=0.025123),
+                "dry_run": True, "ranks_sum": float(t.item()), "time_left_s": round(left, 1),
+                "launched_by": "self" if os.environ.get("SPMV_ACC_BENCH_CHILD") == "1" else "external launcher"}
+        full.update(leg)
+        line = json.loads(compact_line(full))
+        line.update({k: full[k] for k in ("dry_run", "ranks_sum", "launched_by", "time_left_s")})
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     dist.destroy_process_group()
 
 
@@ -662,6 +793,9 @@ def main():
         return
     if args.leg_child:
         leg_child(args)
+        return
+    if args.cpu_baseline_child:
+        cpu_baseline_child(args)
         return
     # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner with NCCL_DEBUG set, loader
     # notices): from here on file descriptor 1 is stderr, and the JSON line is written to the saved descriptor at the end.
@@ -754,13 +888,17 @@ def main():
                 out_extra["settle_rest_ms"] = round(spmv_acc_amd.prepare(m, n, nnz, W["rp"], W["ci"], W["v"], x, strategy=strat, beta=beta), 3)
         torch.cuda.synchronize()
         y.copy_(y0)
-        sync_all()
-        t0 = time.perf_counter()
-        # timed region: exactly K back-to-back launches between one hipEvent pair on the library stream
-        total_ms = spmv_acc_amd.time_spmv_total(strat, args.steps, alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y)
-        sync_all()
-        wall = time.perf_counter() - t0
-        b2b_ms = total_ms / args.steps
+        # timed region: exactly K back-to-back launches between one hipEvent pair on the library stream and nothing else (the plan is settled,
+        # the events exist, arguments are converted once: spmv_acc_time_spmv_region); one untimed region first, then REGION_REPS timed ones
+        region = spmv_acc_amd.time_spmv_region(strat, args.steps, alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y)
+        region()
+        region_event_ms = []
+        wall, walls = median_region(lambda: region_event_ms.append(region()), REGION_REPS, sync_all)
+        b2b_ms = float(np.median(region_event_ms)) / args.steps
+        out_extra["region_reps"] = REGION_REPS
+        out_extra["ms_per_step_events"] = round(b2b_ms, 6)
+        out_extra["ms_per_step_wall_all"] = [round(w / args.steps * 1e3, 6) for w in walls]
+        out_extra["ms_per_step_events_all"] = [round(e / args.steps, 6) for e in region_event_ms]
         # the reference harness's protocol (csr_spmv.hpp:66-74): y reset by a device copy before every launch, one event pair
         # per launch, median -- what roofline.frac is quoted on
         ms = spmv_acc_amd.time_spmv(strat, max(20, min(args.steps, 50)), alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y, y0=y0)
@@ -783,12 +921,13 @@ def main():
         alpha, beta = 0.4, 0.0  # spectral radius of 0.4 * A is below 1: the iteration neither overflows nor underflows
         for _ in range(max(args.warmup, 1)):
             eng.iterate(alpha)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.iterate(alpha)
-        sync_all()
-        wall = time.perf_counter() - t0
+
+        def ghost_region():
+            for _ in range(args.steps):
+                eng.iterate(alpha)
+
+        wall, walls = median_region(ghost_region, REGION_REPS, sync_all)
+        out_extra["region_reps"] = REGION_REPS
         xe = eng.x_ext.clone()
         ms = spmv_acc_amd.time_spmv(strat, min(args.steps, 50), alpha, beta, m, eng.n_local + eng.n_ghost, nnz, W["rp"],
                                     eng.cols_local, W["v"], xe, y)
@@ -801,92 +940,109 @@ def main():
         out_extra["exchanged_bytes_per_rank_per_step"] = eng.exchanged_bytes_per_step
         out_extra["ghost_columns"] = eng.n_ghost
     else:
+        budget_s = float(os.environ.get("SPMV_ACC_BENCH_BUDGET_S", "420"))
+
+        def time_left():
+            t = torch.tensor([budget_left(budget_s)], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return float(t.item())
+
         wall, ev_ms, extra = sharded_leg(torch, dist, args, W, x, y0, alpha, beta, rank, world, device, backend, force_dist,
-                                         args.steps, args.warmup)
+                                         args.steps, args.warmup, time_left=time_left)
         out_extra.update(extra)
         if backend == "nccl":
             out_extra["rccl"] = rccl_debug_summary(rank)
         if args.workload == "hardesty3" and args.scale == 1.0 and not args.no_legs:
-            # BASELINE configs[4] as a first-class leg of every N > 1 run: each rank owns 32 M rows of the (N * 32 M)-row banded
-            # matrix (global column ids, x replicated), beta = 0, one exchange of the y slices per step.
-            from spmv_acc_amd import synth as _synth
+            # Side legs under the run's wall-clock allowance (SPMV_ACC_BENCH_BUDGET_S, default 420 s; the decision is collective -- the minimum over
+            # ranks): a slow exchange must not cost the run its line by eating the driver's timeout.
+            if time_left() > 150.0:
+                # BASELINE configs[4] as a first-class leg of every N > 1 run: each rank owns 32 M rows of the (N * 32 M)-row banded
+                # matrix (global column ids, x replicated), beta = 0, one exchange of the y slices per step.
+                from spmv_acc_amd import synth as _synth
 
-            rows = 32_000_000
-            brp, bci, bv = _synth.banded_torch(rows, first_row=rank * rows, total_rows=world * rows, device=device)
-            BW = dict(m=rows, n=world * rows, nnz=int(brp[-1].item()), rp=brp, ci=bci, v=bv, strategy="adaptive")
-            gen_b = torch.Generator(device=device)
-            gen_b.manual_seed(4321)
-            bx = torch.rand(world * rows, generator=gen_b, device=device, dtype=torch.float64) * 2 - 1
-            by0 = torch.zeros(rows, dtype=torch.float64, device=device)
-            bsteps = min(args.steps, 50)
-            bwall, bev, bextra = sharded_leg(torch, dist, args, BW, bx, by0, 1.0, 0.0, rank, world, device, backend, force_dist,
-                                             bsteps, min(args.warmup, 5))
-            b_alg_b = _synth.algorithmic_bytes(rows, rows + 7, BW["nnz"], beta_nonzero=False)  # x: the columns the shard references
-            bextra.update({
-                "workload": f"banded offsets -4..+3, {world} x 32 M rows (BASELINE configs[4]; 8 ranks = the 256 M-row matrix), "
-                            "row-range shards, x replicated, beta = 0, allgather(y) per step",
-                "rows_per_gpu": rows, "nnz_per_gpu": BW["nnz"], "steps": bsteps,
-                "spmv_only_frac_of_hbm_peak": round(b_alg_b / (bev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
-            # beside it, what this matrix allows when x is partitioned like the rows (x_{k+1} = f(y_k) solvers): each rank receives only
-            # the x entries its columns reference -- 4 + 3 doubles per neighbour for this band -- instead of every peer's 256 MB slice
-            # (GhostedRowShardedSpmv, `--exchange ghost`).  Reported, never the headline: north_star prescribes the allgather of y.
-            try:
-                from spmv_acc_amd.dist import GhostedRowShardedSpmv
+                rows = 32_000_000
+                brp, bci, bv = _synth.banded_torch(rows, first_row=rank * rows, total_rows=world * rows, device=device)
+                BW = dict(m=rows, n=world * rows, nnz=int(brp[-1].item()), rp=brp, ci=bci, v=bv, strategy="adaptive")
+                gen_b = torch.Generator(device=device)
+                gen_b.manual_seed(4321)
+                bx = torch.rand(world * rows, generator=gen_b, device=device, dtype=torch.float64) * 2 - 1
+                by0 = torch.zeros(rows, dtype=torch.float64, device=device)
+                bsteps = min(args.steps, 50)
+                bwall, bev, bextra = sharded_leg(torch, dist, args, BW, bx, by0, 1.0, 0.0, rank, world, device, backend, force_dist,
+                                                 bsteps, min(args.warmup, 5), time_left=time_left)
+                b_alg_b = _synth.algorithmic_bytes(rows, rows + 7, BW["nnz"], beta_nonzero=False)  # x: the columns the shard references
+                bextra.update({
+                    "workload": f"banded offsets -4..+3, {world} x 32 M rows (BASELINE configs[4]; 8 ranks = the 256 M-row matrix), "
+                                "row-range shards, x replicated, beta = 0, allgather(y) per step",
+                    "rows_per_gpu": rows, "nnz_per_gpu": BW["nnz"], "steps": bsteps,
+                    "spmv_only_frac_of_hbm_peak": round(b_alg_b / (bev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+                # beside it, what this matrix allows when x is partitioned like the rows (x_{k+1} = f(y_k) solvers): each rank receives only
+                # the x entries its columns reference -- 4 + 3 doubles per neighbour for this band -- instead of every peer's 256 MB slice
+                # (GhostedRowShardedSpmv, `--exchange ghost`).  Reported, never the headline: north_star prescribes the allgather of y.
+                try:
+                    if time_left() < 60.0:
+                        raise RuntimeError("skipped: time budget (SPMV_ACC_BENCH_BUDGET_S)")
+                    from spmv_acc_amd.dist import GhostedRowShardedSpmv
 
-                gbounds = np.arange(world + 1, dtype=np.int64) * rows
-                geng = GhostedRowShardedSpmv(rank, world, gbounds, brp, bci, bv, device, strategy="adaptive")
-                geng.set_x(bx[rank * rows: (rank + 1) * rows])
-                for _ in range(3):
-                    geng.iterate(0.4)  # (spectral radius of 0.4 * A is below 1)
-                dist.barrier()
-                torch.cuda.synchronize()
-                g0 = time.perf_counter()
-                for _ in range(bsteps):
-                    geng.iterate(0.4)
-                dist.barrier()
-                torch.cuda.synchronize()
-                gt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=device)
-                dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-                gwall = float(gt.item())
-                bextra["halo_exchange"] = {
-                    "what": "x partitioned like the rows, x <- 0.4 * A * x, each rank receiving only the columns it references",
-                    "ms_per_step": round(gwall / bsteps * 1e3, 6), "gflops_total": round(2.0 * BW["nnz"] * world * bsteps / gwall / 1e9, 3),
-                    "exchanged_bytes_per_rank_per_step": geng.exchanged_bytes_per_step, "ghost_columns": geng.n_ghost}
+                    gbounds = np.arange(world + 1, dtype=np.int64) * rows
+                    geng = GhostedRowShardedSpmv(rank, world, gbounds, brp, bci, bv, device, strategy="adaptive")
+                    geng.set_x(bx[rank * rows: (rank + 1) * rows])
+                    for _ in range(3):
+                        geng.iterate(0.4)  # (spectral radius of 0.4 * A is below 1)
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    g0 = time.perf_counter()
+                    for _ in range(bsteps):
+                        geng.iterate(0.4)
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    gt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=device)
+                    dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+                    gwall = float(gt.item())
+                    bextra["halo_exchange"] = {
+                        "what": "x partitioned like the rows, x <- 0.4 * A * x, each rank receiving only the columns it references",
+                        "ms_per_step": round(gwall / bsteps * 1e3, 6), "gflops_total": round(2.0 * BW["nnz"] * world * bsteps / gwall / 1e9, 3),
+                        "exchanged_bytes_per_rank_per_step": geng.exchanged_bytes_per_step, "ghost_columns": geng.n_ghost}
+                    spmv_acc_amd.release_plans(brp)
+                    del geng
+                except Exception as ex:  # noqa: BLE001 -- a side leg must not cost the run its line
+                    bextra["halo_exchange_error"] = repr(ex)[:200]
+                out_extra["banded"] = bextra
                 spmv_acc_amd.release_plans(brp)
-                del geng
-            except Exception as ex:  # noqa: BLE001 -- a side leg must not cost the run its line
-                bextra["halo_exchange_error"] = repr(ex)[:200]
-            out_extra["banded"] = bextra
-            spmv_acc_amd.release_plans(brp)
-            del brp, bci, bv, bx, by0, BW
-            torch.cuda.empty_cache()
-            # STRONG scaling beside the weak-scaling value ("strong scaling on a problem that fits one GPU and weak
-            # scaling"): the ONE Hardesty3-sized matrix (same seed on every rank) cut into `world` nnz-balanced row ranges, equal
-            # padded shards, x replicated, allgather(y) per step.  gflops_total counts the matrix once.
-            from spmv_acc_amd.dist import local_csr_slice, shard_bounds
+                del brp, bci, bv, bx, by0, BW
+                torch.cuda.empty_cache()
+            else:
+                out_extra["banded"] = {"skipped": "time budget (SPMV_ACC_BENCH_BUDGET_S)"}
+            if time_left() > 90.0:
+                # STRONG scaling beside the weak-scaling value ("strong scaling on a problem that fits one GPU and weak
+                # scaling"): the ONE Hardesty3-sized matrix (same seed on every rank) cut into `world` nnz-balanced row ranges, equal
+                # padded shards, x replicated, allgather(y) per step.  gflops_total counts the matrix once.
+                from spmv_acc_amd.dist import local_csr_slice, shard_bounds
 
-            gm, gn, gnnz, grp, gci, gv = synth.hardesty3_like_torch(device=device, seed=0xC2, scale=args.scale)
-            h_rp = grp.cpu().numpy()
-            sb = shard_bounds(gm, world, mode=1, h_rowptr=h_rp)
-            r0, r1 = int(sb[rank]), int(sb[rank + 1])
-            lrp, lci, lv = local_csr_slice(grp, gci, gv, r0, r1)
-            lrp = lrp.contiguous()
-            SW = dict(m=r1 - r0, n=gn, nnz=int(h_rp[r1] - h_rp[r0]), rp=lrp, ci=lci, v=lv, strategy=strat)
-            gen_s = torch.Generator(device=device)
-            gen_s.manual_seed(99)
-            sy0 = torch.rand(r1 - r0, generator=gen_s, device=device, dtype=torch.float64)
-            ssteps = min(args.steps, 100)
-            swall, sev, sextra = sharded_leg(torch, dist, args, SW, x, sy0, alpha, beta, rank, world, device, backend, force_dist, ssteps,
-                                             min(args.warmup, 5), bounds=sb)
-            sextra.pop("spmv_plus_exchange_gflops_total", None)  # (that key assumes equal non-zeros per rank: weak scaling)
-            sextra.update({"workload": "the ONE Hardesty3-sized matrix in `world` nnz-balanced row ranges (strong scaling)",
-                           "rows_this_rank": r1 - r0, "nnz_this_rank": SW["nnz"], "steps": ssteps,
-                           "gflops_total": round(2.0 * gnnz * ssteps / swall / 1e9, 3),
-                           "ms_per_step": round(swall / ssteps * 1e3, 6)})
-            out_extra["strong_scaling"] = sextra
-            spmv_acc_amd.release_plans(lrp)
-            del grp, gci, gv, lrp, lci, lv, SW
-            torch.cuda.empty_cache()
+                gm, gn, gnnz, grp, gci, gv = synth.hardesty3_like_torch(device=device, seed=0xC2, scale=args.scale)
+                h_rp = grp.cpu().numpy()
+                sb = shard_bounds(gm, world, mode=1, h_rowptr=h_rp)
+                r0, r1 = int(sb[rank]), int(sb[rank + 1])
+                lrp, lci, lv = local_csr_slice(grp, gci, gv, r0, r1)
+                lrp = lrp.contiguous()
+                SW = dict(m=r1 - r0, n=gn, nnz=int(h_rp[r1] - h_rp[r0]), rp=lrp, ci=lci, v=lv, strategy=strat)
+                gen_s = torch.Generator(device=device)
+                gen_s.manual_seed(99)
+                sy0 = torch.rand(r1 - r0, generator=gen_s, device=device, dtype=torch.float64)
+                ssteps = min(args.steps, 100)
+                swall, sev, sextra = sharded_leg(torch, dist, args, SW, x, sy0, alpha, beta, rank, world, device, backend, force_dist, ssteps,
+                                                 min(args.warmup, 5), bounds=sb, time_left=time_left)
+                sextra.pop("spmv_plus_exchange_gflops_total", None)  # (that key assumes equal non-zeros per rank: weak scaling)
+                sextra.update({"workload": "the ONE Hardesty3-sized matrix in `world` nnz-balanced row ranges (strong scaling)",
+                               "rows_this_rank": r1 - r0, "nnz_this_rank": SW["nnz"], "steps": ssteps,
+                               "gflops_total": round(2.0 * gnnz * ssteps / swall / 1e9, 3),
+                               "ms_per_step": round(swall / ssteps * 1e3, 6)})
+                out_extra["strong_scaling"] = sextra
+                spmv_acc_amd.release_plans(lrp)
+                del grp, gci, gv, lrp, lci, lv, SW
+                torch.cuda.empty_cache()
+            else:
+                out_extra["strong_scaling"] = {"skipped": "time budget (SPMV_ACC_BENCH_BUDGET_S)"}
 
     ms_per_step = wall / args.steps * 1e3
     nnz_total = nnz * world  # weak scaling: every rank processes its own nnz

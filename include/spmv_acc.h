@@ -283,6 +283,18 @@ int spmv_acc_query_plan_slab_passes(const int *d_rowptr, int m);
  * 0: the first-call budget (tunable first_call_budget) deferred some, the next calls resume them (or call spmv_acc_prepare); -2 = no such plan.
  * No reference counterpart (the reference times nothing). */
 int spmv_acc_query_plan_settled(const int *d_rowptr, int m);
+/* Which kernel ran the plan's LATEST SpMV (round 5).  The reference's strategy name IS its kernel (strategy_picker.cpp:19-65); here a name selects a
+ * policy by default (`flat` may run the row-block kernel where it timed faster, `line_enhance` the column-slab passes on power-law columns) and
+ * tunable strict_strategy = 1 (SPMV_ACC_TUNABLES=strict_strategy=1) binds the name to its algorithm.  -1 = no SpMV yet, -2 = no such plan. */
+enum spmv_acc_kernel {
+  SPMV_ACC_KERNEL_ROWBLOCK = 0,    /* rowblock_stream_kernel: line_enhance / line / thread_row / default (line_enhance_spmv_imp.inl:12-95) */
+  SPMV_ACC_KERNEL_ROWBLOCK_PLUS = 1, /* plus_kernel: adaptive_plus, and the row-block family's rescue of unbalanced rows (csr_adaptive_plus_spmv_imp.inl:31-205) */
+  SPMV_ACC_KERNEL_FLAT_TILE = 2,   /* flat_tile_kernel (+ fix-up): flat (flat_imp_one_pass.hpp:16-77) */
+  SPMV_ACC_KERNEL_SLAB_PASSES = 3, /* segment_tile_kernel passes over the plan's run lists (no reference counterpart) */
+  SPMV_ACC_KERNEL_VECTOR_TILE = 4, SPMV_ACC_KERNEL_VECTOR_ROW = 5, SPMV_ACC_KERNEL_WAVE_ROW = 6, SPMV_ACC_KERNEL_LIGHT = 7,
+  SPMV_ACC_KERNEL_BLOCK_ROW = 8, SPMV_ACC_KERNEL_COL_SLABS = 9, SPMV_ACC_KERNEL_SCALE_ONLY = 10
+};
+int spmv_acc_query_plan_last_kernel(const int *d_rowptr, int m);
 
 void spmv_acc_set_stream(void *hip_stream); /* hipStream_t; NULL = the NULL stream (reference behaviour).  The stream belongs to the
                                              * CALLING HOST THREAD, like HIP's current device: N threads driving N GPUs each set

@@ -96,6 +96,130 @@ void oracle_host_spmv_omp(double alpha, double beta, const double *value, const 
 #endif
 }
 
+/* ---- the CPU baseline's timed form (bench.py `cpu_baseline`, round 5) -------------------------------------------------------
+ * Same arithmetic per row as oracle_host_spmv (cli/verification.cpp:56-66), same nnz-balanced row ranges as oracle_host_spmv_omp,
+ * but the five arrays are first COPIED into 64-byte-aligned buffers by the very threads that will read them (first touch: on a
+ * multi-socket / multi-CCD host a page lands in the memory of the thread that writes it first; numpy-allocated arrays are all
+ * touched by one thread, which made this baseline swing by 2x from box to box).  x is touched by the thread whose rows lie on
+ * that part of the diagonal (columns [r0*n/m, r1*n/m)).  Then `reps` timed runs, y restored from y0 before each, outside the
+ * timed interval; seconds per run into secs[0 .. reps).  The last run's y is copied to y_out (may be NULL) so that the caller can
+ * check it against the sequential form.  Threads are pinned by the caller's environment (OMP_PROC_BIND=close, OMP_PLACES=cores:
+ * libgomp reads them when it is loaded).  Returns 0, or -1 when a buffer could not be allocated.                                   */
+static void nnz_balanced_range(const int *rowptr, int m, int t, int nt, int *r0_out, int *r1_out) {
+  const int64_t first = rowptr[0], nnz = (int64_t)rowptr[m] - first;
+  const int64_t lo_target = first + nnz * t / nt, hi_target = first + nnz * (t + 1) / nt;
+  int lo = 0, hi = m;
+  while (lo < hi) { int mid = lo + (hi - lo) / 2; if (rowptr[mid] < lo_target) lo = mid + 1; else hi = mid; }
+  *r0_out = (t == 0) ? 0 : lo;
+  lo = 0; hi = m;
+  while (lo < hi) { int mid = lo + (hi - lo) / 2; if (rowptr[mid] < hi_target) lo = mid + 1; else hi = mid; }
+  *r1_out = (t == nt - 1) ? m : lo;
+}
+
+static void *alloc64(size_t bytes) { return aligned_alloc(64, (bytes + 63) / 64 * 64 + 64); }
+
+int oracle_host_spmv_bench(double alpha, double beta, const double *value, const int *rowptr, const int *colindex, int m, int n,
+                           const double *x, const double *y0, double *y_out, int threads, int reps, double *secs) {
+  const int64_t nnz = rowptr[m];
+  double *v2 = (double *)alloc64(sizeof(double) * (size_t)nnz), *x2 = (double *)alloc64(sizeof(double) * (size_t)n);
+  double *y2 = (double *)alloc64(sizeof(double) * (size_t)m);
+  int *c2 = (int *)alloc64(sizeof(int) * (size_t)nnz), *rp2 = (int *)alloc64(sizeof(int) * ((size_t)m + 1));
+  int rc = 0;
+  if (!v2 || !x2 || !y2 || !c2 || !rp2) rc = -1;
+  if (threads < 1) threads = 1;
+  if (rc == 0) {
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+#ifdef _OPENMP
+      const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+      const int t = 0, nt = 1;
+#endif
+      int r0, r1;
+      nnz_balanced_range(rowptr, m, t, nt, &r0, &r1);
+      /* first touch, by the thread that will read them */
+      memcpy(rp2 + r0, rowptr + r0, sizeof(int) * (size_t)(r1 - r0 + (t == nt - 1 ? 1 : 0)));
+      memcpy(v2 + rowptr[r0], value + rowptr[r0], sizeof(double) * (size_t)(rowptr[r1] - rowptr[r0]));
+      memcpy(c2 + rowptr[r0], colindex + rowptr[r0], sizeof(int) * (size_t)(rowptr[r1] - rowptr[r0]));
+      memcpy(y2 + r0, y0 + r0, sizeof(double) * (size_t)(r1 - r0));
+      const int64_t c_lo = (t == 0) ? 0 : (int64_t)r0 * n / (m > 0 ? m : 1), c_hi = (t == nt - 1) ? n : (int64_t)r1 * n / (m > 0 ? m : 1);
+      if (c_hi > c_lo) memcpy(x2 + c_lo, x + c_lo, sizeof(double) * (size_t)(c_hi - c_lo));
+      for (int rep = 0; rep < reps; rep++) {
+#ifdef _OPENMP
+#pragma omp barrier
+#endif
+        if (rep > 0) memcpy(y2 + r0, y0 + r0, sizeof(double) * (size_t)(r1 - r0)); /* y restored outside the timed interval */
+#ifdef _OPENMP
+#pragma omp barrier
+        const double t0 = omp_get_wtime();
+#else
+        const double t0 = 0.0;
+#endif
+        for (int i = r0; i < r1; i++) {
+          double acc = 0;
+          for (int j = rp2[i]; j < rp2[i + 1]; j++) acc += v2[j] * x2[c2[j]];
+          y2[i] = alpha * acc + beta * y2[i];
+        }
+#ifdef _OPENMP
+#pragma omp barrier
+        if (t == 0) secs[rep] = omp_get_wtime() - t0;
+#else
+        secs[rep] = t0;
+#endif
+      }
+      if (y_out) memcpy(y_out + r0, y2 + r0, sizeof(double) * (size_t)(r1 - r0));
+    }
+  }
+  free(v2); free(x2); free(y2); free(c2); free(rp2);
+  return rc;
+}
+
+/* STREAM triad a[i] = b[i] + s * c[i] over three arrays of `elems` doubles, first-touched and swept by the same static partition
+ * (the yardstick the CPU baseline is quoted against: what THIS host's memory delivers to `threads` pinned threads).  Returns the
+ * best of `reps` sweeps in GB/s, counting 24 bytes per element (STREAM's convention), or -1.                                      */
+double oracle_stream_triad_gbs(long long elems, int threads, int reps) {
+  double *a = (double *)alloc64(sizeof(double) * (size_t)elems), *b = (double *)alloc64(sizeof(double) * (size_t)elems);
+  double *c = (double *)alloc64(sizeof(double) * (size_t)elems);
+  double best = -1.0;
+  if (a && b && c && elems > 0) {
+    if (threads < 1) threads = 1;
+    double best_s = 1e30;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+#ifdef _OPENMP
+      const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+      const int t = 0, nt = 1;
+#endif
+      const long long i0 = elems * t / nt, i1 = elems * (t + 1) / nt;
+      for (long long i = i0; i < i1; i++) { a[i] = 0.0; b[i] = 1.0; c[i] = 2.0; }
+      for (int rep = 0; rep < reps; rep++) {
+#ifdef _OPENMP
+#pragma omp barrier
+        const double t0 = omp_get_wtime();
+#else
+        const double t0 = 0.0;
+#endif
+        for (long long i = i0; i < i1; i++) a[i] = b[i] + 3.0 * c[i];
+#ifdef _OPENMP
+#pragma omp barrier
+        if (t == 0) { const double dt = omp_get_wtime() - t0; if (dt < best_s) best_s = dt; }
+#else
+        (void)t0;
+#endif
+      }
+    }
+    if (best_s < 1e29 && best_s > 0.0) best = 24.0 * (double)elems / best_s / 1e9;
+    if (a[elems / 2] != 7.0) best = -1.0; /* (keeps the sweep from being optimised away) */
+  }
+  free(a); free(b); free(c);
+  return best;
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

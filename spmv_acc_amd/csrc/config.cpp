@@ -193,19 +193,35 @@ Tunable g_tunables[] = {
                                // non-zeros is a 12-B list entry, a y read-modify-write and a part-used line of each stream: 5.30 -> 5.19 ms, first call 152 ->
                                // 135 ms (thresholds 8 / 16 / 24 / 32 / 48 / 64 / 128 / 256: 5.33 / 5.28 / 5.19 / 5.19 / 5.21 / 5.25 / 5.29 / 5.79,
                                // profiles/r04_rmat25_hub_windows_and_two_class.txt); 0 = every row is cut (round 3)
+    {"strict_strategy", 0, 0}, // 1: a strategy NAME means its ALGORITHM, as in the reference (strategy_picker.cpp:19-65: the name IS the kernel): `flat` always runs
+                               // flat_tile_kernel (no substitution of the row-block kernel on balanced rows, no row-block rescue of hypersparse tiles),
+                               // `line_enhance` / `line` always the row-block kernel or, where fixed row blocks are unbalanced, its row-block-plus rescue
+                               // (never the column-slab passes).  0 (default): the name selects a policy -- the engine may run whichever of its kernels it
+                               // timed faster on the matrix.  adaptive / default are the engine's choice by definition and are not affected
+    // ---- size rules, adjustable so that tests reach every size-selected branch at test size (round 5; defaults = the shipped rules) ----
+    {"slab_kb", 32768, 32768}, // automatic slab count of the column-slab passes: KB of x per slab (S = x bytes / this, 2 ... 16: 16 from x = 496 MB on)
+    {"hint_min_x_mb", 96, 96}, // the column census (gather hints, automatic slab passes) is taken from this many MB of x on (below, x lives in the Infinity Cache)
+    {"max_grid_blocks", kMaxGridBlocks, kMaxGridBlocks}, // workgroups one launch may hold before a kernel whose grid grows with m strides over the rows
+                               // (a launch holds < 2^32 work-items; 8,388,593 is prime).  Lowered by tests so that the striding runs at 10^5 rows
+    {"flat_small_nnz_k", kFlatSmallNnz >> 10, kFlatSmallNnz >> 10}, // flat: below this many Ki non-zeros the tile size / staging order are timed per matrix (small grids)
 };
 static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "TunableId must list every table entry, in order");
 // (the count alone does not catch two entries in the wrong order -- round 4 ran an afternoon with first_call_budget reading slab_whole_below's
 // value: the table's last names are checked against their ids once, at the first tunable lookup)
 inline bool tunable_order_ok() {
   return std::strcmp(g_tunables[kT_first_call_budget].name, "first_call_budget") == 0 && std::strcmp(g_tunables[kT_later_call_budget].name, "later_call_budget") == 0 &&
-         std::strcmp(g_tunables[kT_slab_whole_below].name, "slab_whole_below") == 0 && std::strcmp(g_tunables[kT_vector_target].name, "vector_target") == 0 &&
+         std::strcmp(g_tunables[kT_slab_whole_below].name, "slab_whole_below") == 0 && std::strcmp(g_tunables[kT_strict_strategy].name, "strict_strategy") == 0 &&
+         std::strcmp(g_tunables[kT_flat_small_nnz_k].name, "flat_small_nnz_k") == 0 && std::strcmp(g_tunables[kT_max_grid_blocks].name, "max_grid_blocks") == 0 && std::strcmp(g_tunables[kT_vector_target].name, "vector_target") == 0 &&
          std::strcmp(g_tunables[kT_slab_segments].name, "slab_segments") == 0 && std::strcmp(g_tunables[kT_deterministic].name, "deterministic") == 0 &&
          std::strcmp(g_tunables[kT_zigzag].name, "zigzag") == 0 && std::strcmp(g_tunables[kT_xcd_remap].name, "xcd_remap") == 0;
 }
 void apply_env_tunables();
 
 } // namespace detail
+int max_grid_blocks() {
+  const int v = detail::g_tunables[detail::kT_max_grid_blocks].val;
+  return v >= 64 && v <= kMaxGridBlocks ? v : kMaxGridBlocks;
+}
 
 namespace detail {
 // SPMV_ACC_TUNABLES="validate=1,flat_finish=0": initial values for a process that cannot call spmv_acc_set_tunable

@@ -48,7 +48,7 @@ struct Tunable {
 enum TunableId {
   kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
   kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kT_slab_segments, kT_vector_target, kT_first_call_budget, kT_later_call_budget, kT_slab_whole_below, kTunableCount
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kT_slab_segments, kT_vector_target, kT_first_call_budget, kT_later_call_budget, kT_slab_whole_below, kT_strict_strategy, kT_slab_kb, kT_hint_min_x_mb, kT_max_grid_blocks, kT_flat_small_nnz_k, kTunableCount
 };
 extern Tunable g_tunables[];
 void apply_env_tunables();
@@ -61,6 +61,10 @@ int tile_vec(long long avg);
 int guard_acquire(int device, const int **d_guard, int **h_flag);
 void guard_release(int device, int slot, bool launched, hipStream_t last_stream);
 enum Family { kFamRowblock = 0, kFamPlus = 1, kFamFlat = 2, kFamVector = 3, kFamilyCount = 4 };
+// the kernel behind a plan's latest SpMV (Plan::last_kernel; include/spmv_acc.h SPMV_ACC_KERNEL_*)
+enum LastKernel { kKernelRowblock = 0, kKernelPlus = 1, kKernelFlatTile = 2, kKernelSlabPasses = 3, kKernelVectorTile = 4, kKernelVectorRow = 5,
+                  kKernelWaveRow = 6, kKernelLight = 7, kKernelBlockRow = 8, kKernelColSlabs = 9, kKernelScaleOnly = 10 };
+extern thread_local int t_strict_name; // the strategy the caller NAMED when tunable strict_strategy is on (else -1): run_flat / run_plus keep to the name's kernel
 
 typedef std::tuple<int, const void *, const void *, const void *, int, int> PlanKey;
 
@@ -75,6 +79,7 @@ struct Plan {
   unsigned long long calls = 0;    // SpMV calls served by this plan (the first one builds and tunes it)
   unsigned launches = 0;           // tile-kernel launches so far (parity = walking direction, tunable zigzag)
   double trial_ms = 0.0;           // a trial launch of this matrix as the per-matrix timings measured it: prices later calls' tuning budget
+  int last_kernel = -1;            // which kernel the plan's latest SpMV ran (kKernel*, below): spmv_acc_query_plan_last_kernel, strict_strategy's test
   bool tuning_open = true;         // some per-matrix timing was deferred (or has not been reached yet): later calls may resume it
   CsrDev A;
   int guard_slot = -1;
@@ -262,6 +267,7 @@ extern thread_local bool t_no_policy_timing;
 extern thread_local bool t_in_slab;
 inline bool next_reverse(Plan &p) { return tun(kT_zigzag) && (p.launches++ & 1u); }
 constexpr int kFlatSmallNnz = 24 << 20;
+inline long long flat_small_nnz() { return static_cast<long long>(tun(kT_flat_small_nnz_k)) << 10; } // (tunable: tests cross the rule at test size)
 int policy_for(const Plan &p, int fam);
 bool tune_log_enabled();
 void tune_log(const char *fmt, ...);
@@ -369,7 +375,9 @@ struct TuneTimer {
     // two timed launches instead of three: 3 launches per candidate instead of 5; the candidates of one phase are still measured alike)
     const bool lean = t_budget_spmvs > 0.0 && first >= 0.1f;
     const int warm = first < 0.1f ? 2 : (first < 2.0f && !lean ? 1 : 0);
-    const int timed = first < 0.1f ? 5 : (first < 0.5f ? (lean ? 2 : 3) : (first < 2.0f ? 2 : 1));
+    // (round 5: outside a budget -- spmv_acc_prepare -- five timed launches up to 0.5 ms and three up to 2 ms: the choices of a settled plan rest on
+    // medians of five, where candidates 1-2 % apart used to change places between processes on medians of three)
+    const int timed = first < 0.1f ? 5 : (first < 0.5f ? (lean ? 2 : 5) : (first < 2.0f ? (lean ? 2 : 3) : 1));
     for (int w = 0; w < warm; ++w) fn();
     if (reset_ptr && tun(kT_tune_protocol) == 1) {
       for (int t = 0; t < timed; ++t) {
@@ -394,7 +402,31 @@ struct TuneTimer {
     *ms_per_launch = ms / static_cast<float>(timed);
     return true;
   }
+  // Ranking candidates that are a few per cent apart (round 5): `rounds` rounds with the candidates TAKING TURNS inside each round -- two blocks of
+  // samples taken one after the other rank by the moment they were taken (clocks, what the other candidate left in the caches) as much as by the
+  // kernel --, each turn one time() (a median of several launches under the harness protocol); per candidate the median over its rounds counts.
+  // launch(c) launches candidate c; skip[c] (may be null) leaves a candidate out.  ms[c] is written for the candidates that ran.
+  template <typename F> bool time_in_turns(hipStream_t st, int n, F &&launch, int rounds, float *ms, const bool *skip = nullptr) {
+    constexpr int kMaxRounds = 5;
+    constexpr int kMaxCandidates = 4;
+    if (n > kMaxCandidates) return false;
+    rounds = rounds < 1 ? 1 : (rounds > kMaxRounds ? kMaxRounds : rounds);
+    float sample[kMaxCandidates][kMaxRounds];
+    for (int r = 0; r < rounds; ++r)
+      for (int c = 0; c < n; ++c) {
+        if (skip && skip[c]) continue;
+        if (!time(st, [&] { launch(c); }, &sample[c][r])) return false;
+      }
+    for (int c = 0; c < n; ++c) {
+      if (skip && skip[c]) continue;
+      std::sort(sample[c], sample[c] + rounds);
+      ms[c] = rounds == 2 ? sample[c][0] : sample[c][rounds / 2];
+    }
+    return true;
+  }
 };
+// rounds of a ranking between near-equal candidates: three where the call may spend (spmv_acc_prepare), one under a call's tuning budget
+inline int ranking_rounds() { return t_budget_spmvs > 0.0 ? 1 : 3; }
 
 // Time the stream-load cache policies on THIS matrix with the kernel family that will run it (scratch y, beta = 0:
 // no side effects on the caller's y) and keep the fastest.  Up to eight launches per candidate (TuneTimer: 3 to reach

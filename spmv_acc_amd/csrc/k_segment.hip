@@ -333,7 +333,7 @@ bool launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds 
   if (S < 1 || S > kSegMaxPlanes) return false; // (one counter per plane in 16 lanes / 16 packed bytes)
   if (A.m <= 0) return true;
   long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row ...
-  if (blocks > kMaxGridBlocks) blocks = kMaxGridBlocks;                                               // ... up to what a launch holds
+  if (blocks > max_grid_blocks()) blocks = max_grid_blocks();                                         // ... up to what a launch holds
   hipLaunchKernelGGL(segment_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S, cnt,
                      beg, not_monotone, rest_below);
   const long long short_blocks = (static_cast<long long>(A.m) + 1 + kThreads - 1) / kThreads; // m + 1: the closing zeros

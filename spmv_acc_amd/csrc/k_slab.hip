@@ -128,7 +128,7 @@ void launch_slab_merge(hipStream_t stream, int ms, const int *rowid, const doubl
 void launch_slab_count(hipStream_t stream, const CsrDev &A, int width, int S, int *cnt) {
   if (A.m <= 0) return;
   long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row ...
-  if (blocks > kMaxGridBlocks) blocks = kMaxGridBlocks;                                               // ... up to what a launch holds
+  if (blocks > max_grid_blocks()) blocks = max_grid_blocks();                                         // ... up to what a launch holds
   hipLaunchKernelGGL(slab_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, width, S, cnt);
 }
 
@@ -136,7 +136,7 @@ void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, 
                          double *v_out, bool values_only) {
   if (A.m <= 0) return;
   long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave);
-  if (blocks > kMaxGridBlocks) blocks = kMaxGridBlocks;
+  if (blocks > max_grid_blocks()) blocks = max_grid_blocks();
   hipLaunchKernelGGL(slab_scatter_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.v, A.m, width, S,
                      rps, off, ci_out, v_out, values_only ? 1 : 0);
 }

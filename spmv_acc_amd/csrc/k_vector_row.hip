@@ -312,13 +312,13 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
   if (A.m <= 0) return;
   if (row_split < 0) row_split = 0;
   if (row_split > A.m) row_split = A.m;
-  const long long avg = static_cast<long long>(A.nnz) / A.m;
+  const long long avg = static_cast<long long>(A.count()) / A.m;
   const int wide = w0 > w1 ? w0 : w1;
   // rows per lane group: 1 when rows outgrow the hoisted steps, or when the caller knows the row lengths are very uneven
   // (four hub rows of a power-law matrix in one group would run one after the other)
   const int rows = (single_row_groups || avg > 2LL * wide) ? 1 : 4;
   // (a forced width on a matrix of very many short rows would need more workgroups than a launch holds: narrower lane groups then)
-  while ((static_cast<long long>(A.m) + rows * (kThreads / (w0 > w1 ? w0 : w1)) - 1) / (rows * (kThreads / (w0 > w1 ? w0 : w1))) + 1 > kMaxGridBlocks &&
+  while ((static_cast<long long>(A.m) + rows * (kThreads / (w0 > w1 ? w0 : w1)) - 1) / (rows * (kThreads / (w0 > w1 ? w0 : w1))) + 1 > max_grid_blocks() &&
          (w0 > 1 || w1 > 1)) {
     if (w0 > 1) w0 >>= 1;
     if (w1 > 1) w1 >>= 1;
@@ -366,7 +366,7 @@ void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int 
 void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double beta, const double *x, double *y) {
   if (A.m <= 0) return;
   int grid = ceil_div_ll(A.m, kThreads / kWave);
-  if (grid > kMaxGridBlocks) grid = kMaxGridBlocks;
+  if (grid > max_grid_blocks()) grid = max_grid_blocks();
   hipLaunchKernelGGL(wave_row_kernel, dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci, A.v,
                      x, y, A.yin ? A.yin : y, A.guard, A.stale);
 }

@@ -77,6 +77,7 @@ constexpr int kThreads = 256;             // 4 waves per workgroup
 // wavefront per row = 17.5 M workgroups ran the first 2.9 M rows and reported nothing).  Kernels whose grid grows with m alone stride over a capped,
 // prime number of workgroups (prime: a power-of-two stride gives one wavefront all the hub rows of an R-MAT matrix, k_segment.hip).
 constexpr int kMaxGridBlocks = 8388593;
+int max_grid_blocks(); // = kMaxGridBlocks unless a test lowered it (tunable max_grid_blocks, config.cpp): what the launchers clamp their grids to
 constexpr int kNnzPerThread = 8;          // two 4-wide steps per lane per round
 constexpr int kTile = kThreads * kNnzPerThread; // 2048 products = 16 KB of LDS per workgroup
 constexpr int kPlusThreads = 256;         // row-block-plus ANALYSIS geometry: the reference's (THREADS 256, R 2,

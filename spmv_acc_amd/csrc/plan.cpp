@@ -159,7 +159,7 @@ unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *sample
   static const char kBuild[] = __DATE__ " " __TIME__;
   mix(kBuild, sizeof(kBuild));
   for (TunableId id : {kT_rowblock_target, kT_vector_target, kT_hint_budget_kb, kT_tune_protocol, kT_cache_ends_mb, kT_zigzag, kT_xcd_chunk, kT_xcd_chunk_tiles,
-                       kT_slab_whole_below, kT_rowlen, kT_legacy_kernels}) {
+                       kT_slab_whole_below, kT_rowlen, kT_legacy_kernels, kT_slab_kb, kT_hint_min_x_mb, kT_flat_small_nnz_k, kT_max_grid_blocks}) {
     const int v = tun(id);
     mix(&v, sizeof(int));
   }
@@ -518,7 +518,8 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->adaptive_family = afam;
       out->adaptive_family_beta0 = p.adaptive_family[0];
       out->settled = p.calls > 0 && !p.tuning_open ? 1 : 0;
-      out->slab_passes = p.seg_state == 1 && (tun(kT_slab_segments) >= 2 || (tun(kT_slab_segments) < 0 && p.seg_choice == 1)) ? p.seg_slabs - (p.seg_rest_below > 0 ? 1 : 0) : 0; // (column slabs: the whole-row pass of the two-class form is not counted)
+      out->last_kernel = p.last_kernel;
+      out->slab_passes = p.seg_state == 1 && (tun(kT_slab_segments) >= 1 || (tun(kT_slab_segments) < 0 && p.seg_choice == 1)) ? p.seg_slabs - (p.seg_rest_below > 0 ? 1 : 0) : 0; // (column slabs: the whole-row pass of the two-class form is not counted)
       return true;
     }
   }

@@ -390,7 +390,7 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
     F.needs_fixup = F.mode_tuned[cls ^ 1] ? F.tuned_fixup[cls ^ 1] : false;
     return true;
   }
-  if (t_coarse_tuning && p.A.count() >= kFlatSmallNnz) { // (small matrices: the timings are cheap and decide the comparison)
+  if (t_coarse_tuning && p.A.count() >= flat_small_nnz()) { // (small matrices: the timings are cheap and decide the comparison)
     F.needs_fixup = true;
     return true;
   }
@@ -417,7 +417,7 @@ bool autotune_flat_mode(Plan &p, hipStream_t st, const double *x) {
 // the tile whenever that is legal (no second launch: what wins on short kernels).
 bool autotune_flat_geometry(Plan &p, hipStream_t st, const double *x) {
   if (p.flat_geometry_tuned || tun(kT_col16) > 0 || flat_segment_sum() || t_capturing || by_rule()) return true;
-  if (p.A.count() >= kFlatSmallNnz || p.flat.ntiles <= 1) {
+  if (p.A.count() >= flat_small_nnz() || p.flat.ntiles <= 1) {
     p.flat_geometry_tuned = true;
     return true;
   }
@@ -487,7 +487,7 @@ bool ensure_hint(Plan &p, hipStream_t st) {
   // (and while x lives in the 256 MB Infinity Cache beside the rest of the working set a cold gather is a hit there, which a non-temporal
   // load forfeits: R-MAT scale 21 / 22 / 23, x = 16 / 32 / 64 MB: hinted 268 / 604 / 1343 us against 212 / 477 / 1250 plain; scale 24 / 25,
   // x = 128 / 256 MB: 3.03 / 7.2 ms against 3.38 / 8.2 -- the timed choice gets all five right, this bound just saves the census)
-  if (mode < 0 && static_cast<long long>(A.n) * 8 < (96LL << 20)) return true;
+  if (mode < 0 && static_cast<long long>(A.n) * 8 < (static_cast<long long>(tun(kT_hint_min_x_mb)) << 20)) return true;
   ++t_plan_work;
   const auto census_t0 = std::chrono::steady_clock::now();
   const int nlines = (A.n + (1 << kHintLineShift) - 1) >> kHintLineShift;

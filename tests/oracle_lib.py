@@ -46,6 +46,9 @@ def lib():
         L.oracle_host_spmv_plain.restype = None
         L.oracle_host_spmv_omp.argtypes = [cd, cd, _dp, _ip, _ip, ci, _dp, _dp, ci]
         L.oracle_host_spmv_omp.restype = None
+        L.oracle_host_spmv_bench.argtypes = [cd, cd, _dp, _ip, _ip, ci, ci, _dp, _dp, _dp, ci, ci, _dp]
+        L.oracle_stream_triad_gbs.argtypes = [ctypes.c_longlong, ci, ci]
+        L.oracle_stream_triad_gbs.restype = cd
         L.oracle_verify.argtypes = [_dp, _dp, ci]
         L.oracle_verify_y.argtypes = [_dp, _dp, ci, _dp, _ip, _ip]
         L.oracle_verify_y.restype = None
@@ -135,6 +138,22 @@ def host_spmv_omp(alpha, beta, rowptr, cols, vals, x, y, threads):
     """In-place multi-threaded form (for timing)."""
     m = rowptr.size - 1
     lib().oracle_host_spmv_omp(alpha, beta, _d(vals), _i(rowptr), _i(cols), m, _d(x), _d(y), threads)
+
+
+def host_spmv_bench(alpha, beta, rowptr, cols, vals, x, y0, threads, reps):
+    """The timed form of the CPU baseline (first-touch placement by the reading threads, y restored before every run): returns
+    (seconds per run, y of the last run)."""
+    m = len(rowptr) - 1
+    secs = np.zeros(reps, dtype=np.float64)
+    y = np.empty(m, dtype=np.float64)
+    rc = lib().oracle_host_spmv_bench(alpha, beta, _d(vals), _i(rowptr), _i(cols), m, len(x), _d(x), _d(y0), _d(y), threads, reps, _d(secs))
+    if rc != 0:
+        raise MemoryError("oracle_host_spmv_bench: allocation failed")
+    return secs, y
+
+
+def stream_triad_gbs(elems, threads, reps=5):
+    return float(lib().oracle_stream_triad_gbs(int(elems), threads, reps))
 
 
 def host_spmv_inplace(alpha, beta, rowptr, cols, vals, x, y):

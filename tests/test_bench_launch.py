@@ -30,6 +30,28 @@ def test_gpus_n_without_world_size_launches_its_own_ranks():
     assert "launching 2 ranks" in r.stderr
 
 
+def test_eight_ranks_print_one_short_line_with_every_multi_gpu_key():
+    """What the driver will run once, on a node this builder never sees: `bench.py --gpus 8`.  Eight gloo ranks on CPU go through the N > 1
+    machinery that needs no GPU -- self-launch, rendezvous, the repeated K-step regions with MAX over ranks per repetition, the collective
+    time-budget decision -- and rank 0's line, made by compact_line() from a record with EVERY key of a real N > 1 run, stays below 6 KB."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1"], env=_env(SPMV_ACC_BENCH_DRYRUN="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 6000, (len(lines), len(lines[0]))
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_sum"] == 36.0 and out["launched_by"] == "self"
+    assert out["rccl"] == {"ranks": 8, "ranks_ok": True}
+    # every repetition is the MAX over ranks: rank 7's fake step sleeps 8 ms
+    assert out["ms_per_step"] >= 8.0, out["ms_per_step"]
+    for key in ("exchange", "spmv_only_gflops_per_gpu", "spmv_only_ms_max_over_ranks", "spmv_plus_exchange_ms_per_step",
+                "spmv_plus_exchange_gflops_total", "allgather_bytes_per_rank_per_step", "dependent_step_ms_by_pipeline", "pipeline_best",
+                "banded", "strong_scaling", "roofline", "cpu_baseline", "config", "region_reps"):
+        assert key in out, key
+    assert out["banded"]["halo_exchange"]["ms_per_step"] > 0 and out["strong_scaling"]["gflops_total"] > 0
+    assert out["time_left_s"] > 0  # the collective budget decision ran (minimum over ranks)
+
+
 def test_launched_by_torch_distributed_run_it_is_an_ordinary_rank():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29617", BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"]

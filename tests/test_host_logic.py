@@ -320,3 +320,32 @@ def test_reference_flat_benchmark_tu_builds_against_include(hiplib, tmp_path):
         assert name in defined, name
     # it loads and runs to main() without a GPU (the SpMV calls sit behind a false test)
     assert subprocess.run([exe], capture_output=True, timeout=60).returncode == 0
+
+
+def test_every_size_threshold_names_a_test():
+    """tests/size_thresholds.py: every size-selected branch of the engine is registered with the test(s) that cross it; every named constant of the
+    engine's sources is either such a rule or listed as geometry.  (Round 4's wrong-result regression sat behind a size rule no test crossed.)"""
+    import glob
+    import re
+
+    import size_thresholds as st
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    test_text = "\n".join(open(f).read() for f in glob.glob(os.path.join(root, "tests", "test_*.py")))
+    defined = set(re.findall(r"^def (test_\w+)\(", test_text, flags=re.M))
+    registered = set()
+    for name, path, pattern, tests, what in st.SIZE_RULES:
+        src = open(os.path.join(root, path)).read()
+        assert re.search(pattern, src), f"{name}: the rule is no longer where the registry says ({path}: {pattern}) -- re-register it"
+        assert tests, name
+        for t in tests:
+            assert t in defined, f"{name}: names the test {t}, which does not exist"
+        registered.update(re.findall(r"k[A-Z]\w+", name))
+    found = {}
+    for path in st.SCANNED:
+        for const in re.findall(r"constexpr\s+[\w:<> ]+?\s+(k[A-Z]\w*)\s*=", open(os.path.join(root, path)).read()):
+            found[const] = path
+    unknown = sorted(c for c in found if c not in registered and c not in st.NOT_SIZE_RULES)
+    assert not unknown, f"constants neither registered as size rules nor listed as geometry in tests/size_thresholds.py: {[(c, found[c]) for c in unknown]}"
+    stale = sorted(c for c in st.NOT_SIZE_RULES if c not in found)
+    assert not stale, f"tests/size_thresholds.py lists constants that no longer exist: {stale}"

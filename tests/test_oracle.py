@@ -56,6 +56,22 @@ def test_host_spmv_omp_bit_identical(oracle):
         assert np.array_equal(y, ref)
 
 
+def test_host_spmv_bench_form_is_the_same_arithmetic(oracle):
+    """bench.py's cpu_baseline times oracle_host_spmv_bench (arrays re-placed by first touch, y restored before every run): per row
+    the arithmetic of cli/verification.cpp:56-66 still, so y is bitwise the sequential form's -- for any thread count, a rectangular
+    matrix (x is placed by column ranges n/m per row), empty rows and more threads than rows."""
+    rng = np.random.default_rng(7)
+    for m, n, avg, kind in ((5000, 3000, 7, "powerlaw"), (300, 9000, 3, "uniform"), (5, 40, 2, "uniform")):
+        rowptr, cols, vals = synth.random_csr(m, n, avg, seed=m, kind=kind)
+        x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+        ref = oracle.host_spmv(0.5, -2.0, rowptr, cols, vals, x, y0)
+        for t in (1, 3, 8):
+            secs, y = oracle.host_spmv_bench(0.5, -2.0, rowptr, cols, vals, x, y0, t, 3)
+            assert np.array_equal(y, ref), (m, n, t)
+            assert secs.shape == (3,) and (secs >= 0).all()
+    assert oracle.stream_triad_gbs(1 << 16, 2, 2) > 0
+
+
 def test_verify_thresholds(oracle):
     hy = np.array([1.0, 2.0, 1e-13, 0.0, 5.0])
     assert oracle.verify(hy.copy(), hy) == -1  # 0/0 = NaN passes, as in the reference
