@@ -353,6 +353,14 @@ int spmv_acc_time_spmv_events(int strategy, int iters, double alpha, double beta
 int spmv_acc_time_spmv_total(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
                              const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
                              const double *dx, double *dy, float *total_ms_out);
+/* The per-launch protocol once more, with the library's KERNEL CLOCK on (round 5): event_ms_out[i] (may be NULL) is the event pair around call i as
+ * above -- the reference harness's figure, which also holds the protocol's floor (two marker packets and the dispatch latency: ~4-7 us on MI355X) --
+ * and kernel_ms_out[i] the sum of the durations of the kernels call i launched, each read from the dispatch's own begin / end timestamps
+ * (hipExtLaunchKernelGGL start / stop events: what rocprofv3 --kernel-trace reports).  launches_out[i] (may be NULL): kernels per call.
+ * replaces: nothing in the reference (its harness has the event pair only, benchmark/utils/timer_utils.h:16-51). */
+int spmv_acc_time_spmv_kernels(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
+                               const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
+                               const double *dx, double *dy, const double *d_y0, float *event_ms_out, float *kernel_ms_out, int *launches_out);
 /* The same region and NOTHING else (round 5): no plan work -- the caller settles the plan first (spmv_acc_prepare_beta) --, no allocation, the
  * event pair is made once per host thread.  A wall clock around this call, between two device synchronisations, reads the K launches' own time
  * (bench.py's `value` / `ms_per_step`: median over repeated regions, the reference's median rule, benchmark/utils/benchmark_time.cpp:23-43). */

@@ -39,7 +39,7 @@ C_ABI_SYMBOLS = (
     "spmv_acc_last_prepare_us", "spmv_acc_sharded_spmv", "spmv_acc_shard_prepare", "spmv_acc_csr_spmv_chunks", "spmv_acc_query_plan_settled", "spmv_acc_csr_spmv_oop", "spmv_acc_check_plans",
     "spmv_acc_query_plan_beta0", "spmv_acc_query_plan_slab_passes", "spmv_acc_shard_create", "spmv_acc_shard_step", "spmv_acc_shard_pipeline",
     "spmv_acc_shard_destroy", "spmv_acc_rccl_comm_init_all", "spmv_acc_rccl_comm_destroy", "spmv_acc_set_tune_cache",
-    "spmv_acc_prepare_beta", "spmv_acc_time_spmv_events", "spmv_acc_refresh_values", "spmv_acc_time_spmv_region", "spmv_acc_query_plan_last_kernel",
+    "spmv_acc_prepare_beta", "spmv_acc_time_spmv_events", "spmv_acc_refresh_values", "spmv_acc_time_spmv_region", "spmv_acc_query_plan_last_kernel", "spmv_acc_time_spmv_kernels",
 )
 
 _lib = None
@@ -106,6 +106,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_get_tunable.argtypes = [ctypes.c_char_p]
     lib.spmv_acc_reset_tunables.restype = None
     lib.spmv_acc_time_spmv_total.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+    lib.spmv_acc_time_spmv_kernels.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.spmv_acc_time_spmv_region.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.spmv_acc_copy_ceiling_gbs.argtypes = [vp, vp, ctypes.c_longlong, ci]
     lib.spmv_acc_copy_ceiling_gbs.restype = cd
@@ -341,6 +342,22 @@ def time_spmv_total(strategy, iters: int, alpha: float, beta: float, m: int, n: 
     if rc != 0:
         raise SpmvAccError(f"time_spmv_total failed ({rc}): {lib.spmv_acc_last_error_string().decode()}")
     return float(out.value)
+
+
+def time_spmv_kernels(strategy, iters: int, alpha: float, beta: float, m: int, n: int, nnz: int, rowptr, colindex, value, x, y, y0=None):
+    """The per-launch protocol with the library's kernel clock on: returns (event_ms, kernel_ms, launches) per call -- the event pair around
+    the call (the reference harness's figure) and the sum of the call's own kernel durations (what rocprofv3 --kernel-trace reports)."""
+    lib = load_library()
+    _csr_args(lib, m, n, nnz, rowptr, colindex, value, x, y, y0)
+    ev = (ctypes.c_float * iters)()
+    kn = (ctypes.c_float * iters)()
+    ln = (ctypes.c_int * iters)()
+    rc = lib.spmv_acc_time_spmv_kernels(strategy_id(strategy), iters, alpha, beta, m, n, nnz, None, _ptr(rowptr), _ptr(colindex), _ptr(value),
+                                        _ptr(x), _ptr(y), _ptr(y0), ctypes.cast(ev, ctypes.c_void_p), ctypes.cast(kn, ctypes.c_void_p),
+                                        ctypes.cast(ln, ctypes.c_void_p))
+    if rc != 0:
+        raise SpmvAccError(f"time_spmv_kernels failed ({rc}): {lib.spmv_acc_last_error_string().decode()}")
+    return list(ev), list(kn), list(ln)
 
 
 def time_spmv_region(strategy, iters: int, alpha: float, beta: float, m: int, n: int, nnz: int, rowptr, colindex, value, x, y):

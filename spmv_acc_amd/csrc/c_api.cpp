@@ -541,6 +541,64 @@ int spmv_acc_time_spmv_total(int strategy, int iters, double alpha, double beta,
   return rc;
 }
 
+// The per-launch protocol of spmv_acc_time_spmv_events with the KERNEL CLOCK on (round 5): besides the event pair around every call -- the
+// reference harness's figure, which holds the marker packets and the dispatch latency of the protocol too -- every kernel the call launches carries
+// its own start / stop events (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps, what rocprofv3 --kernel-trace reports), and
+// kernel_ms_out[i] is their SUM over call i's launches: the call's kernel time without the gaps.  launches_out (may be null): kernels per call.
+int spmv_acc_time_spmv_kernels(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
+                               const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
+                               const double *dx, double *dy, const double *d_y0, float *event_ms_out, float *kernel_ms_out, int *launches_out) {
+  if (iters <= 0 || !kernel_ms_out) {
+    set_error(kErrBadArgument, "spmv_acc_time_spmv_kernels: bad argument");
+    return kErrBadArgument;
+  }
+  if (spmv_acc_prepare_beta(strategy, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, nullptr) != kOk) return last_error();
+  hipStream_t st = get_stream();
+  std::vector<hipEvent_t> ev(2 * static_cast<size_t>(iters));
+  for (auto &e : ev) {
+    if (hipEventCreate(&e) != hipSuccess) {
+      set_error(kErrHip, "hipEventCreate failed");
+      return kErrHip;
+    }
+  }
+  clear_error();
+  const size_t ybytes = sizeof(double) * static_cast<size_t>(m);
+  std::vector<size_t> first(static_cast<size_t>(iters) + 1, 0);
+  kernel_clock_begin();
+  for (int i = 0; i < iters; ++i) {
+    if (d_y0) { // y reset outside both clocks (the copy is launched with the kernel clock off)
+      if (ybytes % 16 == 0 && reinterpret_cast<uintptr_t>(dy) % 16 == 0 && reinterpret_cast<uintptr_t>(d_y0) % 16 == 0)
+        launch_stream_copy(st, dy, d_y0, static_cast<long long>(ybytes), false);
+      else
+        (void)hipMemcpyAsync(dy, d_y0, ybytes, hipMemcpyDeviceToDevice, st);
+    }
+    (void)hipEventRecord(ev[2 * i], st);
+    first[i] = kernel_clock_used();
+    kernel_clock_set(true);
+    run_spmv(strategy, 0, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy);
+    kernel_clock_set(false);
+    (void)hipEventRecord(ev[2 * i + 1], st);
+  }
+  first[iters] = kernel_clock_used();
+  int rc = hipStreamSynchronize(st) == hipSuccess ? kOk : kErrHip;
+  if (kernel_clock_failed()) rc = kErrHip;
+  for (int i = 0; i < iters && rc == kOk; ++i) {
+    float ms = 0.f;
+    if (event_ms_out && hipEventElapsedTime(&event_ms_out[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = kErrHip;
+    double sum = 0.0;
+    for (size_t k = first[i]; k + 1 < first[i + 1] + 1 && k < first[i + 1] && rc == kOk; k += 2) {
+      if (hipEventElapsedTime(&ms, kernel_clock_event(k), kernel_clock_event(k + 1)) != hipSuccess) rc = kErrHip;
+      sum += ms;
+    }
+    kernel_ms_out[i] = static_cast<float>(sum);
+    if (launches_out) launches_out[i] = static_cast<int>((first[i + 1] - first[i]) / 2);
+  }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  if (rc != kOk) set_error(kErrHip, "spmv_acc_time_spmv_kernels: HIP failure while timing");
+  if (rc == kOk && last_error() != kOk) rc = last_error();
+  return rc;
+}
+
 // One timed REGION and nothing else (round 5; bench.py's `value`): `iters` back-to-back launches between one event pair -- no plan work (the caller
 // has settled the plan: spmv_acc_prepare), no allocation, no event creation (one event pair per host thread, made on first use) -- so that a
 // wall clock around this call, bracketed by device synchronisations, reads the launches' own time.  (spmv_acc_time_spmv_total settles the plan

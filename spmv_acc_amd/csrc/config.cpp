@@ -176,7 +176,8 @@ Tunable g_tunables[] = {
                                // over those runs, each gathering from 1/S of x.  -1 = on matrices whose column census finds a hot set (the
                                // matrices that get gather hints: power-law columns, x far beyond the L2s) 8 slabs are built and timed once
                                // against the row-block-plus kernel, the faster stays (R-MAT scale 25: 7.3 -> 5.3 ms; with `deterministic`, which
-                               // times nothing, the row-block-plus kernel stays); 0 = off; S >= 2 = always,
+                               // times nothing, the row-block-plus kernel stays); 0 = off; 1 = always, with the AUTOMATIC slab count (the x-size
+                               // rule, tunable slab_kb: what tests use to reach the maximum count at test size); S >= 2 = always,
                                // whatever the strategy (rows that are not ordered: the ordinary path)
     {"vector_target", 1900, 1900}, // vector-row tile kernel: products a workgroup's rows should bring to its 2048-product tile (the row-block family's
                                // `rowblock_target` went to 1500 in round 3; this kernel, with two rows per lane group, keeps the fuller tile:
@@ -218,6 +219,49 @@ inline bool tunable_order_ok() {
 void apply_env_tunables();
 
 } // namespace detail
+// ---- kernel clock (kernels.hpp SPMV_ACC_LAUNCH): per host thread, a growing pool of event pairs, one pair per launch while the clock is on ----
+namespace detail {
+struct KernelClock {
+  bool on = false;
+  int device = -1;
+  std::vector<hipEvent_t> pool; // pairs: [2k] start, [2k + 1] stop
+  size_t used = 0;              // events handed out since kernel_clock_begin
+  bool failed = false;
+};
+thread_local KernelClock t_kclock;
+} // namespace detail
+void kernel_clock_begin() {
+  using detail::t_kclock;
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  if (dev != t_kclock.device) { // (events belong to a device: a thread that moved on starts a new pool; the old events go with the process)
+    t_kclock.pool.clear();
+    t_kclock.device = dev;
+  }
+  t_kclock.used = 0;
+  t_kclock.failed = false;
+}
+void kernel_clock_set(bool on) { detail::t_kclock.on = on; }
+size_t kernel_clock_used() { return detail::t_kclock.used; }
+bool kernel_clock_failed() { return detail::t_kclock.failed; }
+hipEvent_t kernel_clock_event(size_t i) { return i < detail::t_kclock.pool.size() ? detail::t_kclock.pool[i] : nullptr; }
+bool kernel_clock_next(hipEvent_t *start, hipEvent_t *stop) {
+  detail::KernelClock &k = detail::t_kclock;
+  if (!k.on) return false;
+  while (k.pool.size() < k.used + 2) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) {
+      (void)hipGetLastError();
+      k.failed = true;
+      return false; // (the launch goes out plain; the timing entry reports the failure)
+    }
+    k.pool.push_back(e);
+  }
+  *start = k.pool[k.used];
+  *stop = k.pool[k.used + 1];
+  k.used += 2;
+  return true;
+}
 int max_grid_blocks() {
   const int v = detail::g_tunables[detail::kT_max_grid_blocks].val;
   return v >= 64 && v <= kMaxGridBlocks ? v : kMaxGridBlocks;

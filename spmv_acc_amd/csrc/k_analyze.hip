@@ -148,7 +148,7 @@ bool plus_analyze_device_count(hipStream_t stream, const int *rp, int m, int min
   const int cap = threads_per_block / vec_size;
   const int g = grid_for(static_cast<long long>(n));
 
-  hipLaunchKernelGGL(next_kernel, dim3(g), dim3(256), 0, stream, rp, m, min_nnz, cap, next);
+  SPMV_ACC_LAUNCH(next_kernel, dim3(g), dim3(256), 0, stream, rp, m, min_nnz, cap, next);
   (void)hipMemsetAsync(reach, 0, n, stream);
   (void)hipMemsetAsync(reach, 1, 1, stream); // row 0 opens the first block
   (void)hipMemcpyAsync(ja, next, 4 * n, hipMemcpyDeviceToDevice, stream);
@@ -156,12 +156,12 @@ bool plus_analyze_device_count(hipStream_t stream, const int *rp, int m, int min
   int rounds = 1;
   while ((1LL << rounds) < static_cast<long long>(m) + 1) ++rounds;
   for (int k = 0; k < rounds; ++k) {
-    hipLaunchKernelGGL(jump_kernel, dim3(g), dim3(256), 0, stream, m, ja, jb, reach);
+    SPMV_ACC_LAUNCH(jump_kernel, dim3(g), dim3(256), 0, stream, m, ja, jb, reach);
     int *t = ja;
     ja = jb;
     jb = t;
   }
-  hipLaunchKernelGGL(count_kernel, dim3(g), dim3(256), 0, stream, rp, m, min_nnz, next, reach, cnt);
+  SPMV_ACC_LAUNCH(count_kernel, dim3(g), dim3(256), 0, stream, rp, m, min_nnz, next, reach, cnt);
   size_t scan_bytes = 0;
   (void)rocprim::exclusive_scan(nullptr, scan_bytes, cnt, base, 0, n, rocprim::plus<int>(), stream);
   if (rocprim::exclusive_scan(scan_tmp, scan_bytes, cnt, base, 0, n, rocprim::plus<int>(), stream) != hipSuccess)
@@ -186,8 +186,8 @@ void plus_analyze_device_emit(hipStream_t stream, const int *rp, int m, int min_
     return;
   }
   const int g = grid_for(m);
-  hipLaunchKernelGGL((emit_kernel<0>), dim3(g), dim3(256), 0, stream, rp, m, min_nnz, next, reach, base, d_bp, d_fbr);
-  hipLaunchKernelGGL((emit_kernel<1>), dim3(g), dim3(256), 0, stream, rp, m, min_nnz, next, reach, base, d_bp, d_fbr);
+  SPMV_ACC_LAUNCH((emit_kernel<0>), dim3(g), dim3(256), 0, stream, rp, m, min_nnz, next, reach, base, d_bp, d_fbr);
+  SPMV_ACC_LAUNCH((emit_kernel<1>), dim3(g), dim3(256), 0, stream, rp, m, min_nnz, next, reach, base, d_bp, d_fbr);
 }
 
 } // namespace spmv_acc

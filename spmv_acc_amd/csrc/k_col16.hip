@@ -125,7 +125,7 @@ size_t col16_scan_bytes(int nchunks) {
 void launch_col16_base(hipStream_t stream, const int *ci, int nnz, int nchunks, int *base, int *esc_count) {
   if (nchunks <= 0) return;
   const int waves_per_block = kThreads / kWave;
-  hipLaunchKernelGGL(col16_base_kernel, dim3((nchunks + waves_per_block - 1) / waves_per_block), dim3(kThreads), 0, stream, ci, nnz,
+  SPMV_ACC_LAUNCH(col16_base_kernel, dim3((nchunks + waves_per_block - 1) / waves_per_block), dim3(kThreads), 0, stream, ci, nnz,
                      nchunks, base, esc_count);
 }
 
@@ -139,7 +139,7 @@ void launch_col16_encode(hipStream_t stream, const int *ci, int nnz, int nchunks
                          unsigned short *d16, int *esc_cols) {
   if (nchunks <= 0) return;
   const int waves_per_block = kThreads / kWave;
-  hipLaunchKernelGGL(col16_encode_kernel, dim3((nchunks + waves_per_block - 1) / waves_per_block), dim3(kThreads), 0, stream, ci, nnz,
+  SPMV_ACC_LAUNCH(col16_encode_kernel, dim3((nchunks + waves_per_block - 1) / waves_per_block), dim3(kThreads), 0, stream, ci, nnz,
                      nchunks, base, esc_start, d16, esc_cols);
 }
 

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void flat_fixup_kernel(int ntiles, int stride,
 
 void launch_break_points_from(hipStream_t stream, const int *rp, int m, int nnz, int stride, int tile0, int *bp, int bp_len) {
   if (bp_len <= 0) return;
-  hipLaunchKernelGGL(break_points_kernel, dim3((bp_len + 255) / 256), dim3(256), 0, stream, rp, m, nnz, stride, tile0, bp,
+  SPMV_ACC_LAUNCH(break_points_kernel, dim3((bp_len + 255) / 256), dim3(256), 0, stream, rp, m, nnz, stride, tile0, bp,
                      bp_len);
 }
 void launch_break_points(hipStream_t stream, const int *rp, int m, int nnz, int stride, int *bp, int bp_len) {
@@ -381,11 +381,11 @@ void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P,
                          double *y) {
   const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
   if (P.early_stream)
-    hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
+    SPMV_ACC_LAUNCH((flat_tile_kernel<NPT, NTC, NTV, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
                        P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
   else
-    hipLaunchKernelGGL((flat_tile_kernel<NPT, NTC, NTV, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
+    SPMV_ACC_LAUNCH((flat_tile_kernel<NPT, NTC, NTV, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
                        P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
 }
@@ -394,7 +394,7 @@ template <bool NTC, bool NTV>
 void launch_flat_segsum(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                         double *y) {
   const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
+  SPMV_ACC_LAUNCH((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
                      P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
                      static_cast<const int4v *>(P.digest), nullptr);
@@ -403,7 +403,7 @@ void launch_flat_segsum(hipStream_t stream, const CsrDev &A, const FlatPlan &P, 
 template <bool NTC, bool NTV>
 void launch_flat_hint(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x, double *y) {
   const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
+  SPMV_ACC_LAUNCH((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
                      P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
                      static_cast<const int4v *>(P.digest), A.cold);
@@ -413,7 +413,7 @@ template <bool NTV>
 void launch_flat_col16(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                        double *y) {
   const Col16Dev c = {P.col16->d16, P.col16->base, P.col16->esc_start, P.col16->esc_cols};
-  hipLaunchKernelGGL((flat_tile_kernel<kNnzPerThread, true, NTV, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
+  SPMV_ACC_LAUNCH((flat_tile_kernel<kNnzPerThread, true, NTV, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
                      P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, c, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
 }
@@ -431,13 +431,13 @@ void launch_flat_policy(hipStream_t stream, const CsrDev &A, const FlatPlan &P, 
 
 void launch_flat_digest(hipStream_t stream, const CsrDev &A, const FlatPlan &P) {
   if (P.ntiles <= 0) return;
-  hipLaunchKernelGGL(flat_digest_kernel, dim3((P.ntiles + 255) / 256), dim3(256), 0, stream, A.rp, P.bp, P.ntiles, A.m, A.nnz, P.stride,
+  SPMV_ACC_LAUNCH(flat_digest_kernel, dim3((P.ntiles + 255) / 256), dim3(256), 0, stream, A.rp, P.bp, P.ntiles, A.m, A.nnz, P.stride,
                      P.tile0, static_cast<int4v *>(P.digest));
 }
 
 void launch_flat_needs_fixup(hipStream_t stream, const CsrDev &A, const FlatPlan &P, int *d_flag) {
   if (P.ntiles <= 0) return;
-  hipLaunchKernelGGL(flat_needs_fixup_kernel, dim3((P.ntiles + 255) / 256), dim3(256), 0, stream, A.rp, P.bp, P.ntiles,
+  SPMV_ACC_LAUNCH(flat_needs_fixup_kernel, dim3((P.ntiles + 255) / 256), dim3(256), 0, stream, A.rp, P.bp, P.ntiles,
                      A.m, A.nnz, P.stride, P.tile0, d_flag);
 }
 
@@ -467,7 +467,7 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
   else if (npt == 16) launch_flat_policy<16>(stream, A, P, alpha, beta, x, y);
   else launch_flat_policy<8>(stream, A, P, alpha, beta, x, y);
   if (P.ntiles > 1 && P.needs_fixup) {
-    hipLaunchKernelGGL(flat_fixup_kernel, dim3((P.ntiles - 1 + 255) / 256), dim3(256), 0, stream, P.ntiles, P.stride,
+    SPMV_ACC_LAUNCH(flat_fixup_kernel, dim3((P.ntiles - 1 + 255) / 256), dim3(256), 0, stream, P.ntiles, P.stride,
                        P.tile0, alpha, beta, P.head, P.tail, P.tail_row, P.tail_end, y, A.yin ? A.yin : y);
   }
 }

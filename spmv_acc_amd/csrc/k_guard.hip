@@ -70,12 +70,12 @@ int rowptr_digest_parts(int m) {
 }
 
 void launch_rowptr_digest(hipStream_t stream, const int *rp, int m, unsigned long long *part) {
-  hipLaunchKernelGGL(rowptr_digest_kernel, dim3(rowptr_digest_parts(m)), dim3(kThreads), 0, stream, rp, static_cast<long long>(m) + 1, part);
+  SPMV_ACC_LAUNCH(rowptr_digest_kernel, dim3(rowptr_digest_parts(m)), dim3(kThreads), 0, stream, rp, static_cast<long long>(m) + 1, part);
 }
 
 void launch_rowptr_verdict(hipStream_t stream, const unsigned long long *part, int m, unsigned long long expected, int *stale,
                            unsigned long long *digest_out) {
-  hipLaunchKernelGGL(rowptr_verdict_kernel, dim3(1), dim3(kThreads), 0, stream, part, rowptr_digest_parts(m), expected, stale, digest_out);
+  SPMV_ACC_LAUNCH(rowptr_verdict_kernel, dim3(1), dim3(kThreads), 0, stream, part, rowptr_digest_parts(m), expected, stale, digest_out);
 }
 
 } // namespace spmv_acc

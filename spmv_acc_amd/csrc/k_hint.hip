@@ -101,21 +101,21 @@ __global__ __launch_bounds__(256) void hint_bits_kernel(const int *__restrict__ 
 void launch_hint_census(hipStream_t stream, const int *ci, int nnz, int ncols, int stride, int samples, unsigned *counts) {
   if (samples <= 0) return;
   const long long blocks = (static_cast<long long>(samples) + 255) / 256;
-  hipLaunchKernelGGL(hint_census_kernel, dim3(static_cast<unsigned>(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, ci, nnz, stride,
+  SPMV_ACC_LAUNCH(hint_census_kernel, dim3(static_cast<unsigned>(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, ci, nnz, stride,
                      samples, ncols, counts);
 }
 
 void launch_hint_hist(hipStream_t stream, const unsigned *counts, int nlines, unsigned *hist_lines, unsigned long long *hist_hits) {
   if (nlines <= 0) return;
   const long long blocks = (static_cast<long long>(nlines) + 256 * 64 - 1) / (256 * 64);
-  hipLaunchKernelGGL(hint_hist_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, counts, nlines, hist_lines, hist_hits);
+  SPMV_ACC_LAUNCH(hint_hist_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, counts, nlines, hist_lines, hist_hits);
 }
 
 void launch_hint_bits(hipStream_t stream, const int *ci, int nnz, int ncols, const unsigned *counts, unsigned threshold, unsigned char *bits) {
   const long long nbytes = (static_cast<long long>(nnz) + 7) / 8;
   if (nbytes <= 0) return;
   const long long blocks = (nbytes + 255) / 256;
-  hipLaunchKernelGGL(hint_bits_kernel, dim3(static_cast<unsigned>(blocks < 262144 ? blocks : 262144)), dim3(256), 0, stream, ci, nnz, ncols,
+  SPMV_ACC_LAUNCH(hint_bits_kernel, dim3(static_cast<unsigned>(blocks < 262144 ? blocks : 262144)), dim3(256), 0, stream, ci, nnz, ncols,
                      counts, threshold, bits, nbytes);
 }
 

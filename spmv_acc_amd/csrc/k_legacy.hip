@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void block_row_kernel(int m, int nnz, dou
 void launch_light(hipStream_t stream, const CsrDev &A, int w, int grid_blocks, unsigned *counter, double alpha, double beta, const double *x,
                   double *y) {
   if (A.m <= 0) return;
-  hipLaunchKernelGGL(light_kernel, dim3(grid_blocks), dim3(kThreads), 0, stream, A.m, w, alpha, beta, counter, A.rp, A.ci, A.v, x, y,
+  SPMV_ACC_LAUNCH(light_kernel, dim3(grid_blocks), dim3(kThreads), 0, stream, A.m, w, alpha, beta, counter, A.rp, A.ci, A.v, x, y,
                      A.yin ? A.yin : y, A.guard, A.stale);
 }
 
@@ -140,7 +140,7 @@ void launch_block_row(hipStream_t stream, const CsrDev &A, int grid_blocks, doub
   // (an ODD number of workgroups: with a power-of-two grid workgroup 0 would walk the rows k * grid, which on matrices whose row length follows
   // the bits of the row index -- R-MAT -- are all hubs)
   const int grid = A.m < grid_blocks ? A.m : (grid_blocks | 1);
-  hipLaunchKernelGGL(block_row_kernel, dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci, A.v, x, y,
+  SPMV_ACC_LAUNCH(block_row_kernel, dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci, A.v, x, y,
                      A.yin ? A.yin : y, A.guard, A.stale);
 }
 

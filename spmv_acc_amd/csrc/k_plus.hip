@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void plus_fixup_kernel(int m, int nblocks, dou
 void launch_plus_digest(hipStream_t stream, const CsrDev &A, const int *bp, const int *fbr, int nblocks, int long_chunk,
                         void *blk, int *d_has_long) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(plus_digest_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, A.m, nblocks, long_chunk, bp, fbr, A.rp,
+  SPMV_ACC_LAUNCH(plus_digest_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, A.m, nblocks, long_chunk, bp, fbr, A.rp,
                      static_cast<int4v *>(blk), d_has_long);
 }
 
@@ -205,7 +205,7 @@ void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *
                  const double *x, double *y, bool reverse) {
   if (nblocks <= 0) return;
 #define SPMV_ACC_LAUNCH_PLUS(NC, NV, H)                                                                             \
-  hipLaunchKernelGGL((plus_kernel<NC, NV, H>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk, \
+  SPMV_ACC_LAUNCH((plus_kernel<NC, NV, H>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk, \
                      alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, partial, A.m, A.guard, A.stale, reverse ? 1 : 0, \
                      A.cold)
   if (A.cold != nullptr) { // gather hints (kernels.hpp): cold gathers non-temporal
@@ -225,7 +225,7 @@ void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *
   }
 #undef SPMV_ACC_LAUNCH_PLUS
   if (has_long_rows) {
-    hipLaunchKernelGGL(plus_fixup_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, A.m, nblocks, alpha, beta,
+    SPMV_ACC_LAUNCH(plus_fixup_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, A.m, nblocks, alpha, beta,
                        bp, fbr, partial, y, A.yin ? A.yin : y);
   }
 }

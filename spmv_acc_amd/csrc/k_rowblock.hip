@@ -199,7 +199,7 @@ void launch_vec(hipStream_t stream, const CsrDev &A, const RowDigest *D, int rpb
   // bits 4-5 of the flags: cache policy of the stream loads (0 nt/nt, 1 plain/plain, 2 colindex plain + values nt,
   // 3 colindex nt + values plain)
 #define SPMV_ACC_LAUNCH_RB_H(NC, NV, LN, H)                                                                         \
-  hipLaunchKernelGGL((rowblock_stream_kernel<VEC, NC, NV, LN, H>), dim3(nblocks), dim3(kThreads), 0, stream, A.m,   \
+  SPMV_ACC_LAUNCH((rowblock_stream_kernel<VEC, NC, NV, LN, H>), dim3(nblocks), dim3(kThreads), 0, stream, A.m,   \
                      A.nnz, nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, A.guard, A.stale,             \
                      LN ? D->lens : static_cast<const unsigned char *>(nullptr),                                   \
                      LN ? D->base : static_cast<const int *>(nullptr), cache_ends, A.cold)
@@ -230,16 +230,16 @@ void launch_vec(hipStream_t stream, const CsrDev &A, const RowDigest *D, int rpb
 void launch_max_block_nnz(hipStream_t stream, const int *rp, int m, int rows_per_block, int avg_block, int *d_out) {
   const int nblocks = static_cast<int>((static_cast<long long>(m) + rows_per_block - 1) / rows_per_block);
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(max_block_nnz_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, rp, m, rows_per_block,
+  SPMV_ACC_LAUNCH(max_block_nnz_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, stream, rp, m, rows_per_block,
                      nblocks, avg_block, d_out);
 }
 
 void launch_row_digest(hipStream_t stream, const int *rp, int m, int rows_per_block, unsigned char *lens, int *base) {
   if (m <= 0 || rows_per_block <= 0) return;
   const int nblocks = static_cast<int>((static_cast<long long>(m) + rows_per_block - 1) / rows_per_block);
-  hipLaunchKernelGGL(row_digest_base_kernel, dim3((nblocks + 1 + 255) / 256), dim3(256), 0, stream, rp, m, rows_per_block, nblocks,
+  SPMV_ACC_LAUNCH(row_digest_base_kernel, dim3((nblocks + 1 + 255) / 256), dim3(256), 0, stream, rp, m, rows_per_block, nblocks,
                      base);
-  hipLaunchKernelGGL(row_digest_lens_kernel, dim3(static_cast<unsigned>((static_cast<long long>(m) + 255) / 256)), dim3(256), 0,
+  SPMV_ACC_LAUNCH(row_digest_lens_kernel, dim3(static_cast<unsigned>((static_cast<long long>(m) + 255) / 256)), dim3(256), 0,
                      stream, rp, m, rows_per_block, lens, base);
 }
 

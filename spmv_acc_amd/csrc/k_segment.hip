@@ -334,50 +334,50 @@ bool launch_segment_count(hipStream_t stream, const CsrDev &A, const SlabBounds 
   if (A.m <= 0) return true;
   long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row ...
   if (blocks > max_grid_blocks()) blocks = max_grid_blocks();                                         // ... up to what a launch holds
-  hipLaunchKernelGGL(segment_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S, cnt,
+  SPMV_ACC_LAUNCH(segment_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S, cnt,
                      beg, not_monotone, rest_below);
   const long long short_blocks = (static_cast<long long>(A.m) + 1 + kThreads - 1) / kThreads; // m + 1: the closing zeros
-  hipLaunchKernelGGL(segment_count_short_kernel, dim3(static_cast<unsigned>(short_blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S,
+  SPMV_ACC_LAUNCH(segment_count_short_kernel, dim3(static_cast<unsigned>(short_blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, B, S,
                      cnt, beg, not_monotone, rest_below);
   return true;
 }
 void launch_segment_pieces(hipStream_t stream, const int *cnt_s, int m, int piece_max, int *pieces) {
   const long long blocks = (static_cast<long long>(m) + 1 + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(segment_pieces_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, cnt_s, m, piece_max, pieces);
+  SPMV_ACC_LAUNCH(segment_pieces_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, cnt_s, m, piece_max, pieces);
 }
 void launch_segment_compact(hipStream_t stream, const int *cnt_s, const int *beg_s, const int *pos, int m, int piece_max, int *seg_row,
                             int *seg_begin, int *seg_len, int *has_pieces) {
   if (m <= 0) return;
   const long long blocks = (static_cast<long long>(m) + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(segment_compact_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, cnt_s, beg_s, pos, m, piece_max,
+  SPMV_ACC_LAUNCH(segment_compact_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, cnt_s, beg_s, pos, m, piece_max,
                      seg_row, seg_begin, seg_len, has_pieces);
 }
 void launch_segment_cost(hipStream_t stream, int entries, int *seg_len, int *cost) {
   const long long blocks = (static_cast<long long>(entries) + 1 + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(segment_cost_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, entries, seg_len, cost);
+  SPMV_ACC_LAUNCH(segment_cost_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, entries, seg_len, cost);
 }
 int segment_block_count(long long total_cost) { return static_cast<int>((total_cost + kSegCost - 1) / kSegCost); }
 void launch_segment_blocks(hipStream_t stream, int entries, int nblocks, const int *cptr, int *blk_first) {
   const long long blocks = (static_cast<long long>(nblocks) + 1 + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(segment_blocks_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, entries, nblocks, cptr, blk_first);
+  SPMV_ACC_LAUNCH(segment_blocks_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, entries, nblocks, cptr, blk_first);
 }
 void launch_segment_tiles(hipStream_t stream, int nblocks, double alpha, const int *blk_first, const int *seg_row, const int *seg_begin,
                           const int *vptr, const int *ci, const double *v, const double *x, double *ys, double *y, const unsigned char *cold) {
   if (nblocks <= 0) return;
   if (cold)
-    hipLaunchKernelGGL(segment_tile_kernel<true>, dim3(nblocks), dim3(kThreads), 0, stream, alpha, blk_first, seg_row, seg_begin, vptr, ci, v, x, ys, y, cold);
+    SPMV_ACC_LAUNCH(segment_tile_kernel<true>, dim3(nblocks), dim3(kThreads), 0, stream, alpha, blk_first, seg_row, seg_begin, vptr, ci, v, x, ys, y, cold);
   else
-    hipLaunchKernelGGL(segment_tile_kernel<false>, dim3(nblocks), dim3(kThreads), 0, stream, alpha, blk_first, seg_row, seg_begin, vptr, ci, v, x, ys, y, cold);
+    SPMV_ACC_LAUNCH(segment_tile_kernel<false>, dim3(nblocks), dim3(kThreads), 0, stream, alpha, blk_first, seg_row, seg_begin, vptr, ci, v, x, ys, y, cold);
 }
 void launch_segment_cut_list(hipStream_t stream, const int *cnt_s, const int *pos, int m, int piece_max, int *counter, int *cut) {
   if (m <= 0) return;
   const long long blocks = (static_cast<long long>(m) + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(segment_cut_list_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, cnt_s, pos, m, piece_max, counter, cut);
+  SPMV_ACC_LAUNCH(segment_cut_list_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, cnt_s, pos, m, piece_max, counter, cut);
 }
 void launch_segment_merge(hipStream_t stream, int ncut, const int *cut, int entries, const int *seg_row, const double *ys, double *y) {
   if (ncut <= 0) return;
   const long long blocks = (static_cast<long long>(ncut) + (kThreads / kWave) - 1) / (kThreads / kWave);
-  hipLaunchKernelGGL(segment_merge_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, ncut, cut, entries, seg_row, ys, y);
+  SPMV_ACC_LAUNCH(segment_merge_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, ncut, cut, entries, seg_row, ys, y);
 }
 
 } // namespace spmv_acc

@@ -113,23 +113,23 @@ __global__ __launch_bounds__(kThreads) void slab_merge_kernel(int ms, const int 
 
 void launch_slab_flags(hipStream_t stream, const int *rps, int m, int *flags) {
   const long long blocks = (static_cast<long long>(m) + 1 + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(slab_flags_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, rps, m, flags);
+  SPMV_ACC_LAUNCH(slab_flags_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, rps, m, flags);
 }
 void launch_slab_compact(hipStream_t stream, const int *rps, const int *pos, int m, int *rowid, int *crp) {
   const long long blocks = (static_cast<long long>(m) + 1 + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(slab_compact_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, rps, pos, m, rowid, crp);
+  SPMV_ACC_LAUNCH(slab_compact_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, rps, pos, m, rowid, crp);
 }
 void launch_slab_merge(hipStream_t stream, int ms, const int *rowid, const double *ys, double *y) {
   if (ms <= 0) return;
   const long long blocks = (static_cast<long long>(ms) + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(slab_merge_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, ms, rowid, ys, y);
+  SPMV_ACC_LAUNCH(slab_merge_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, ms, rowid, ys, y);
 }
 
 void launch_slab_count(hipStream_t stream, const CsrDev &A, int width, int S, int *cnt) {
   if (A.m <= 0) return;
   long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave); // one wavefront per row ...
   if (blocks > max_grid_blocks()) blocks = max_grid_blocks();                                         // ... up to what a launch holds
-  hipLaunchKernelGGL(slab_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, width, S, cnt);
+  SPMV_ACC_LAUNCH(slab_count_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, width, S, cnt);
 }
 
 void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, const int *rps, const long long *off, int *ci_out,
@@ -137,7 +137,7 @@ void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, 
   if (A.m <= 0) return;
   long long blocks = (static_cast<long long>(A.m) + (kThreads / kWave) - 1) / (kThreads / kWave);
   if (blocks > max_grid_blocks()) blocks = max_grid_blocks();
-  hipLaunchKernelGGL(slab_scatter_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.v, A.m, width, S,
+  SPMV_ACC_LAUNCH(slab_scatter_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.v, A.m, width, S,
                      rps, off, ci_out, v_out, values_only ? 1 : 0);
 }
 

@@ -327,10 +327,10 @@ void launch_vector_row(hipStream_t stream, const CsrDev &A, int row_split, int w
   const int nb1 = ceil_div_ll(A.m - row_split, rows * (kThreads / w1));
   if (nb0 + nb1 == 0) return;
   if (rows == 1)
-    hipLaunchKernelGGL(vector_row_kernel<1>, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1, alpha, beta,
+    SPMV_ACC_LAUNCH(vector_row_kernel<1>, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1, alpha, beta,
                        A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, A.guard, A.stale);
   else
-    hipLaunchKernelGGL(vector_row_kernel<4>, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1, alpha, beta,
+    SPMV_ACC_LAUNCH(vector_row_kernel<4>, dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, row_split, nb0, w0, w1, alpha, beta,
                        A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, A.guard, A.stale);
 }
 
@@ -352,7 +352,7 @@ void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int 
   const int nb1 = ceil_div_ll(A.m - row_split, rpb1);
   if (nb0 + nb1 == 0) return;
 #define SPMV_ACC_LAUNCH_VT(NC, NV)                                                                                    \
-  hipLaunchKernelGGL((vector_tile_kernel<NC, NV>), dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, A.nnz, row_split, nb0, \
+  SPMV_ACC_LAUNCH((vector_tile_kernel<NC, NV>), dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, A.nnz, row_split, nb0, \
                      w0, w1, rpb0, rpb1, xcd_chunk, alpha, beta, A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, A.guard, A.stale, reverse ? 1 : 0)
   switch (stream_policy & 3) {
   case 1: SPMV_ACC_LAUNCH_VT(false, false); break;
@@ -367,7 +367,7 @@ void launch_wave_row(hipStream_t stream, const CsrDev &A, double alpha, double b
   if (A.m <= 0) return;
   int grid = ceil_div_ll(A.m, kThreads / kWave);
   if (grid > max_grid_blocks()) grid = max_grid_blocks();
-  hipLaunchKernelGGL(wave_row_kernel, dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci, A.v,
+  SPMV_ACC_LAUNCH(wave_row_kernel, dim3(grid), dim3(kThreads), 0, stream, A.m, A.nnz, alpha, beta, A.rp, A.ci, A.v,
                      x, y, A.yin ? A.yin : y, A.guard, A.stale);
 }
 
@@ -376,10 +376,10 @@ void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long lon
   if (n16 <= 0) return;
   const dim3 grid(ceil_div_ll(n16, kThreads * 4));
   if (non_temporal) {
-    hipLaunchKernelGGL(stream_copy_kernel<true>, grid, dim3(kThreads), 0, stream, static_cast<int4v *>(dst),
+    SPMV_ACC_LAUNCH(stream_copy_kernel<true>, grid, dim3(kThreads), 0, stream, static_cast<int4v *>(dst),
                        static_cast<const int4v *>(src), n16);
   } else {
-    hipLaunchKernelGGL(stream_copy_kernel<false>, grid, dim3(kThreads), 0, stream, static_cast<int4v *>(dst),
+    SPMV_ACC_LAUNCH(stream_copy_kernel<false>, grid, dim3(kThreads), 0, stream, static_cast<int4v *>(dst),
                        static_cast<const int4v *>(src), n16);
   }
 }
@@ -389,22 +389,22 @@ void launch_validate_csr(hipStream_t stream, const CsrDev &A, int *d_flags) {
   long long blocks = (work + kThreads - 1) / kThreads;
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(validate_csr_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, A.n,
+  SPMV_ACC_LAUNCH(validate_csr_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream, A.rp, A.ci, A.m, A.n,
                      A.nnz, d_flags);
 }
 
 void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard) {
   static_assert(kGuardSamples == kWave, "one lane per sample");
-  hipLaunchKernelGGL(guard_fill_kernel, dim3(1), dim3(kWave), 0, stream, rp, m, d_guard);
+  SPMV_ACC_LAUNCH(guard_fill_kernel, dim3(1), dim3(kWave), 0, stream, rp, m, d_guard);
 }
 
 void launch_guard_check(hipStream_t stream, const CsrDev &A) {
-  if (A.guard && A.stale) hipLaunchKernelGGL(guard_check_kernel, dim3(1), dim3(kWave), 0, stream, A.rp, A.m, A.guard, A.stale);
+  if (A.guard && A.stale) SPMV_ACC_LAUNCH(guard_check_kernel, dim3(1), dim3(kWave), 0, stream, A.rp, A.m, A.guard, A.stale);
 }
 
 void launch_scale_y(hipStream_t stream, int m, double beta, double *y, const double *yin) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(scale_y_kernel, dim3(ceil_div_ll(m, kThreads)), dim3(kThreads), 0, stream, m, beta, y, yin ? yin : y);
+  SPMV_ACC_LAUNCH(scale_y_kernel, dim3(ceil_div_ll(m, kThreads)), dim3(kThreads), 0, stream, m, beta, y, yin ? yin : y);
 }
 
 } // namespace spmv_acc

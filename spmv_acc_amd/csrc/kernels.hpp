@@ -4,8 +4,24 @@
 #pragma once
 
 #include <hip/hip_runtime_api.h>
+#include <hip/hip_ext.h>
 
 namespace spmv_acc {
+
+// ---- kernel clock (round 5) --------------------------------------------------------------------------------------------------------------
+// Every launcher launches through SPMV_ACC_LAUNCH.  Ordinarily that IS hipLaunchKernelGGL.  While the calling host thread's kernel clock is on
+// (spmv_acc_time_spmv_kernels, c_api.cpp) each launch carries its own start / stop event pair -- hipExtLaunchKernelGGL writes the dispatch's own
+// begin / end timestamps into them, the figures rocprofv3 --kernel-trace reports -- so that a call's KERNEL time (the sum over its launches) can be
+// read live, beside the event-pair time of the reference harness's protocol, which also holds the protocol's floor (marker packets, dispatch latency).
+bool kernel_clock_next(hipEvent_t *start, hipEvent_t *stop); // false: the clock is off (the usual case: one thread-local load)
+#define SPMV_ACC_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                                  \
+  do {                                                                                                                           \
+    hipEvent_t kc_e0_ = nullptr, kc_e1_ = nullptr;                                                                               \
+    if (::spmv_acc::kernel_clock_next(&kc_e0_, &kc_e1_))                                                                         \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, kc_e0_, kc_e1_, 0, __VA_ARGS__);                                 \
+    else                                                                                                                         \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                                       \
+  } while (0)
 
 // Device-side CSR view (all pointers are device pointers; int32 indices, fp64 values).
 struct CsrDev {
