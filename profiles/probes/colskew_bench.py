@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Balanced rows, power-law columns (every row 16 non-zeros, column bits 1 with probability 0.24: R-MAT's column marginal without its row skew):
-which strategies reach the gather hints?   python tools/probes/colskew_bench.py [log2 n = 25]"""
+which strategies reach the gather hints?   python profiles/probes/colskew_bench.py [log2 n = 25]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -9,7 +9,7 @@ only x >= 496 MB reaches (profiles/r04_rmat26_check.txt):
   fat_rows      1,000 rows of 1 M non-zeros each
   mostly_empty  100 M rows, 99 % of them empty, the rest 40 non-zeros
 under every strategy family, the forced slab passes and the flat tile kernel alone.
-    python tools/probes/extreme_shapes_check.py [shape ...]"""
+    python profiles/probes/extreme_shapes_check.py [shape ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -4,7 +4,7 @@ NON-TEMPORAL (20-25 % slower: x lives in the Infinity Cache, nt forfeits the hit
 vector L1 (and, at sc1, make the L2 treat the line as coherent) without the streaming hint.  Experimental builds mark cold = far from both stream
 neighbours (-DSPMV_ACC_HINT_BY_POSITION) and issue cold gathers with aux 1 / 2 / 16 / 17 (-DSPMV_ACC_COLD_AUX=...), gather_hint = 1 uses the marks:
     for a in 1 2 16 17; do make -C spmv_acc_amd/csrc -j8 OBJ_DIR=build_aux$a OUT_DIR=../lib_aux$a EXTRA="-DSPMV_ACC_HINT_BY_POSITION -DSPMV_ACC_COLD_AUX=$a"; done
-    python tools/probes/far_gather_policy_ab.py [workload ...]"""
+    python profiles/probes/far_gather_policy_ab.py [workload ...]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -2,7 +2,7 @@
 """Round 4's first-call budget finishes the per-matrix timings lazily over the following calls.  Does a plan settled that way end up as fast as one
 settled by spmv_acc_prepare?  Per sweep stand-in and strategy: steady time (60 back-to-back launches between two events, best of 3) after
 (A) prepare, (B) 40 plain calls; `settled` of both, and the choices query_plan reports.
-    python tools/probes/lazy_vs_prepare.py [name ...]"""
+    python profiles/probes/lazy_vs_prepare.py [name ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

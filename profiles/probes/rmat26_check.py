@@ -3,7 +3,7 @@
 against the CPU oracle) on R-MAT scale 26 -- 67 M rows, ~1.05 G non-zeros: past 2^30 non-zeros and 2^32 bytes of every array with a power-law
 matrix (the suite's R-MAT 25 stays 1.5 % below both; the int32-limit test is banded) -- under the automatic choice, the forced slab passes and the
 one-kernel path, with per-SpMV times.
-    python tools/probes/rmat26_check.py [scale=26]"""
+    python profiles/probes/rmat26_check.py [scale=26]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -3,7 +3,7 @@
 line re-fetch argument says long rows want more slabs and medium rows fewer.  This probe splits the matrix into row classes by
 length -- each class as a matrix of its own (the other rows emptied, same columns) -- and times every class under the one-kernel path and under forced
 S = 2 / 4 / 8 / 12 / 15 passes (slab_whole_below = 0): the sum of the per-class minima is what a multi-class form could reach at best.
-    python tools/probes/rmat_class_probe.py [scale=25]"""
+    python profiles/probes/rmat_class_probe.py [scale=25]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""slab_whole_below re-swept on R-MAT 24 / 25 / 26 now that the whole-row pass takes gather hints (the round-4 sweep without them:
-8 / 16 / 24 / 32 / 48 / 64 / 128 / 256 -> 5.33 / 5.28 / 5.19 / 5.19 / 5.21 / 5.25 / 5.29 / 5.79 ms on R-MAT 25).
-    python tools/probes/whole_below_sweep.py [scales=24,25,26]"""
+"""R-MAT 24 / 25 / 26 under forced slab counts around what the automatic rule picks (slabs of ~32 MB of x): is the rule's S still the best S
+with the two-class lists and the wavefront merge?    python profiles/probes/rmat_slab_count_sweep.py [scales=24,25,26]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -15,15 +14,16 @@ for scale in [int(t) for t in (sys.argv[1] if len(sys.argv) > 1 else "24,25,26")
     x = torch.rand(n, device="cuda", dtype=torch.float64) * 2 - 1
     y0 = torch.rand(m, device="cuda", dtype=torch.float64)
     y = y0.clone()
+    auto = max(2, min(16, (n * 8 + (16 << 20)) // (32 << 20)))
     out = []
-    for T in (16, 24, 32, 48, 64, 96, 128, 192):
+    for S in sorted({max(2, auto // 2), max(2, auto - 3), max(2, auto - 2), max(2, auto - 1), auto, min(16, auto + 1), min(16, auto + 2), min(16, auto + 4), 0}):
         lib.spmv_acc_reset_tunables()
-        lib.spmv_acc_set_tunable(b"slab_whole_below", T)
+        lib.spmv_acc_set_tunable(b"slab_segments", S)
         spmv_acc_amd.prepare(m, n, nnz, rp, ci, v, x, strategy="line_enhance")
         ms = min(float(np.median(spmv_acc_amd.time_spmv("line_enhance", 8, 1.0, 1.0, m, n, nnz, rp, ci, v, x, y, y0=y0))) for _ in range(2))
-        out.append(f"{T}: {ms * 1e3:.0f} ({spmv_acc_amd.query_plan(rp, m)['slab_passes']})")
+        out.append(f"S={S}: {ms * 1e3:.0f}")
         spmv_acc_amd.release_plans(rp)
-    print(f"R-MAT {scale}: slab_whole_below -> us (column slabs): " + "  ".join(out), flush=True)
+    print(f"R-MAT {scale} (x {n * 8 >> 20} MB, rule S = {auto}): " + "  ".join(out) + "  us", flush=True)
     del rp, ci, v, x, y, y0
     torch.cuda.empty_cache()
 lib.spmv_acc_reset_tunables()

@@ -3,7 +3,7 @@
 column slab of their last (largest) column -- x locality for the cold gathers without cutting any row?  Emulated with matrices: the short rows of
 R-MAT as a matrix of their own, (a) in row order, (b) rows permuted into (bucket, row) order for B = 2 ... 16 buckets; both through the forced slab
 passes with every row whole (= the whole-row pass alone), plain and hinted as the plan's timing decides.
-    python tools/probes/whole_rows_bucket_probe.py [scale=25]"""
+    python profiles/probes/whole_rows_bucket_probe.py [scale=25]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -88,7 +88,7 @@ template <bool NT> __device__ __forceinline__ double2v load_stream_d2(const doub
 // calls stay two instructions (same destination register, complementary lanes, one wait at the first use).  Byte offsets are
 // 32 bits: the engine uses hints only where x is below 4 GB; out-of-range offsets read 0 instead of faulting.
 // (the cold gathers' cache policy is a build-time constant: an immediate operand.  1 = sc0, 2 = nt, 16 = sc1 and their sums exist for A/B builds --
-// make EXTRA=-DSPMV_ACC_COLD_AUX=17 OBJ_DIR=build_exp OUT_DIR=../lib_exp, tools/probes/far_gather_policy_ab.py)
+// make EXTRA=-DSPMV_ACC_COLD_AUX=17 OBJ_DIR=build_exp OUT_DIR=../lib_exp, profiles/probes/far_gather_policy_ab.py)
 #ifndef SPMV_ACC_COLD_AUX
 #define SPMV_ACC_COLD_AUX 2
 #endif

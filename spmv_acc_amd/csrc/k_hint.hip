@@ -5,7 +5,7 @@
 // such requests per second whatever the load flavour (profiles/r01_gather_microbench.txt).  Where the columns of a matrix follow a
 // power law (graphs: R-MAT, web / social matrices) a small set of x lines takes a large share of the gathers, but the lines the
 // other gathers bring in push it out of L2 again.  Issuing just those other gathers non-temporal keeps the hot set resident:
-// tools/micro/skewed_gather_bench.hip measures 66 -> 74-76 G gathers/s on R-MAT scale-25 columns (all gathers non-temporal: 43).
+// profiles/probes/micro/skewed_gather_bench.hip measures 66 -> 74-76 G gathers/s on R-MAT scale-25 columns (all gathers non-temporal: 43).
 //
 // The plan therefore takes a census of the matrix' columns once:
 //   1. hint_census_kernel: a uniform sample of up to kHintSamples non-zeros; one atomic per sample on the counter of its x line

@@ -4,10 +4,10 @@
 // Reference role: none -- the reference streams every row against all of x.  SURVEY.md section 7 names the problem ("R-MAT ... x =
 // 256 MB, random 8 B reads per 64/128 B line ... consider column-window blocking"): on power-law columns ~60 % of the gathers fall
 // on a few MB of x, but every one of the eight 4 MB L2s has to hold that hot set AND absorb the lines the cold gathers bring in.
-// With S slabs a phase gathers from 1/S of x only: the L2s hold a hot set S times deeper (tools/micro/xcd_slab_gather_bench.hip:
-// 67 -> 109 G gathers/s with an eighth of x per L2; tools/probes/col_slab_probe.py: R-MAT scale 25 7.15 -> 5.46 ms with S = 8 DENSE slabs,
+// With S slabs a phase gathers from 1/S of x only: the L2s hold a hot set S times deeper (profiles/probes/micro/xcd_slab_gather_bench.hip:
+// 67 -> 109 G gathers/s with an eighth of x per L2; profiles/probes/col_slab_probe.py: R-MAT scale 25 7.15 -> 5.46 ms with S = 8 DENSE slabs,
 // i.e. S passes over y and S full row-pointer arrays).  The slabs are kept COMPACT -- only the rows that have non-zeros in a slab,
-// with a row-id list (tools/probes/col_slab_compact_probe.py: 45 M non-empty (row, slab) pairs of 268 M on R-MAT 25) -- so a phase is an
+// with a row-id list (profiles/probes/col_slab_compact_probe.py: 45 M non-empty (row, slab) pairs of 268 M on R-MAT 25) -- so a phase is an
 // ordinary SpMV of a smaller matrix into a compact y_s plus a merge y[rowid] += y_s.  The plan then holds a re-ordered COPY of colindex and values, which is why this is
 // opt-in like the 16-bit column stream: after editing VALUES in place call spmv_acc_refresh_values (one scatter pass, the slabs'
 // structure and plans stay), after editing the structure spmv_acc_release_plans.

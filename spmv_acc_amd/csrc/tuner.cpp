@@ -665,7 +665,7 @@ bool ensure_segments(Plan &p, int S_cols, hipStream_t st) {
   const int rest_below = tun(kT_slab_whole_below) > 1 ? tun(kT_slab_whole_below) : 0;
   // (kSegMaxPlanes planes in all: the count kernels keep one counter per plane in 16 lanes / 16 packed bytes.  The automatic slab count reaches
   // 16 from x = 496 MB on, and until this clamp the whole-row plane was then a 17th: rows of exactly 32 non-zeros -- the only ones the one-lane count
-  // kernel cuts by slab -- had slab 8's run filed twice.  Found by tools/probes/rmat26_check.py, 130,277 wrong rows on R-MAT 26)
+  // kernel cuts by slab -- had slab 8's run filed twice.  Found by profiles/probes/rmat26_check.py, 130,277 wrong rows on R-MAT 26)
   if (S_cols > kSegMaxPlanes - (rest_below > 0 ? 1 : 0)) S_cols = kSegMaxPlanes - (rest_below > 0 ? 1 : 0);
   const int S = S_cols + (rest_below > 0 ? 1 : 0); // planes
   if (p.seg_state >= 0 && (p.seg_state == 0 || (p.seg_slabs == S && p.seg_rest_below == rest_below))) return true;

@@ -350,5 +350,16 @@ def test_bench_line_carries_every_baseline_config(torch_dev):
     assert d["banded_shard"]["rows"] == 32_000_000
     both_protocols(d["banded_shard"]["adaptive"], "banded_shard")
     assert d["per_launch_reset_ms_median"] > 0 and d["back_to_back_ms_mean"] > 0
-    assert abs(d["roofline"]["launch_ms_mean"] - d["per_launch_reset_ms_median"]) < 1e-9  # roofline.frac: the reset protocol
+    # roofline.frac: the kernel's own launch duration (kernel clock, round 5); the reference harness's event pair -- kernel + the protocol's floor -- beside it
+    assert abs(d["roofline"]["launch_ms_mean"] - d["kernel_clock_ms_median"]) < 1e-9
+    assert abs(d["roofline"]["per_launch_protocol"]["launch_ms_median"] - d["per_launch_reset_ms_median"]) < 1e-9
+    assert d["kernel_clock_ms_median"] <= d["per_launch_reset_ms_median"] and d["roofline"]["per_launch_protocol"]["frac"] <= d["roofline"]["frac"]
+    assert line["roofline"]["per_launch_protocol"]["frac"] == d["roofline"]["per_launch_protocol"]["frac"]
+    assert d["region_reps"] >= 5 and len(d["ms_per_step_wall_all"]) == d["region_reps"]
+    for name, row in d["sweep"].items():
+        for strat in ("flat", "adaptive"):
+            assert 0 < row[strat]["us_kernel_clock"] <= row[strat]["us"] + 0.011 and row[strat]["launches_per_spmv"] >= 1, (name, strat, row[strat])
+    assert "ge_0.70_kernel_clock" in d["sweep_summary"]["flat"] and "ge_0.70_kernel_clock" in line["sweep_summary"]["adaptive"]
+    cb = d["cpu_baseline"]
+    assert cb["bitwise_equal_to_sequential"] and cb["stream_triad_gbs"] > 0 and len(cb["value_median_per_round"]) == 3 and cb["cores"] >= 1
     assert "builder-run" in d["roofline"]["traffic_source"]

@@ -1148,7 +1148,7 @@ def test_billion_rows(torch_dev):
 def test_more_rows_than_a_launch_holds_wavefronts(torch_dev, hiplib):
     """70 M rows: at one wavefront per row a grid would be 17.5 M workgroups = 2^32.06 work-items, and a HIP launch of 2^32 or more
     work-items WRAPS on this stack (the first 2.9 M rows were computed, nothing was reported: KERNEL_STRATEGY WF_ROW returned a wrong y
-    from round 1 on, found in round 3 by tools/probes/many_rows_probe.py).  Every kernel whose grid grows with m alone now strides over a capped
+    from round 1 on, found in round 3 by profiles/probes/many_rows_probe.py).  Every kernel whose grid grows with m alone now strides over a capped
     number of workgroups: wf_row, the direct vector-row form under a forced width, LIGHT, and the plan-time builds of both column-slab
     forms, against an independent device evaluation on every row."""
     torch = torch_dev

@@ -998,7 +998,7 @@ def test_slab_passes_two_class_form(torch_dev, oracle, hiplib, whole_below):
 
 @pytest.mark.parametrize("slabs,whole_below", [(16, 32), (16, 0), (15, 32), (40, 32)])
 def test_slab_planes_never_exceed_what_the_count_kernels_hold(torch_dev, oracle, hiplib, slabs, whole_below):
-    """Regression (round 4, found by tools/probes/rmat26_check.py on R-MAT 26): 16 column slabs -- what the automatic mode picks once x reaches 496 MB --
+    """Regression (round 4, found by profiles/probes/rmat26_check.py on R-MAT 26): 16 column slabs -- what the automatic mode picks once x reaches 496 MB --
     plus the whole-row plane of the two-class form made 17 planes, one more than the count kernels keep counters for; rows of EXACTLY 32 non-zeros (the
     only ones the one-lane count kernel cuts by slab) then had one slab's run filed twice.  The build now gives the whole-row plane one of the 16; the
     matrix here is mostly such rows, spread over all columns."""
