@@ -280,7 +280,8 @@ def timed_leg(torch, strat, A, x, y0, iters, warm=10, beta=1.0, cols_touched=Non
             "us_events_without_system_fence": round(nf_ms * 1e3, 2), "frac_events_without_system_fence": frac(nf_ms),
             "us_kernel_clock": round(kn_ms * 1e3, 2), "frac_kernel_clock": frac(kn_ms), "launches_per_spmv": int(np.median(kl)),
             "gflops": round(2.0 * nnz / (reset_ms * 1e-3) / 1e9, 1),
-            "plan": [info.get(k, -1) for k in ("stream_policy", "adaptive_family", "flat_fixup")]}
+            "plan": [info.get(k, -1) for k in ("stream_policy", "adaptive_family", "flat_fixup")], "kernel": info.get("last_kernel"),
+            "settled": bool(info.get("settled"))}
 
 
 def _leg_vectors(torch, device, m, n):
@@ -1103,7 +1104,7 @@ def main():
     result.update(out_extra)
     info = spmv_acc_amd.query_plan(W["rp"], m) if args.exchange != "ghost" else None
     if info:  # what the first call measured and kept for this matrix (kernel family: 0 fixed row blocks, 1 row-block-plus, 2 flat)
-        result["plan"] = {k: info[k] for k in ("stream_policy", "adaptive_family", "flat_fixup", "plus_blocks", "flat_tiles", "slab_passes")}
+        result["plan"] = {k: info[k] for k in ("stream_policy", "adaptive_family", "flat_fixup", "plus_blocks", "flat_tiles", "slab_passes", "settled", "last_kernel")}
     if rank == 0:
         result["copy_ceiling_gbs"] = round(copy_ceiling_gbs(torch, device), 1)
         # the same achieved rates against what THIS box copies at (boxes of this pool read 6.25 .. 6.66 TB/s; the large sweep stand-ins

@@ -555,7 +555,8 @@ int run_benchmark(const Options &o, HostCsr &A, HostVectors &v) {
               << calc2 << "," << destroy << "," << total << "," << vr.first_failed_at << "," << vr.failed_count << ","
               << vr.max_error << std::endl;
     std::cout << "PLAN," << mtx << "," << name << ",first_call_us," << first_us << ",pre_us," << first_run.pre << ",calc_us,"
-              << first_run.calc << ",settle_us," << settle_us << std::endl;
+              << first_run.calc << ",settle_us," << settle_us << ",settled," << spmv_acc_query_plan_settled(d.csr.row_ptr, A.rows) << ",kernel,"
+              << spmv_acc_query_plan_last_kernel(d.csr.row_ptr, A.rows) << std::endl; // (settled 1: runs two and three were steady runs of ONE kernel, bitwise stable)
   }
   HIP_CHECK(hipEventDestroy(e0));
   HIP_CHECK(hipEventDestroy(e1));

@@ -346,7 +346,11 @@ def test_bench_line_carries_every_baseline_config(torch_dev):
     assert all(row["flat_tile_kernel"]["us"] > 0 for row in d["sweep"].values()) and "ge_0.70" in d["sweep_summary"]["flat_tile_kernel"]
     assert "child process" in d["legs_measured"]
     both_protocols(d["rmat25"]["line_enhance"], "rmat25")
-    assert "path" in d["rmat25"]
+    # (restored in round 5: the default path -- the slab passes the plan-time timing chose -- beats the one-kernel path it was timed against)
+    both_protocols(d["rmat25"]["line_enhance_without_slab_passes"], "rmat25, one-kernel path")
+    assert "path" in d["rmat25"] and "column-slab passes" in d["rmat25"]["path"]
+    assert d["rmat25"]["line_enhance"]["us"] < d["rmat25"]["line_enhance_without_slab_passes"]["us"], d["rmat25"]
+    assert d["plan"]["settled"] is True  # every timed figure is taken on a settled plan (spmv_acc_query_plan_settled)
     assert d["banded_shard"]["rows"] == 32_000_000
     both_protocols(d["banded_shard"]["adaptive"], "banded_shard")
     assert d["per_launch_reset_ms_median"] > 0 and d["back_to_back_ms_mean"] > 0

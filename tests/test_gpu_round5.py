@@ -394,6 +394,7 @@ def test_kernel_clock_reads_the_kernels_own_time(torch_dev, oracle, hiplib):
     torch = torch_dev
     m = n = 400_000
     rowptr, cols, vals = synth.random_csr(m, n, 12, seed=2, kind="uniform")
+    cols, vals = _sorted_rows(rowptr, cols, vals)  # (ascending columns inside every row: what the slab passes' run lists need)
     nnz = int(rowptr[-1])
     rng = np.random.default_rng(3)
     x, y0 = rng.standard_normal(n), rng.standard_normal(m)
