@@ -402,7 +402,8 @@ def test_kernel_clock_reads_the_kernels_own_time(torch_dev, oracle, hiplib):
     ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
     try:
         for strat, tun, want_launches in (("line_enhance", {}, (1,)), ("flat", {"flat_rowblock": 0, "flat_finish": 0}, (2,)),
-                                          ("flat", {"flat_rowblock": 0, "flat_finish": 1}, (1,)), ("adaptive", {"slab_segments": 3}, range(4, 12))):
+                                          ("flat", {"flat_rowblock": 0, "flat_finish": 1}, (1,)), ("adaptive", {"slab_segments": 3, "slab_whole_below": 0}, range(4, 8)),  # the guard check + three slab passes (+ merges)
+                                          ("adaptive", {"slab_segments": 3}, (2,))):  # rows of ~12 non-zeros: all in the whole-row pass (+ the guard check)
             for k, v in tun.items():
                 hiplib.spmv_acc_set_tunable(k.encode(), v)
             y = dy0.clone()
