@@ -135,7 +135,9 @@ class RowShardedSpmv:
         """Per-chunk CSR views of this rank's slice.  A chunk is a row SUB-RANGE of the slice's own arrays: rowptr[a : b + 1] as a
         view (so its first entry is the chunk's first non-zero, not 0), the whole colindex / value arrays, nnz = rowptr[b] -- the
         library's kernels accept that form (tests/test_gpu_parity.py::test_row_shard_without_rebasing), so nothing is copied or
-        rebased (round 3 made one rebased rowptr copy per chunk)."""
+        rebased (round 3 made one rebased rowptr copy per chunk).  Round 5: the library reads the view's first non-zero (rowptr[a]) once per plan
+        and sizes every heuristic, flat's tile range and the column census by the chunk's OWN non-zeros (until then `nnz`, the end offset, was read
+        as the count: chunk k of C looked k + 1 times as dense as it is)."""
         if depth not in self._chunks:
             out = []
             ends = None
