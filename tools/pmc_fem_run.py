@@ -22,22 +22,32 @@ import torch
 import spmv_acc_amd
 from spmv_acc_amd import synth
 
-m, n, nnz, rp, ci, v = synth.sweep_standin_torch(a.workload, device="cuda")
+beta = 1.0
+if a.workload == "banded_shard":  # BASELINE configs[4]: rank 3's 32 M-row shard of the 256 M-row banded matrix, beta = 0 (bench.py leg_banded_shard)
+    m, n = 32_000_000, 256_000_000
+    rp, ci, v = synth.banded_torch(m, first_row=3 * m, total_rows=n, device="cuda")
+    nnz = int(rp[-1].item())
+    beta = 0.0
+    balg = synth.algorithmic_bytes(m, m + 7, nnz, beta_nonzero=False)
+else:
+    m, n, nnz, rp, ci, v = synth.sweep_standin_torch(a.workload, device="cuda")
+    balg = synth.algorithmic_bytes(m, n, nnz)
 g = torch.Generator(device="cuda")
 g.manual_seed(1234)
 x = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
 y0 = torch.rand(m, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
 y = y0.clone()
-spmv_acc_amd.prepare(m, n, nnz, rp, ci, v, x, strategy=a.strategy, beta=1.0)
-out = {"workload": a.workload, "strategy": a.strategy, "m": m, "n": n, "nnz": nnz, "algorithmic_bytes": synth.algorithmic_bytes(m, n, nnz)}
+spmv_acc_amd.prepare(m, n, nnz, rp, ci, v, x, strategy=a.strategy, beta=beta)
+out = {"workload": a.workload, "strategy": a.strategy, "m": m, "n": n, "nnz": nnz, "algorithmic_bytes": balg}
 if a.no_timing:
     for _ in range(a.iters):
         y.copy_(y0)
-        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=a.strategy)
+        spmv_acc_amd.csr_spmv(1.0, beta, m, n, nnz, rp, ci, v, x, y, strategy=a.strategy)
     torch.cuda.synchronize()
 else:
-    per = spmv_acc_amd.time_spmv(a.strategy, a.iters, 1.0, 1.0, m, n, nnz, rp, ci, v, x, y, y0=y0)
-    b2b = spmv_acc_amd.time_spmv_total(a.strategy, a.iters, 1.0, 1.0, m, n, nnz, rp, ci, v, x, y) / a.iters
-    out.update(per_launch_us_median=round(float(np.median(per)) * 1e3, 2), back_to_back_us=round(b2b * 1e3, 2))
+    ev, kn, ln = spmv_acc_amd.time_spmv_kernels(a.strategy, a.iters, 1.0, beta, m, n, nnz, rp, ci, v, x, y, y0=y0)
+    b2b = spmv_acc_amd.time_spmv_total(a.strategy, a.iters, 1.0, beta, m, n, nnz, rp, ci, v, x, y) / a.iters
+    out.update(per_launch_us_median=round(float(np.median(ev)) * 1e3, 2), kernel_clock_us_median=round(float(np.median(kn)) * 1e3, 2),
+               back_to_back_us=round(b2b * 1e3, 2))
 out["plan"] = spmv_acc_amd.query_plan(rp, m)
 print(json.dumps(out))
