@@ -594,6 +594,7 @@ int spmv_acc_time_spmv_kernels(int strategy, int iters, double alpha, double bet
     if (launches_out) launches_out[i] = static_cast<int>((first[i + 1] - first[i]) / 2);
   }
   for (auto &e : ev) (void)hipEventDestroy(e);
+  kernel_clock_release();
   if (rc != kOk) set_error(kErrHip, "spmv_acc_time_spmv_kernels: HIP failure while timing");
   if (rc == kOk && last_error() != kOk) rc = last_error();
   return rc;

@@ -242,6 +242,12 @@ void kernel_clock_begin() {
   t_kclock.failed = false;
 }
 void kernel_clock_set(bool on) { detail::t_kclock.on = on; }
+void kernel_clock_release() { // the timing entry is done with its events: the pool does not outlive the call
+  for (hipEvent_t e : detail::t_kclock.pool) (void)hipEventDestroy(e);
+  detail::t_kclock.pool.clear();
+  detail::t_kclock.used = 0;
+  detail::t_kclock.on = false;
+}
 size_t kernel_clock_used() { return detail::t_kclock.used; }
 bool kernel_clock_failed() { return detail::t_kclock.failed; }
 hipEvent_t kernel_clock_event(size_t i) { return i < detail::t_kclock.pool.size() ? detail::t_kclock.pool[i] : nullptr; }

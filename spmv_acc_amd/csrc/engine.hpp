@@ -122,6 +122,7 @@ void release_plans(const int *d_rowptr, int m_only = -1);
 // config.cpp: the kernel clock behind SPMV_ACC_LAUNCH (kernels.hpp), per host thread
 void kernel_clock_begin();          // forget the pairs handed out so far (the pool of events is kept)
 void kernel_clock_set(bool on);     // on: every launch of this host thread carries its own event pair
+void kernel_clock_release();        // destroy the pool's events (end of a timing call)
 size_t kernel_clock_used();         // events handed out since kernel_clock_begin (2 per launch)
 bool kernel_clock_failed();
 hipEvent_t kernel_clock_event(size_t i);

@@ -110,7 +110,16 @@ for case in range(cases):
                 ("line_enhance", {"slab_segments": 8, "slab_whole_below": 0}), ("adaptive", {"slab_segments": 4, "slab_whole_below": 1 << 30}),
                 ("flat", {"slab_segments": 3, "slab_whole_below": 5, "calls": 2}),
                 # ... and the whole-row pass with the plan's gather hints (built whatever n is; the rule takes them, the timing may or may not)
-                ("line_enhance", {"slab_segments": 8, "gather_hint": 1, "deterministic": 1}), ("adaptive", {"slab_segments": 5, "gather_hint": 1, "calls": 2})]
+                ("line_enhance", {"slab_segments": 8, "gather_hint": 1, "deterministic": 1}), ("adaptive", {"slab_segments": 5, "gather_hint": 1, "calls": 2}),
+                # round 5: a name means its kernel (strict_strategy), the size rules lowered so that every size-selected branch runs on these sizes (the
+                # automatic slab count at any S, the census / automatic passes at any x, grid-stride launches, flat above its small-grid rule), and every
+                # case is a row SHARD passed without rebasing (rp32[r0:]): plans sized by the view's own non-zeros, flat's tile range from its first tile
+                ("flat", {"strict_strategy": 1}), ("line_enhance", {"strict_strategy": 1, "slab_segments": 4}), ("line", {"strict_strategy": 1, "calls": 2}),
+                ("adaptive", {"slab_segments": 1, "slab_kb": 16}), ("line_enhance", {"slab_segments": 1, "slab_kb": 1, "slab_whole_below": 0}),
+                ("adaptive_plus", {"slab_kb": 64, "hint_min_x_mb": 0, "hint_budget_kb": 64, "calls": 3}), ("adaptive", {"hint_min_x_mb": 0, "slab_kb": 4096, "calls": 3}),
+                ("wf_row", {"max_grid_blocks": 96, "legacy_kernels": 0}), ("vector_row", {"max_grid_blocks": 64, "vector_tile": 0}),
+                ("line_enhance", {"max_grid_blocks": 200, "col_slabs": 3}), ("flat", {"max_grid_blocks": 128, "slab_segments": 6}),
+                ("flat", {"flat_small_nnz_k": 1, "flat_rowblock": 0}), ("flat", {"flat_small_nnz_k": 1 << 20, "flat_rowblock": 0, "calls": 2})]
     for strat, knobs in [(s_, dict(k_, call=c_)) for s_, k_ in variants for c_ in range(k_.get("calls", 1))]:
         lib.spmv_acc_reset_tunables()
         oop = bool(knobs.get("oop"))

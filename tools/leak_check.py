@@ -35,6 +35,15 @@ for it in range(300):
     lib.spmv_acc_set_stream(side.cuda_stream)
     spmv_acc_amd.csr_spmv(1.0,0.0,20000,20000,nnz,drp,dci,dv,x,y,strategy="flat")
     lib.spmv_acc_set_stream(None)
+    # round 5: the kernel clock (its event pool goes with the call), the region timer, the strict / size-rule tunables, an un-rebased view with its own plan
+    spmv_acc_amd.time_spmv_kernels("adaptive",3,1.0,1.0,20000,20000,nnz,drp,dci,dv,x,y,y0=x)
+    spmv_acc_amd.time_spmv_region("flat",3,1.0,1.0,20000,20000,nnz,drp,dci,dv,x,y)()
+    for knobs in ({"strict_strategy": 1}, {"slab_segments": 1, "slab_kb": 8}, {"hint_min_x_mb": 0, "hint_budget_kb": 16}, {"max_grid_blocks": 64, "col_slabs": 2}):
+        for k, val in knobs.items(): lib.spmv_acc_set_tunable(k.encode(), val)
+        spmv_acc_amd.csr_spmv(1.0,1.0,20000,20000,nnz,drp,dci,dv,x,y,strategy="flat" if "strict_strategy" in knobs else "adaptive_plus")
+        lib.spmv_acc_reset_tunables()
+    spmv_acc_amd.csr_spmv(1.0,0.0,12000,20000,int(rowptr[20000]),drp[8000:],dci,dv,x,y[8000:],strategy="flat")
+    spmv_acc_amd.release_plans(drp[8000:])
     spmv_acc_amd.release_plans(drp)
     if it==20: f0=free()
 f1=free()
