@@ -586,7 +586,7 @@ int spmv_acc_time_spmv_kernels(int strategy, int iters, double alpha, double bet
     float ms = 0.f;
     if (event_ms_out && hipEventElapsedTime(&event_ms_out[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = kErrHip;
     double sum = 0.0;
-    for (size_t k = first[i]; k + 1 < first[i + 1] + 1 && k < first[i + 1] && rc == kOk; k += 2) {
+    for (size_t k = first[i]; k + 1 < first[i + 1] && rc == kOk; k += 2) { // (pairs: [k] start, [k + 1] stop)
       if (hipEventElapsedTime(&ms, kernel_clock_event(k), kernel_clock_event(k + 1)) != hipSuccess) rc = kErrHip;
       sum += ms;
     }
