@@ -80,7 +80,9 @@ balg = bench["roofline"]["algorithmic_bytes_per_launch"]
 fetch_b, write_b = f[2] * 1024.0, w[2] * 1024.0
 corrected = 2.0 * fetch_b + write_b                      # MI355X_MICROARCH.md: gfx950 tallies wide coalesced reads at half
 reads_alg = balg - write_b                               # algorithmic read bytes
-lower = reads_alg + max(2.0 * fetch_b - reads_alg, 0.0) / 2.0 + write_b  # over-fetch counted at its raw (64-B sector) size
+# (until round 4 the over-fetch -- the far gathers -- was also counted at 64 B per gather as a lower bound; round 5's request-size counters show that every
+# L2-missing read of these kernels, gathers included, is a 128-B request (profiles/r05_gather_request_size_microbench.txt): the corrected figure IS the traffic)
+lower = corrected
 print(json.dumps({"kernel": f[0], "FETCH_SIZE_KB": f[2], "WRITE_SIZE_KB": w[2], "corrected_bytes": int(round(corrected)),
                   "lower_bound_bytes": int(round(lower)), "algorithmic_bytes": balg, "round": tag,
                   "workload": bench["config"]["workload"], "strategy": bench["config"]["strategy"]}))
