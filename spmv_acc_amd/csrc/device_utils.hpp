@@ -203,6 +203,8 @@ __device__ __forceinline__ void check_plan_guard(const int *__restrict__ rp, int
 __device__ __forceinline__ bool keeps_y(const double *y, const double *yin, double beta) { return beta == 1.0 && yin == y; }
 
 __device__ __forceinline__ void store_y(double *y, const double *yin, int row, double alpha, double beta, double s) {
+  // (plain store: non-temporal y stores pay in the row-block kernel only -- flat / row-block-plus / vector-row: -0.6 ... +1.3 %, mixed signs,
+  // profiles/r05_short_row_dissection.txt)
   y[row] = (beta == 0.0) ? alpha * s : alpha * s + beta * yin[row];
 }
 

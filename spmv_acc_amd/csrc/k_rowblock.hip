@@ -70,6 +70,9 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   if (flags & 64) b = zigzag_block(b, nblocks); // every other SpMV on a plan walks the matrix backwards (dispatch.cpp)
   if (flags & 1) b = xcd_contiguous_block(b, nblocks);
   if (flags & 4) b = xcd_chunked_block(b, nblocks, flags >> 8);
+  // (Tried in round 5 and removed: workgroups walking GROUPS of 2 ... 8 consecutive row blocks, so that the stores of block i travel while block
+  // i + 1 streams and s_endpgm's wait for outstanding stores is paid once per group: 2-14 % SLOWER on every stand-in, small and large --
+  // profiles/r05_short_row_dissection.txt.  What the y stores cost is the memory system's price for a write stream beside a read stream, not a wait.)
 
   const long long base_ll = static_cast<long long>(b) * rpb;
   const int row_base = static_cast<int>(base_ll);
@@ -130,13 +133,23 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
     }
     const int lo = (r0 > off ? r0 : off) - off;
     const int hi = (r1 < off + kTile ? r1 : off + kTile) - off;
+#ifdef SPMV_ACC_EXP_NO_ROW_SUM // (dissection builds only, profiles/r05_short_row_dissection.txt: one LDS read per row instead of its sum)
+    acc += lds[lo < kTile ? lo : 0] + static_cast<double>(hi);
+#else
     acc += tile_row_sum<kThreads>(lds, spans, lo, hi > lo ? hi : lo, lane, VEC); // long spans go to whole waves
+#endif
     if (off + kTile < s1) __syncthreads(); // next round overwrites the tile
   }
   acc = group_sum<VEC>(acc);
+#ifdef SPMV_ACC_EXP_NO_Y_STORE // (dissection builds only: the store stays in the code, its condition is never true)
+  if (writer && acc == 123.456e300) {
+#else
   if (writer) {
-    if (early_y) y[row] = alpha * acc + beta * y_old;
-    else store_y(y, yin, row, alpha, beta, acc);
+#endif
+    // non-temporal store (round 5): a write stream beside a read stream costs the memory system ~3 x its bytes (read_write_mix_bench.hip: 24 KB read +
+    // 2 KB written per workgroup reads at 5.1-5.7 TB/s, 5.4-5.9 with non-temporal stores); in this kernel: banded shard -2.1 %, the other stand-ins
+    // -0.1 ... -0.6 %, none slower (two builds A/B-ed in one process, profiles/r05_short_row_dissection.txt)
+    __builtin_nontemporal_store(early_y ? alpha * acc + beta * y_old : (beta == 0.0 ? alpha * acc : alpha * acc + beta * yin[row]), y + row);
   }
 }
 

@@ -69,10 +69,17 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
           xg[k][2] = gather_hinted(xr, c[k].z, nib[k] & 4u);
           xg[k][3] = gather_hinted(xr, c[k].w, nib[k] & 8u);
         } else {
+#ifdef SPMV_ACC_EXP_NO_GATHER // (dissection builds only: every gather an L1 hit, the dependency on the column load kept)
+          xg[k][0] = x[c[k].x & 1023];
+          xg[k][1] = x[c[k].y & 1023];
+          xg[k][2] = x[c[k].z & 1023];
+          xg[k][3] = x[c[k].w & 1023];
+#else
           xg[k][0] = x[c[k].x];
           xg[k][1] = x[c[k].y];
           xg[k][2] = x[c[k].z];
           xg[k][3] = x[c[k].w];
+#endif
         }
       }
     }

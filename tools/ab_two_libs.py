@@ -31,7 +31,12 @@ spmv_acc_amd.load_library()  # (torch's HIP runtime first, see spmv_acc_amd.load
 libs = {"shipped": raw(spmv_acc_amd.LIB_PATH), "exp": raw(os.environ.get("AB_EXP_LIB") or os.path.join(ROOT, "spmv_acc_amd", "lib_exp", "libspmv_acc.so"))}
 sid = spmv_acc_amd.strategy_id(strat)
 for name in names:
-    m, n, nnz, rp, ci, v = synth.sweep_standin_torch(name)
+    if name == "banded":  # BASELINE configs[4]: rank 3's 32 M-row shard
+        m, n = 32_000_000, 256_000_000
+        rp, ci, v = synth.banded_torch(m, first_row=3 * m, total_rows=n, device="cuda")
+        nnz = int(rp[-1].item())
+    else:
+        m, n, nnz, rp, ci, v = synth.sweep_standin_torch(name)
     x = torch.rand(n, device="cuda", dtype=torch.float64)
     y0 = torch.rand(m, device="cuda", dtype=torch.float64)
     y = y0.clone()
