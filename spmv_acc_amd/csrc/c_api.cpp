@@ -554,9 +554,12 @@ int spmv_acc_time_spmv_kernels(int strategy, int iters, double alpha, double bet
   }
   if (spmv_acc_prepare_beta(strategy, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, nullptr) != kOk) return last_error();
   hipStream_t st = get_stream();
-  std::vector<hipEvent_t> ev(2 * static_cast<size_t>(iters));
+  std::vector<hipEvent_t> ev(2 * static_cast<size_t>(iters), nullptr);
   for (auto &e : ev) {
     if (hipEventCreate(&e) != hipSuccess) {
+      e = nullptr;
+      for (auto &made : ev)
+        if (made) (void)hipEventDestroy(made);
       set_error(kErrHip, "hipEventCreate failed");
       return kErrHip;
     }
