@@ -142,7 +142,7 @@ unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *sample
     const unsigned char *c = static_cast<const unsigned char *>(p);
     for (size_t i = 0; i < bytes; ++i) h = (h ^ c[i]) * 1099511628211ULL;
   };
-  static const char kVersion[] = "spmv_acc_amd 0.4 tune v4";
+  static const char kVersion[] = "spmv_acc_amd 0.5 tune v5";
   mix(kVersion, sizeof(kVersion));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
