@@ -484,12 +484,18 @@ int spmv_acc_time_spmv_events(int strategy, int iters, double alpha, double beta
     const char *e = std::getenv("SPMV_ACC_RESET_MEMCPY");
     return e && *e && *e != '0';
   }();
+  // SPMV_ACC_RESET_NT=0: the reset copy with default-policy loads / stores (rounds 1-4); default since round 5: non-temporal, like the DMA write of the
+  // reference's own reset (hipMemcpy host -> device, benchmark/csr_spmv.hpp:68) it does not park 2 * 8 * m bytes of y in the L2s in front of the timed launch
+  static const bool reset_nt = [] {
+    const char *e = std::getenv("SPMV_ACC_RESET_NT");
+    return !(e && *e == '0');
+  }();
   const size_t ybytes = sizeof(double) * static_cast<size_t>(m);
   const bool kernel_copy = !reset_memcpy && reinterpret_cast<uintptr_t>(dy) % 16 == 0 && reinterpret_cast<uintptr_t>(d_y0) % 16 == 0;
   for (int i = 0; i < iters; ++i) {
     if (d_y0) {
       const size_t body = kernel_copy ? ybytes / 16 * 16 : 0;
-      if (body) launch_stream_copy(st, dy, d_y0, static_cast<long long>(body), false);
+      if (body) launch_stream_copy(st, dy, d_y0, static_cast<long long>(body), reset_nt);
       if (body < ybytes && kernel_copy) // (odd m: the last double)
         hipLaunchKernelGGL(copy_doubles_kernel, dim3(1), dim3(64), 0, st, dy + body / 8, d_y0 + body / 8, static_cast<int>((ybytes - body) / 8));
       else if (body < ybytes)
@@ -545,6 +551,13 @@ int spmv_acc_time_spmv_total(int strategy, int iters, double alpha, double beta,
 // reference harness's figure, which holds the marker packets and the dispatch latency of the protocol too -- every kernel the call launches carries
 // its own start / stop events (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps, what rocprofv3 --kernel-trace reports), and
 // kernel_ms_out[i] is their SUM over call i's launches: the call's kernel time without the gaps.  launches_out (may be null): kernels per call.
+static bool reset_nt_copy() { // (SPMV_ACC_RESET_NT, see spmv_acc_time_spmv_events)
+  static const bool nt = [] {
+    const char *e = std::getenv("SPMV_ACC_RESET_NT");
+    return !(e && *e == '0');
+  }();
+  return nt;
+}
 int spmv_acc_time_spmv_kernels(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
                                const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
                                const double *dx, double *dy, const double *d_y0, float *event_ms_out, float *kernel_ms_out, int *launches_out) {
@@ -571,7 +584,7 @@ int spmv_acc_time_spmv_kernels(int strategy, int iters, double alpha, double bet
   for (int i = 0; i < iters; ++i) {
     if (d_y0) { // y reset outside both clocks (the copy is launched with the kernel clock off)
       if (ybytes % 16 == 0 && reinterpret_cast<uintptr_t>(dy) % 16 == 0 && reinterpret_cast<uintptr_t>(d_y0) % 16 == 0)
-        launch_stream_copy(st, dy, d_y0, static_cast<long long>(ybytes), false);
+        launch_stream_copy(st, dy, d_y0, static_cast<long long>(ybytes), reset_nt_copy());
       else
         (void)hipMemcpyAsync(dy, d_y0, ybytes, hipMemcpyDeviceToDevice, st);
     }
