@@ -8,6 +8,9 @@ only x >= 496 MB reaches (profiles/r04_rmat26_check.txt):
   diagonal      200 M rows of one non-zero each                                         (rows past 2^27, nothing to balance)
   fat_rows      1,000 rows of 1 M non-zeros each
   mostly_empty  100 M rows, 99 % of them empty, the rest 40 non-zeros
+  near_max_fem   (round 5) ~30 M rows of 60 ... 82 non-zeros, nnz = 2^31 - 65537 exactly: the largest count the library accepts (plan.cpp refuses
+                 nnz > INT_MAX - 65536) -- every int32 non-zero index at its upper end (2^30 < nnz had never been run: R-MAT 26 is 1.07 B)
+  near_max_short (round 5) ~430 M rows of 0 ... 10 non-zeros, the same nnz: rows past 2^28 with non-zero indices past 2^30
 under every strategy family, the forced slab passes and the flat tile kernel alone.
     python profiles/probes/extreme_shapes_check.py [shape ...]"""
 import os, sys
@@ -31,7 +34,7 @@ def from_lens(lens, n, skew=False):
     rowptr = torch.zeros(m + 1, dtype=torch.int64, device="cuda")
     torch.cumsum(lens, 0, out=rowptr[1:])
     nnz = int(rowptr[-1].item())
-    assert nnz < 2**31 - 65536
+    assert nnz <= 2**31 - 65537
     ci = torch.empty(nnz, dtype=torch.int32, device="cuda")
     step = 1 << 27
     r0 = 0
@@ -74,6 +77,19 @@ def shape(name):
     if name == "mostly_empty":
         lens = torch.where(torch.rand(100_000_000, generator=gen, device="cuda") < 0.01, 40, 0).long()
         return from_lens(lens, 100_000_000, skew=True)
+    if name in ("near_max_fem", "near_max_short"):
+        want = 2**31 - 65537
+        if name == "near_max_fem":
+            lens = torch.randint(60, 83, (31_000_000,), generator=gen, **i64)
+        else:
+            lens = torch.randint(0, 11, (440_000_000,), generator=gen, **i64)
+        # keep the rows up to the one that crosses the largest accepted count, and shorten that one to land on it exactly
+        cs = torch.cumsum(lens, 0)
+        k = int(torch.searchsorted(cs, torch.tensor([want], **i64)).item())
+        lens = lens[: k + 1].clone()
+        lens[k] -= int(cs[k].item()) - want
+        del cs
+        return from_lens(lens, lens.numel(), skew=False)
     raise SystemExit(f"unknown shape {name}")
 
 
