@@ -37,7 +37,10 @@ PY
   [ -n "$ST" ] && { head -1 $ST; grep -E "spmv_acc" $ST | head -6; } > $OUT/kernel_stats_spmv.csv
   rm -rf $OUT/trace
   i=0
-  for C in "$GROUPS_SQ1" "$GROUPS_SQ2" "$GROUPS_SQ3" "$GROUPS_SQ4" "$GROUPS_TC1" "$GROUPS_TC2" "$GROUPS_TC3" "$GROUPS_TC4" "$GROUPS_TC5" "FETCH_SIZE" "WRITE_SIZE"; do
+  # PMC_LEAN=1: the traffic counters only (request sizes, FETCH_SIZE, WRITE_SIZE) -- the per-stand-in table of moved bytes over all twelve
+  if [ "${PMC_LEAN:-0}" = "1" ]; then PASSES=("$GROUPS_TC4" "FETCH_SIZE" "WRITE_SIZE"); else
+    PASSES=("$GROUPS_SQ1" "$GROUPS_SQ2" "$GROUPS_SQ3" "$GROUPS_SQ4" "$GROUPS_TC1" "$GROUPS_TC2" "$GROUPS_TC3" "$GROUPS_TC4" "$GROUPS_TC5" "FETCH_SIZE" "WRITE_SIZE"); fi
+  for C in "${PASSES[@]}"; do
     i=$((i+1))
     D=$OUT/pmc_$i
     mkdir -p $D
