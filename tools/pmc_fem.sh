@@ -21,6 +21,8 @@ GROUPS_TC5="TCC_EA0_RDREQ_LEVEL_sum TCC_TAG_STALL_sum TCC_READ_SECTORS_sum"
 for W in "$@"; do
   OUT=$R/gpurun_out/pmc_fem_$TAG/${W}_$S
   mkdir -p $OUT
+  # EXTRA_TUNABLES (e.g. strict_strategy=1): set for every pass, the unprofiled one included
+  export SPMV_ACC_TUNABLES="${EXTRA_TUNABLES:-}"
   python3 $R/tools/pmc_fem_run.py --workload $W --strategy $S --iters 40 2> $OUT/plain.log | tail -1 > $OUT/plain.json || { echo "fail plain $W"; tail -3 $OUT/plain.log; continue; }
   cat $OUT/plain.json
   PIN=$(python3 - "$OUT/plain.json" "$S" <<'PY'
@@ -30,7 +32,7 @@ pins = ["stream_plain=%d" % d["stream_policy"]] if d.get("stream_policy", -1) >=
 print(",".join(pins))
 PY
 )
-  export SPMV_ACC_TUNABLES="$PIN"
+  export SPMV_ACC_TUNABLES="$PIN${EXTRA_TUNABLES:+,$EXTRA_TUNABLES}"
   echo "[pmc_fem] $W $S pinned: $SPMV_ACC_TUNABLES"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/tools/pmc_fem_run.py --workload $W --strategy $S --iters 40 > $OUT/trace.json 2> $OUT/trace.log || { echo "fail trace $W"; tail -3 $OUT/trace.log; }
   ST=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
