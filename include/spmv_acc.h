@@ -332,7 +332,9 @@ enum spmv_acc_error {
 /* ---- measurement helper ----------------------------------------------------------------------------------------------------
  * replaces: hip::timer::event_timer around the L1 call (benchmark/utils/timer_utils.h:16-51,
  * benchmark/csr_spmv.hpp:67-74).  Runs `iters` SpMVs with `strategy`; each is bracketed by hipEvents on
- * the library stream, y is restored from d_y0 (device, m doubles, may be NULL) outside the timed region.
+ * the library stream, y is restored from d_y0 (device, m doubles, may be NULL) outside the timed region -- by a non-temporal copy kernel
+ * (round 5: like the DMA write of the reference's hipMemcpy reset, csr_spmv.hpp:68, it parks nothing in the L2s; env SPMV_ACC_RESET_NT=0: the
+ * default-policy copy of rounds 1-4, SPMV_ACC_RESET_MEMCPY=1: hipMemcpyAsync device -> device).
  * ms_out receives iters per-launch durations in milliseconds.  Returns 0 or an error code.  What is timed is a SETTLED plan: the helpers
  * first finish whatever per-matrix timings the first-call budget left open (spmv_acc_prepare_beta: at least one untimed SpMV into a scratch y). */
 int spmv_acc_time_spmv(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
