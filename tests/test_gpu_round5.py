@@ -422,3 +422,40 @@ def test_kernel_clock_reads_the_kernels_own_time(torch_dev, oracle, hiplib):
     finally:
         hiplib.spmv_acc_reset_tunables()
         spmv_acc_amd.release_plans()
+
+
+def test_subnormal_products_and_sums_are_not_flushed(torch_dev, oracle, hiplib):
+    """fp64 subnormals: the reference's host arithmetic (cli/verification.cpp:56-66) keeps them and so must every kernel family -- values and x of
+    ~1e-160 make every product subnormal (~1e-320) and every row sum too.  Sums of subnormals are exact in any order; a product is rounded on its
+    own (mul, then add) or inside an fma, at most one unit of the last subnormal place (2^-1074) apart per non-zero.  A flush to zero anywhere
+    (loads, products, cross-lane sums, the alpha / beta step, stores) would return exact zeros, thousands of units away."""
+    torch = torch_dev
+    ulp = float(np.nextafter(0.0, 1.0))
+    for kind, m, avg in (("uniform", 20000, 6), ("dense_rows", 1500, 400), ("spikes", 20000, 4)):
+        n = m
+        rowptr, cols, vals = synth.random_csr(m, n, avg, seed=11, kind=kind)
+        nnz = int(rowptr[-1])
+        rng = np.random.default_rng(12)
+        vals = rng.uniform(0.5, 2.0, nnz) * 1e-160 * rng.choice([-1.0, 1.0], nnz)
+        x = rng.uniform(0.5, 2.0, n) * 1e-160
+        y0 = rng.uniform(0.5, 2.0, m) * 1e-320
+        ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
+        assert np.count_nonzero(ref) >= 0.99 * m and np.abs(ref).max() < 2.2250738585072014e-308  # (the case is what it says: all subnormal)
+        lens = np.diff(rowptr).astype(np.float64)
+        drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+        try:
+            for strat in spmv_acc_amd.STRATEGIES:
+                for tun in ({}, {"flat_rowblock": 0}) if strat == "flat" else ({},):
+                    for k, v in tun.items():
+                        hiplib.spmv_acc_set_tunable(k.encode(), v)
+                    y = dy0.clone()
+                    spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy=strat)
+                    torch.cuda.synchronize()
+                    got = y.cpu().numpy()
+                    worst = np.max(np.abs(got - ref) / ((lens + 1.0) * ulp))
+                    assert worst <= 1.0, (kind, strat, tun, worst, int(np.count_nonzero(got)))
+                    hiplib.spmv_acc_reset_tunables()
+                    spmv_acc_amd.release_plans(drp)
+        finally:
+            hiplib.spmv_acc_reset_tunables()
+            spmv_acc_amd.release_plans()
