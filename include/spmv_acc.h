@@ -283,6 +283,12 @@ int spmv_acc_query_plan_slab_passes(const int *d_rowptr, int m);
  * 0: the first-call budget (tunable first_call_budget) deferred some, the next calls resume them (or call spmv_acc_prepare); -2 = no such plan.
  * No reference counterpart (the reference times nothing). */
 int spmv_acc_query_plan_settled(const int *d_rowptr, int m);
+/* Did the plan's LATEST SpMV read the plan's 16-bit column encoding instead of colindex (round 6; tunable col16, default: timed per matrix and
+ * kernel family)?  16 / 32 / 64 = yes, with that many ints per 256-non-zero chunk record; 0 = no (the caller's colindex was streamed);
+ * -1 = no SpMV yet; -2 = no such plan.  A plan that uses the encoding holds structure derived from colindex: after editing column indices in
+ * place (same rowptr) call spmv_acc_release_plans (64 samples of colindex are re-checked by every launch, like rowptr's).  No reference counterpart:
+ * the reference streams one 4-byte column per non-zero (hip-flat/flat_imp_one_pass.hpp:35-39, hip-line-enhance/line_enhance_spmv_imp.inl:55-62). */
+int spmv_acc_query_plan_col16(const int *d_rowptr, int m);
 /* Which kernel ran the plan's LATEST SpMV (round 5).  The reference's strategy name IS its kernel (strategy_picker.cpp:19-65); here a name selects a
  * policy by default (`flat` may run the row-block kernel where it timed faster, `line_enhance` the column-slab passes on power-law columns) and
  * tunable strict_strategy = 1 (SPMV_ACC_TUNABLES=strict_strategy=1) binds the name to its algorithm.  -1 = no SpMV yet, -2 = no such plan. */

@@ -36,7 +36,7 @@ C_ABI_SYMBOLS = (
     "spmv_acc_set_stream", "spmv_acc_get_stream", "spmv_acc_last_error", "spmv_acc_last_error_string",
     "spmv_acc_clear_error", "spmv_acc_time_spmv", "spmv_acc_version", "spmv_acc_set_tunable",
     "spmv_acc_get_tunable", "spmv_acc_reset_tunables", "spmv_acc_time_spmv_total", "spmv_acc_copy_ceiling_gbs", "spmv_acc_adaptive_plus_analyze_device", "spmv_acc_prepare",
-    "spmv_acc_last_prepare_us", "spmv_acc_sharded_spmv", "spmv_acc_shard_prepare", "spmv_acc_csr_spmv_chunks", "spmv_acc_query_plan_settled", "spmv_acc_csr_spmv_oop", "spmv_acc_check_plans",
+    "spmv_acc_last_prepare_us", "spmv_acc_sharded_spmv", "spmv_acc_shard_prepare", "spmv_acc_csr_spmv_chunks", "spmv_acc_query_plan_settled", "spmv_acc_query_plan_col16", "spmv_acc_csr_spmv_oop", "spmv_acc_check_plans",
     "spmv_acc_query_plan_beta0", "spmv_acc_query_plan_slab_passes", "spmv_acc_shard_create", "spmv_acc_shard_step", "spmv_acc_shard_pipeline",
     "spmv_acc_shard_destroy", "spmv_acc_rccl_comm_init_all", "spmv_acc_rccl_comm_destroy", "spmv_acc_set_tune_cache",
     "spmv_acc_prepare_beta", "spmv_acc_time_spmv_events", "spmv_acc_refresh_values", "spmv_acc_time_spmv_region", "spmv_acc_query_plan_last_kernel", "spmv_acc_time_spmv_kernels",
@@ -117,6 +117,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_query_plan_beta0.argtypes = [vp, ci]
     lib.spmv_acc_query_plan_slab_passes.argtypes = [vp, ci]
     lib.spmv_acc_query_plan_settled.argtypes = [vp, ci]
+    lib.spmv_acc_query_plan_col16.argtypes = [vp, ci]
     lib.spmv_acc_query_plan_last_kernel.argtypes = [vp, ci]
     lib.spmv_acc_shard_create.argtypes = [ctypes.POINTER(vp), vp, ci, ci, ci, ci, ci, vp, vp, vp, ci]
     lib.spmv_acc_shard_step.argtypes = [vp, cd, cd, vp, vp, vp]
@@ -424,6 +425,7 @@ def query_plan(rowptr, m: int):
     info = dict(zip(keys, (int(v) for v in out)))
     info["slab_passes"] = max(0, int(load_library().spmv_acc_query_plan_slab_passes(_ptr(rowptr), m)))
     info["settled"] = int(load_library().spmv_acc_query_plan_settled(_ptr(rowptr), m)) == 1
+    info["col16"] = int(load_library().spmv_acc_query_plan_col16(_ptr(rowptr), m))
     info["last_kernel"] = KERNEL_NAMES.get(int(load_library().spmv_acc_query_plan_last_kernel(_ptr(rowptr), m)), "none")
     return info
 

@@ -390,6 +390,10 @@ int spmv_acc_query_plan_last_kernel(const int *d_rowptr, int m) {
   PlanInfo info;
   return query_plan(d_rowptr, m, &info) ? info.last_kernel : -2;
 }
+int spmv_acc_query_plan_col16(const int *d_rowptr, int m) {
+  PlanInfo info;
+  return query_plan(d_rowptr, m, &info) ? info.col16 : -2;
+}
 int spmv_acc_query_plan_settled(const int *d_rowptr, int m) {
   PlanInfo info;
   return query_plan(d_rowptr, m, &info) ? info.settled : -2;

@@ -123,9 +123,11 @@ Tunable g_tunables[] = {
     {"vector_tile", 1, 1},     // vector_row / light / the two-width split: 1 = w lanes per row over LDS-staged tiles (16-B stream
                                // loads), 0 = w lanes per row straight from global memory (4-/8-byte loads; also the form very
                                // uneven matrices keep)
-    {"col16", 0, 0},           // OPT-IN, flat only: 1 = the plan holds a 16-bit encoding of colindex (per-256-non-zero base + escape list,
-                               // k_col16.hip) and the tile kernel streams 2 B instead of 4 B per column.  The plan then holds a copy
-                               // derived from colindex: after editing colindex in place call spmv_acc_release_plans.
+    {"col16", -1, -1},         // 16-bit column encoding (k_col16.hip; row blocks and flat): -1 = built once per plan and timed against the caller's
+                               // colindex per kernel family, kept where it wins by > 1.5 %; 0 never; 1 always where it can be built (16 / 32 / 64
+                               // also pin the record size: tests).  A plan that uses it holds structure DERIVED from colindex: 64 samples of
+                               // colindex are re-checked by every launch (like rowptr's), an in-place edit between the samples needs
+                               // spmv_acc_release_plans -- `deterministic` and col16 = 0 keep to the caller's arrays.
     {"vector_width", 0, 0},    // vector_row / light: lanes per row; 0 = the reference's rule (vector_row.cpp:15-27: pow2 >= avg row length / 2)
     {"zigzag", 1, 1},          // every other SpMV on a plan walks the matrix in reverse block / tile order: with the streams cacheable, what the
                                // previous SpMV touched last is still in the 256 MB Infinity Cache when the next one starts there

@@ -82,6 +82,16 @@ template <bool NT> __device__ __forceinline__ double2v load_stream_d2(const doub
   return NT ? __builtin_nontemporal_load(reinterpret_cast<const double2v_a8 *>(p)) : *reinterpret_cast<const double2v_a8 *>(p);
 }
 
+// ---- gathers with a 32-bit byte offset (round 6) ------------------------------------------------------------------------------
+// x[col] through the scalar-base form of global_load (`global_load_dwordx2 v, v_off, s[x:x+1]`): the address is the wave-uniform
+// pointer plus an UNSIGNED 32-bit byte offset held in one VGPR -- one shift per gather instead of sign-extend + 64-bit shift-add,
+// and one address register instead of two (eight gathers in flight per lane: the difference between 65-67 and <= 64 VGPRs, i.e.
+// between 7 and 8 waves per SIMD, in the row-block kernel's instances).  Valid while 8 * n < 2^32; the launchers pass the
+// kernel-uniform flag `x32` only then (kernels.hpp x32_ok), larger x takes the general staging form with its 64-bit addresses.
+__device__ __forceinline__ double gather_u32(const double *x, int col) {
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + (static_cast<unsigned>(col) << 3));
+}
+
 // ---- hinted gathers -------------------------------------------------------------------------------------------------------
 // A gather whose cache policy is chosen per lane.  Written as `cold ? nontemporal_load(p) : *p` the compiler folds the two loads
 // into one plain load of a selected address; buffer loads carry the policy as an immediate operand of the builtin, so the two

@@ -24,14 +24,19 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
   }
   p.A.cold = nullptr; // (the plan-time timings below run without gather hints)
   p.flat.col16 = nullptr;
-  if (tun(kT_col16) > 0) {
-    if (!ensure_col16(p, st)) return false;
-    p.flat.col16 = &p.col16; // (used by the 2048-non-zero tile only; other tile sizes read colindex)
-  }
   if (!autotune_policy(p, kFamFlat, st, [&](int pol, double *ys) { launch_flat_with(st, p, pol, 1.0, trial_beta(), x, ys); })) return false;
   if (!autotune_flat_mode(p, st, x)) return false;
   if (!autotune_flat_geometry(p, st, x)) return false;
   if (!autotune_hint(p, kFamFlat, st, [&](double *ys) { launch_flat_with(st, p, policy_for(p, kFamFlat), 1.0, trial_beta(), x, ys); })) return false;
+  // the 16-bit column encoding (round 6: timed per matrix; read by the 2048-non-zero tile only, other tile sizes read colindex)
+  const Col16 *c16 = nullptr;
+  if (p.flat.stride == kThreads * kNnzPerThread && !flat_segment_sum() &&
+      !autotune_col16(p, kFamFlat, st, [&](const Col16 *c, double *ys) {
+        p.flat.col16 = c;
+        launch_flat_with(st, p, policy_for(p, kFamFlat), 1.0, trial_beta(), x, ys);
+      }, &c16))
+    return false;
+  p.flat.col16 = c16;
   // Small grids: the tile kernel's extra dependent hop (tile digest -> row extents) is not hidden by other workgroups.  Where the
   // fixed row blocks are balanced (nothing for non-zero-cut tiles to repair) the two kernels are timed once and the faster runs.
   const int rb_mode = tun(kT_flat_rowblock);
@@ -77,6 +82,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
   }
   launch_flat_with(st, p, policy_for(p, kFamFlat), alpha, beta, x, y);
   p.last_kernel = kKernelFlatTile;
+  p.last_c16 = c16 && p.flat.stride == kThreads * kNnzPerThread && p.A.cold == nullptr ? c16->rec_ints : 0;
   return true;
 }
 
@@ -253,9 +259,17 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
         launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p, kFamRowblock) << 4) | zz, 1.0, trial_beta(), x, ys, dg, cache_ends);
       }))
     return false;
+  // the 16-bit column encoding (round 6): built once per plan, timed once per family against the caller's colindex
+  const Col16 *c16 = nullptr;
+  if (!autotune_col16(p, kFamRowblock, st, [&](const Col16 *c, double *ys) {
+        const int zz = next_reverse(p) ? 64 : 0;
+        launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p, kFamRowblock) << 4) | zz, 1.0, trial_beta(), x, ys, dg, cache_ends, c);
+      }, &c16))
+    return false;
   const int zz = next_reverse(p) ? 64 : 0;
-  launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p, kFamRowblock) << 4) | zz, alpha, beta, x, y, dg, cache_ends);
+  launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p, kFamRowblock) << 4) | zz, alpha, beta, x, y, dg, cache_ends, c16);
   p.last_kernel = kKernelRowblock;
+  p.last_c16 = c16 && p.A.cold == nullptr ? c16->rec_ints : 0;
   return true;
 }
 
@@ -724,6 +738,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     ~YinScope() { A.yin = nullptr; }
   } yin_scope{p->A};
   p->A.yin = beta != 0.0 ? dy_in : nullptr;
+  p->last_c16 = 0; // (run_rowblock / run_flat say otherwise when this call's kernel reads the 16-bit column encoding)
 
   if (p->A.count() == 0) {
     launch_scale_y(st, m, beta, dy, p->A.yin);

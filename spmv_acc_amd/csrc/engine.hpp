@@ -142,6 +142,7 @@ struct PlanInfo {
   int adaptive_family_beta0 = -1; // ... of the beta == 0 class alone
   int slab_passes = 0;            // column slabs whose run lists the plan holds and uses (k_segment.hip), 0 = none
   int last_kernel = -1;           // the kernel behind the plan's latest SpMV (SPMV_ACC_KERNEL_* in include/spmv_acc.h), -1 = none yet
+  int col16 = -1;                 // the plan's latest SpMV read the 16-bit column encoding: record ints (16 / 32 / 64), 0 = colindex, -1 = no SpMV yet
   int settled = 0;                // 1: the plan's latest call left no per-matrix timing open (first_call_budget / later_call_budget); 0: later calls will resume some
 };
 bool query_plan(const int *d_rowptr, int m, PlanInfo *out);

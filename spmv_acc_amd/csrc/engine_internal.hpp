@@ -79,6 +79,7 @@ struct Plan {
   unsigned long long calls = 0;    // SpMV calls served by this plan (the first one builds and tunes it)
   unsigned launches = 0;           // tile-kernel launches so far (parity = walking direction, tunable zigzag)
   double trial_ms = 0.0;           // a trial launch of this matrix as the per-matrix timings measured it: prices later calls' tuning budget
+  int last_c16 = -1;               // the plan's latest SpMV read the 16-bit column encoding (its record ints) or colindex (0): spmv_acc_query_plan_col16
   int last_kernel = -1;            // which kernel the plan's latest SpMV ran (kKernel*, below): spmv_acc_query_plan_last_kernel, strict_strategy's test
   bool tuning_open = true;         // some per-matrix timing was deferred (or has not been reached yet): later calls may resume it
   CsrDev A;
@@ -107,7 +108,8 @@ struct Plan {
   // flat
   int flat_tiles = -1;
   FlatPlan flat;
-  Col16 col16;                  // opt-in 16-bit column encoding (tunable col16), built on first use
+  Col16 col16;                  // 16-bit column encoding (k_col16.hip), built the first time a family wants to time it (tunable col16: -1 timed, 0 never, 1 always)
+  int c16_use[kFamilyCount] = {-1, -1, -1, -1}; // timed choice per kernel family: -1 not timed, 0 the caller's colindex, 1 the encoding (row blocks and flat only)
   int flat_npt_choice = 0;      // timed tile size (non-zeros per lane), 0 = not timed
   bool flat_geometry_tuned = false;
   int flat_rowblock_choice = -1;       // small grids: -1 not timed, 0 flat's own tile kernel, 1 the row-block kernel (tunable flat_rowblock)
@@ -162,9 +164,9 @@ struct Plan {
   bool is_stale() const { return A.stale && __atomic_load_n(A.stale, __ATOMIC_RELAXED) != 0; }
   void free_col16() {
     if (col16.d16) (void)hipFree(col16.d16);
-    if (col16.base) (void)hipFree(col16.base);
-    if (col16.esc_start) (void)hipFree(col16.esc_start);
-    if (col16.esc_cols) (void)hipFree(col16.esc_cols);
+    if (col16.rec) (void)hipFree(col16.rec);
+    if (col16.ovf) (void)hipFree(col16.ovf);
+    if (col16.ci_guard) (void)hipFree(col16.ci_guard);
     col16 = Col16();
   }
   void free_digest() {
@@ -240,10 +242,10 @@ struct Plan {
 };
 
 struct TuneRecord {
-  int v[22]; // stream_policy[4][2], adaptive_family[2], flat_npt, flat_early, flat_geometry_tuned, flat_mode[2], plus_min, hint_state0, hint_use[3], flat_rowblock, seg_choice
+  int v[24]; // stream_policy[4][2], adaptive_family[2], flat_npt, flat_early, flat_geometry_tuned, flat_mode[2], plus_min, hint_state0, hint_use[3], flat_rowblock, seg_choice, c16_use[row blocks], c16_use[flat]
   bool operator==(const TuneRecord &o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
 };
-constexpr int kTuneFields = 22;
+constexpr int kTuneFields = 24;
 bool tune_cache_enabled();
 void tune_adopt(Plan &p);
 void tune_store(const Plan &p);
@@ -510,6 +512,44 @@ template <class Launch> bool autotune_hint(Plan &p, int fam, hipStream_t st, Lau
              t_beta_class, ms[0] * 1e3f, ms[1] * 1e3f, p.hint_use[fam] ? "hinted" : "plain");
   }
   p.A.cold = p.hint_use[fam] == 1 ? p.d_cold : nullptr;
+  return true;
+}
+
+// The 16-bit column encoding for kernel family `fam` (row blocks, flat): forced by the tunable, else built once per plan and timed once per family
+// against the caller's colindex -- in turns, like every ranking of near-equal candidates -- and kept where it wins by > 1.5 %.
+// `launch(c16, ys)` launches the family's kernel with the plan's current settings writing to ys, c16 = the encoding or null.  *out: what this
+// call's launch should use.  Not with gather hints (p.A.cold set: power-law columns, nothing local to encode), not by rule (`deterministic`:
+// the caller's arrays as they are), not inside a capture unless everything is decided, not while adaptive is still comparing families.
+template <class Launch> bool autotune_col16(Plan &p, int fam, hipStream_t st, Launch launch, const Col16 **out) {
+  *out = nullptr;
+  const int mode = tun(kT_col16);
+  if (mode == 0 || p.A.cold != nullptr || p.col16.state == 0) return true;
+  if (mode < 0 && (tun(kT_deterministic) || p.c16_use[fam] == 0)) return true;
+  const bool undecided = p.col16.state < 0 || (mode < 0 && p.c16_use[fam] < 0);
+  if (undecided) {
+    if (t_capturing || (mode < 0 && (t_coarse_tuning || t_no_policy_timing || defer_tuning()))) return true;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return true;
+    (void)hipGetLastError();
+  }
+  if (!ensure_col16(p, st)) return false;
+  if (p.col16.state != 1) return true;
+  if (mode < 0 && p.c16_use[fam] < 0) {
+    ++t_plan_work;
+    double *scratch = nullptr;
+    if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
+    TuneTimer timer;
+    timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
+    bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
+    float ms[2] = {0.f, 0.f};
+    ok = ok && timer.time_in_turns(st, 2, [&](int c) { launch(c ? &p.col16 : nullptr, scratch); }, ranking_rounds(), ms);
+    if (!ok) return false;
+    p.c16_use[fam] = ms[1] < 0.985f * ms[0] ? 1 : 0;
+    tune_log("m %d nnz %d family %d beta class %d 16-bit columns (%d ints per chunk record, %lld escapes, %lld in overflow): colindex %.2f us, encoding %.2f us -> %s",
+             p.A.m, p.A.nnz, fam, t_beta_class, p.col16.rec_ints, p.col16.escapes, p.col16.overflow, ms[0] * 1e3f, ms[1] * 1e3f,
+             p.c16_use[fam] ? "encoding" : "colindex");
+  }
+  if (mode > 0 || p.c16_use[fam] == 1) *out = &p.col16;
   return true;
 }
 

@@ -59,12 +59,6 @@ __device__ __forceinline__ int tile_end_excl(const int *__restrict__ rp, const i
   return (e < m && rp[e] < t1) ? e + 1 : e;
 }
 
-// device-side view of the plan's 16-bit column encoding (kernels.hpp Col16), passed by value
-struct Col16Dev {
-  const unsigned short *d16;
-  const int *base, *esc_start, *esc_cols;
-};
-
 // (amdgpu_waves_per_eu(7): the register allocator is asked to stay within 72 VGPRs -- 7 workgroups per CU -- where the
 // plain kernel with the finishing prefetch would take 78; the stream-first variants need more registers by design)
 // SEGSUM: the reference's other reduction of a flat tile (FLAT_SEGMENT_SUM_REDUCE, hip-flat/flat.cpp:59-76 +
@@ -97,7 +91,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
     sh_tail_row = -1;
     spans.n = 0;
   }
-  int t = reverse ? zigzag_block(blockIdx.x, ntiles) : static_cast<int>(blockIdx.x); // every other SpMV walks the tiles backwards
+  int t = (reverse & 1) ? zigzag_block(blockIdx.x, ntiles) : static_cast<int>(blockIdx.x); // every other SpMV walks the tiles backwards
   if (xcd_chunk > 0) t = xcd_chunked_block(t, ntiles, xcd_chunk);
   const int t0 = (t + tile0) * STRIDE; // host guarantees nnz + stride fits in int
   const int t1 = (nnz - t0 > STRIDE) ? t0 + STRIDE : nnz;
@@ -159,12 +153,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EARLY 
     }
   }
 
-  if (C16 && stage_fast_ok(t1, nnz)) // (the one tile that holds the ragged end of the arrays reads colindex as usual)
-    stage_products_col16<kThreads, NPT, NTV>(lds, t0, t1, c16.d16, c16.base, c16.esc_start, c16.esc_cols, v, x);
+  if (C16) check_ci_guard(ci, c16, stale);
+  if (C16 && stage_fast_ok(t1, nnz)) // (the one tile that holds the ragged end of the arrays reads colindex as usual; the engine vouches for x32)
+    stage_products_c16<kThreads, NPT, NTC, NTV>(lds, t0, t0, t1, c16, v, x);
   else if (EARLY && early) stage_finish<kThreads, EARLY ? NPT : 4>(lds, early_regs, x);
   else if (NTC && NTV && cache_ends > 0 && (t < cache_ends || t >= ntiles - cache_ends)) // (k_rowblock.hip: cacheable grid ends)
-    stage_products<kThreads, NPT, false, false, HINT>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0, cold);
-  else stage_products<kThreads, NPT, NTC, NTV, HINT>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0, cold);
+    stage_products<kThreads, NPT, false, false, HINT>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0, cold, (reverse & 2) != 0);
+  else stage_products<kThreads, NPT, NTC, NTV, HINT>(lds, t0, t1, nnz, ci, v, x, xcd_chunk >= 0, cold, (reverse & 2) != 0);
 
   double fin_extra = 0.0; // this lane's share of the overhang (first wave, finish mode)
   if (fin) {
@@ -379,43 +374,43 @@ namespace {
 template <int NPT, bool NTC, bool NTV>
 void launch_flat_variant(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                          double *y) {
-  const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
+  const Col16Dev none = {};
   if (P.early_stream)
     SPMV_ACC_LAUNCH((flat_tile_kernel<NPT, NTC, NTV, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, (P.reverse ? 1 : 0) | (x32_ok(A) ? 2 : 0), P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
   else
     SPMV_ACC_LAUNCH((flat_tile_kernel<NPT, NTC, NTV, false>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m, A.nnz,
                        P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
-                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
+                       P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, (P.reverse ? 1 : 0) | (x32_ok(A) ? 2 : 0), P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
 }
 // the segmented-scan reduction (reference option FLAT_SEGMENT_SUM_REDUCE): 2048-non-zero tiles, values / colindex under the plan's policy
 template <bool NTC, bool NTV>
 void launch_flat_segsum(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                         double *y) {
-  const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
+  const Col16Dev none = {};
   SPMV_ACC_LAUNCH((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
-                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, (P.reverse ? 1 : 0) | (x32_ok(A) ? 2 : 0), P.cache_ends,
                      static_cast<const int4v *>(P.digest), nullptr);
 }
 // gather hints: 2048-non-zero tiles, break-point chain first
 template <bool NTC, bool NTV>
 void launch_flat_hint(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x, double *y) {
-  const Col16Dev none = {nullptr, nullptr, nullptr, nullptr};
+  const Col16Dev none = {};
   SPMV_ACC_LAUNCH((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, false, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
-                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, P.reverse ? 1 : 0, P.cache_ends,
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, none, (P.reverse ? 1 : 0) | (x32_ok(A) ? 2 : 0), P.cache_ends,
                      static_cast<const int4v *>(P.digest), A.cold);
 }
-// opt-in 16-bit columns: NPT 8 tiles (a multiple of the 256-non-zero chunk), values under the plan's cache policy
-template <bool NTV>
+// 16-bit columns (the plan's encoding, timed per matrix): NPT 8 tiles (a multiple of the 256-non-zero chunk), offsets / values under the plan's cache policy
+template <bool NTC, bool NTV>
 void launch_flat_col16(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
                        double *y) {
-  const Col16Dev c = {P.col16->d16, P.col16->base, P.col16->esc_start, P.col16->esc_cols};
-  SPMV_ACC_LAUNCH((flat_tile_kernel<kNnzPerThread, true, NTV, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
+  const Col16Dev c = col16_dev(*P.col16, A);
+  SPMV_ACC_LAUNCH((flat_tile_kernel<kNnzPerThread, NTC, NTV, false, true>), dim3(P.ntiles), dim3(kThreads), 0, stream, A.m,
                      A.nnz, P.ntiles, alpha, beta, A.rp, P.bp, A.ci, A.v, x, y, A.yin ? A.yin : y, P.head, P.tail, P.tail_row, P.tail_end,
-                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, c, P.reverse ? 1 : 0, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
+                     P.xcd_chunk, P.needs_fixup ? 0 : kFlatFinish, P.tile0, A.guard, A.stale, c, (P.reverse ? 1 : 0) | 2, P.cache_ends, static_cast<const int4v *>(P.digest), nullptr);
 }
 template <int NPT>
 void launch_flat_policy(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double alpha, double beta, const double *x,
@@ -459,10 +454,13 @@ void launch_flat(hipStream_t stream, const CsrDev &A, const FlatPlan &P, double 
     case 3: launch_flat_hint<true, false>(stream, A, P, alpha, beta, x, y); break;
     default: launch_flat_hint<true, true>(stream, A, P, alpha, beta, x, y); break;
     }
-  } else if (P.col16 && npt == kNnzPerThread) {
-    // values default for policies 1 (both default) and 3 (values default), non-temporal otherwise
-    if ((P.stream_policy & 3) == 1 || (P.stream_policy & 3) == 3) launch_flat_col16<false>(stream, A, P, alpha, beta, x, y);
-    else launch_flat_col16<true>(stream, A, P, alpha, beta, x, y);
+  } else if (P.col16 && P.col16->state == 1 && x32_ok(A) && npt == kNnzPerThread) {
+    switch (P.stream_policy & 3) {
+    case 1: launch_flat_col16<false, false>(stream, A, P, alpha, beta, x, y); break;
+    case 2: launch_flat_col16<false, true>(stream, A, P, alpha, beta, x, y); break;
+    case 3: launch_flat_col16<true, false>(stream, A, P, alpha, beta, x, y); break;
+    default: launch_flat_col16<true, true>(stream, A, P, alpha, beta, x, y); break;
+    }
   } else if (npt == 4) launch_flat_policy<4>(stream, A, P, alpha, beta, x, y);
   else if (npt == 16) launch_flat_policy<16>(stream, A, P, alpha, beta, x, y);
   else launch_flat_policy<8>(stream, A, P, alpha, beta, x, y);

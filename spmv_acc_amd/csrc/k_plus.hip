@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
   __shared__ double row_acc[kPlusMaxRows];
   __shared__ TileSpans spans;
   if (threadIdx.x == 0) spans.n = 0; // published by the barrier that follows the first staging
-  int g = reverse ? zigzag_block(blockIdx.x, nblocks) : static_cast<int>(blockIdx.x); // zigzag (dispatch.cpp)
+  int g = (reverse & 1) ? zigzag_block(blockIdx.x, nblocks) : static_cast<int>(blockIdx.x); // zigzag (dispatch.cpp)
   if (xcd_chunk > 0) g = xcd_chunked_block(g, nblocks, xcd_chunk);
   const int4v rec = blk[g]; // wave-uniform: one scalar 16-B load
   const int row_begin = rec.x;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void plus_kernel(int nnz, int nblocks, in
     }
     double acc = 0.0;
     for (int off = a0; off < s1; off += kPlusTile) {
-      stage_products<kThreads, kPlusNpt, NTC, NTV, HINT>(lds, off, s1, nnz, ci, v, x, true, cold);
+      stage_products<kThreads, kPlusNpt, NTC, NTV, HINT>(lds, off, s1, nnz, ci, v, x, true, cold, (reverse & 2) != 0);
       __syncthreads();
       const int lo = (r0 > off ? r0 : off) - off;
       const int hi = (r1 < off + kPlusTile ? r1 : off + kPlusTile) - off;
@@ -206,7 +206,7 @@ void launch_plus(hipStream_t stream, const CsrDev &A, const int *bp, const int *
   if (nblocks <= 0) return;
 #define SPMV_ACC_LAUNCH_PLUS(NC, NV, H)                                                                             \
   SPMV_ACC_LAUNCH((plus_kernel<NC, NV, H>), dim3(nblocks), dim3(kThreads), 0, stream, A.nnz, nblocks, xcd_chunk, \
-                     alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, partial, A.m, A.guard, A.stale, reverse ? 1 : 0, \
+                     alpha, beta, static_cast<const int4v *>(blk), A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, partial, A.m, A.guard, A.stale, (reverse ? 1 : 0) | (x32_ok(A) ? 2 : 0), \
                      A.cold)
   if (A.cold != nullptr) { // gather hints (kernels.hpp): cold gathers non-temporal
     switch (stream_policy & 3) {

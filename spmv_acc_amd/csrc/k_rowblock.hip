@@ -45,7 +45,9 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 }
 
 // HINT: gather hints (k_hint.hip): the block's gathers take their cache policy from the plan's cold bits.
-template <int VEC, bool NTC, bool NTV, bool LENS, bool HINT = false>
+// C16: the non-zeros' columns come from the plan's 16-bit encoding (k_col16.hip) instead of colindex: 2.25 B instead of 4 B of stream per
+// non-zero.  The tile origin is then aligned down to a 256-non-zero chunk (a wavefront's step = one chunk record) instead of to 4.
+template <int VEC, bool NTC, bool NTV, bool LENS, bool HINT = false, bool C16 = false>
 __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nnz, int nblocks, int rpb, int flags,
                                                                    double alpha, double beta,
                                                                    const int *__restrict__ rp,
@@ -57,13 +59,14 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
                                                                    int *__restrict__ stale,
                                                                    const unsigned char *__restrict__ lens,
                                                                    const int *__restrict__ base, int cache_ends,
-                                                                   const unsigned char *__restrict__ cold) {
+                                                                   const unsigned char *__restrict__ cold, Col16Dev c16) {
   check_plan_guard(rp, m, guard, stale);
+  if (C16) check_ci_guard(ci, c16, stale);
   __shared__ int wave_tot[kThreads / kWave];
   // rpb rows per workgroup, rpb <= kThreads / VEC (not necessarily a power of two: it is chosen so that
   // rpb * average row length fills most of one LDS tile)
   __shared__ __attribute__((aligned(16))) double lds[kTile]; // written 16 B at a time
-  __shared__ TileSpans spans;
+  __shared__ TileSpans2K spans;
   if (threadIdx.x == 0) spans.n = 0; // published by the barrier that follows the first staging
 
   int b = blockIdx.x;
@@ -112,18 +115,27 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
     incl = wave_inclusive_scan(lane == 0 ? len : 0);
     if ((threadIdx.x & (kWave - 1)) == kWave - 1) wave_tot[threadIdx.x / kWave] = incl;
   }
-  // tile origin aligned down so 16-B loads stay aligned; the (at most 3) extra leading products are never read
-  for (int off = s0 & ~3; off < s1; off += kTile) {
+  // tile origin aligned down so 16-B loads stay aligned; the (at most 3) extra leading products are never read (C16: aligned down to the
+  // chunk, the lanes in front of the block's first group re-read that group)
+  const int lo4 = s0 & ~3;
+  // (an EMPTY block whose first group starts at s1 stages nothing: lo4 >= s1 ends the loop before it starts, as without the encoding)
+  const int off0 = (C16 && lo4 < s1) ? (s0 & ~(kCol16Chunk - 1)) : lo4;
+  const bool c16_ok = C16 && stage_fast_ok(s1, nnz); // (the one block that holds the ragged end of the arrays reads colindex as usual)
+  for (int off = off0; off < s1; off += kTile) {
     // Plans that stream non-temporally (short rows: the vectors are worth more cache than the matrix) still keep the two ENDS
     // of the grid cacheable -- `cache_ends` blocks each, ~24 MB of stream, an L2's worth: with the zigzag order those are the
     // blocks the next SpMV starts with (Hardesty3-sized 155.0 -> 152.9 us; 8 / 16 / 24 / 32 / 48 / 100 MB: 153.5 / 152.9 / 152.9 /
     // 152.9 / 153.3 / 155.1).
-    if (NTC && NTV && cache_ends > 0 && (b < cache_ends || b >= nblocks - cache_ends))
-      stage_products<kThreads, kNnzPerThread, false, false, HINT>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0, cold);
+    const bool cached_end = NTC && NTV && cache_ends > 0 && (b < cache_ends || b >= nblocks - cache_ends);
+    if (C16 && c16_ok) {
+      if (cached_end) stage_products_c16<kThreads, kNnzPerThread, false, false>(lds, off, lo4 > off ? lo4 : off, s1, c16, v, x);
+      else stage_products_c16<kThreads, kNnzPerThread, NTC, NTV>(lds, off, lo4 > off ? lo4 : off, s1, c16, v, x);
+    } else if (cached_end)
+      stage_products<kThreads, kNnzPerThread, false, false, HINT>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0, cold, (flags & 128) != 0);
     else
-      stage_products<kThreads, kNnzPerThread, NTC, NTV, HINT>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0, cold);
+      stage_products<kThreads, kNnzPerThread, NTC, NTV, HINT>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0, cold, (flags & 128) != 0);
     __syncthreads();
-    if (LENS && from_lens && off == (s0 & ~3)) {
+    if (LENS && from_lens && off == off0) {
       const int w = threadIdx.x / kWave;
       int before = s0;
 #pragma unroll
@@ -133,19 +145,11 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
     }
     const int lo = (r0 > off ? r0 : off) - off;
     const int hi = (r1 < off + kTile ? r1 : off + kTile) - off;
-#ifdef SPMV_ACC_EXP_NO_ROW_SUM // (dissection builds only, profiles/r05_short_row_dissection.txt: one LDS read per row instead of its sum)
-    acc += lds[lo < kTile ? lo : 0] + static_cast<double>(hi);
-#else
     acc += tile_row_sum<kThreads>(lds, spans, lo, hi > lo ? hi : lo, lane, VEC); // long spans go to whole waves
-#endif
     if (off + kTile < s1) __syncthreads(); // next round overwrites the tile
   }
   acc = group_sum<VEC>(acc);
-#ifdef SPMV_ACC_EXP_NO_Y_STORE // (dissection builds only: the store stays in the code, its condition is never true)
-  if (writer && acc == 123.456e300) {
-#else
   if (writer) {
-#endif
     // non-temporal store (round 5): a write stream beside a read stream costs the memory system ~3 x its bytes (read_write_mix_bench.hip: 24 KB read +
     // 2 KB written per workgroup reads at 5.1-5.7 TB/s, 5.4-5.9 with non-temporal stores); in this kernel: banded shard -2.1 %, the other stand-ins
     // -0.1 ... -0.6 %, none slower (two builds A/B-ed in one process, profiles/r05_short_row_dissection.txt)
@@ -201,41 +205,56 @@ __global__ __launch_bounds__(256) void row_digest_lens_kernel(const int *__restr
   if (len > 255 || len < 0) atomicOr(base + r / rpb, static_cast<int>(0x80000000u));
 }
 
+template <int VEC, bool NC, bool NV, bool LN, bool H, bool C>
+void launch_rb_instance(hipStream_t stream, const CsrDev &A, const RowDigest *D, const Col16Dev &c16, int nblocks, int rpb, int flags,
+                        double alpha, double beta, const double *x, double *y, int cache_ends) {
+  SPMV_ACC_LAUNCH((rowblock_stream_kernel<VEC, NC, NV, LN, H, C>), dim3(nblocks), dim3(kThreads), 0, stream, A.m, A.nnz, nblocks, rpb, flags,
+                     alpha, beta, A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, A.guard, A.stale,
+                     LN ? D->lens : static_cast<const unsigned char *>(nullptr), LN ? D->base : static_cast<const int *>(nullptr), cache_ends,
+                     H ? A.cold : static_cast<const unsigned char *>(nullptr), c16);
+}
+
+// Instances: the row digest (LENS) exists for lane groups of 1 and 2 only -- it is used for rows of <= 8 non-zeros on average, where the shape
+// rule gives every row one lane; a digest asked for with wider groups is ignored (the kernel reads rowptr: same result).  Gather hints and the
+// 16-bit columns exclude each other (hints serve power-law columns, the encoding local ones): three staging forms per policy.
+template <int VEC, bool NC, bool NV>
+void launch_policy(hipStream_t stream, const CsrDev &A, const RowDigest *D, const Col16 *C, int nblocks, int rpb, int flags, double alpha,
+                   double beta, const double *x, double *y, int cache_ends) {
+  const bool lens = VEC <= 2 && D && D->lens;
+  const bool c16 = C && C->state == 1 && A.cold == nullptr && x32_ok(A);
+  const Col16Dev cd = c16 ? col16_dev(*C, A) : Col16Dev{};
+#define SPMV_ACC_RB(LN, H, CC) launch_rb_instance<VEC, NC, NV, LN, H, CC>(stream, A, D, cd, nblocks, rpb, flags, alpha, beta, x, y, cache_ends)
+  if constexpr (VEC <= 2) {
+    if (lens) {
+      if (c16) SPMV_ACC_RB(true, false, true);
+      else if (A.cold) SPMV_ACC_RB(true, true, false);
+      else SPMV_ACC_RB(true, false, false);
+      return;
+    }
+  }
+  if (c16) SPMV_ACC_RB(false, false, true);
+  else if (A.cold) SPMV_ACC_RB(false, true, false);
+  else SPMV_ACC_RB(false, false, false);
+#undef SPMV_ACC_RB
+}
+
 template <int VEC>
-void launch_vec(hipStream_t stream, const CsrDev &A, const RowDigest *D, int rpb, int xcd, double alpha, double beta,
+void launch_vec(hipStream_t stream, const CsrDev &A, const RowDigest *D, const Col16 *C, int rpb, int xcd, double alpha, double beta,
                 const double *x, double *y, int cache_ends) {
   if (rpb < 1 || rpb > kThreads / VEC) rpb = kThreads / VEC;
   if (D && D->rpb != rpb) D = nullptr; // a digest built for another block size does not apply
   const int nblocks = static_cast<int>((static_cast<long long>(A.m) + rpb - 1) / rpb);
   if (nblocks == 0) return;
-  const int remap = ((xcd & 1) && nblocks >= 64 ? 1 : 0) | (xcd & ~1);
+  const int remap = ((xcd & 1) && nblocks >= 64 ? 1 : 0) | (xcd & ~1) | (x32_ok(A) ? 128 : 0); // bit 7: 32-bit gather offsets
   // bits 4-5 of the flags: cache policy of the stream loads (0 nt/nt, 1 plain/plain, 2 colindex plain + values nt,
-  // 3 colindex nt + values plain)
-#define SPMV_ACC_LAUNCH_RB_H(NC, NV, LN, H)                                                                         \
-  SPMV_ACC_LAUNCH((rowblock_stream_kernel<VEC, NC, NV, LN, H>), dim3(nblocks), dim3(kThreads), 0, stream, A.m,   \
-                     A.nnz, nblocks, rpb, remap, alpha, beta, A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, A.guard, A.stale,             \
-                     LN ? D->lens : static_cast<const unsigned char *>(nullptr),                                   \
-                     LN ? D->base : static_cast<const int *>(nullptr), cache_ends, A.cold)
-#define SPMV_ACC_LAUNCH_RB(NC, NV)                                                                                  \
-  do {                                                                                                             \
-    if (D && D->lens) {                                                                                            \
-      if (A.cold) SPMV_ACC_LAUNCH_RB_H(NC, NV, true, true);                                                        \
-      else SPMV_ACC_LAUNCH_RB_H(NC, NV, true, false);                                                              \
-    } else {                                                                                                       \
-      if (A.cold) SPMV_ACC_LAUNCH_RB_H(NC, NV, false, true);                                                       \
-      else SPMV_ACC_LAUNCH_RB_H(NC, NV, false, false);                                                             \
-    }                                                                                                              \
-  } while (0)
-  // one set of kernels for every base-pointer alignment: their 16-B loads go through under-aligned vector types
-  // (device_utils.hpp), the same instruction with the same cache policy whether or not the caller's arrays are 16-B aligned
+  // 3 colindex nt + values plain).  One set of kernels for every base-pointer alignment: their 16-B loads go through under-aligned
+  // vector types (device_utils.hpp), the same instruction with the same cache policy whether or not the caller's arrays are 16-B aligned
   switch ((xcd >> 4) & 3) {
-  case 1: SPMV_ACC_LAUNCH_RB(false, false); break;
-  case 2: SPMV_ACC_LAUNCH_RB(false, true); break;
-  case 3: SPMV_ACC_LAUNCH_RB(true, false); break;
-  default: SPMV_ACC_LAUNCH_RB(true, true); break;
+  case 1: launch_policy<VEC, false, false>(stream, A, D, C, nblocks, rpb, remap, alpha, beta, x, y, cache_ends); break;
+  case 2: launch_policy<VEC, false, true>(stream, A, D, C, nblocks, rpb, remap, alpha, beta, x, y, cache_ends); break;
+  case 3: launch_policy<VEC, true, false>(stream, A, D, C, nblocks, rpb, remap, alpha, beta, x, y, cache_ends); break;
+  default: launch_policy<VEC, true, true>(stream, A, D, C, nblocks, rpb, remap, alpha, beta, x, y, cache_ends); break;
   }
-#undef SPMV_ACC_LAUNCH_RB
-#undef SPMV_ACC_LAUNCH_RB_H
 }
 
 } // namespace
@@ -257,15 +276,16 @@ void launch_row_digest(hipStream_t stream, const int *rp, int m, int rows_per_bl
 }
 
 void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, int rows_per_block, int xcd_remap,
-                            double alpha, double beta, const double *x, double *y, const RowDigest *digest, int cache_ends) {
+                            double alpha, double beta, const double *x, double *y, const RowDigest *digest, int cache_ends,
+                            const Col16 *col16) {
   switch (vec) {
-  case 1: launch_vec<1>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
-  case 2: launch_vec<2>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
-  case 4: launch_vec<4>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
-  case 8: launch_vec<8>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
-  case 16: launch_vec<16>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
-  case 32: launch_vec<32>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
-  default: launch_vec<64>(stream, A, digest, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  case 1: launch_vec<1>(stream, A, digest, col16, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  case 2: launch_vec<2>(stream, A, digest, col16, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  case 4: launch_vec<4>(stream, A, digest, col16, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  case 8: launch_vec<8>(stream, A, digest, col16, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  case 16: launch_vec<16>(stream, A, digest, col16, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  case 32: launch_vec<32>(stream, A, digest, col16, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
+  default: launch_vec<64>(stream, A, digest, col16, rows_per_block, xcd_remap, alpha, beta, x, y, cache_ends); break;
   }
 }
 

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))
   __shared__ TileSpans spans;
   if (threadIdx.x == 0) spans.n = 0; // published by the barrier that follows the first staging
   const int nblocks = gridDim.x;
-  int blk = reverse ? zigzag_block(blockIdx.x, nblocks) : static_cast<int>(blockIdx.x); // zigzag (dispatch.cpp)
+  int blk = (reverse & 1) ? zigzag_block(blockIdx.x, nblocks) : static_cast<int>(blockIdx.x); // zigzag (dispatch.cpp)
   if (xcd_chunk > 0) blk = xcd_chunked_block(blk, nblocks, xcd_chunk);
   const bool second = blk >= nb0; // block-uniform: which matrix half (one width when row_split == m)
   const int w = second ? w1 : w0;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))
 #pragma unroll
   for (int k = 0; k < kVecTileRows; ++k) acc[k] = 0.0;
   for (int off = s0 & ~3; off < s1; off += kTile) {
-    stage_products<kThreads, kNnzPerThread, NTC, NTV>(lds, off, s1, nnz, ci, v, x);
+    stage_products<kThreads, kNnzPerThread, NTC, NTV>(lds, off, s1, nnz, ci, v, x, true, nullptr, (reverse & 2) != 0);
     __syncthreads();
     int lo[kVecTileRows], hi[kVecTileRows];
 #pragma unroll
@@ -353,7 +353,7 @@ void launch_vector_tile(hipStream_t stream, const CsrDev &A, int row_split, int 
   if (nb0 + nb1 == 0) return;
 #define SPMV_ACC_LAUNCH_VT(NC, NV)                                                                                    \
   SPMV_ACC_LAUNCH((vector_tile_kernel<NC, NV>), dim3(nb0 + nb1), dim3(kThreads), 0, stream, A.m, A.nnz, row_split, nb0, \
-                     w0, w1, rpb0, rpb1, xcd_chunk, alpha, beta, A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, A.guard, A.stale, reverse ? 1 : 0)
+                     w0, w1, rpb0, rpb1, xcd_chunk, alpha, beta, A.rp, A.ci, A.v, x, y, A.yin ? A.yin : y, A.guard, A.stale, (reverse ? 1 : 0) | (x32_ok(A) ? 2 : 0))
   switch (stream_policy & 3) {
   case 1: SPMV_ACC_LAUNCH_VT(false, false); break;
   case 2: SPMV_ACC_LAUNCH_VT(false, true); break;

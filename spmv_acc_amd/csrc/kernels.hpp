@@ -47,6 +47,9 @@ struct CsrDev {
   // Set per call by the engine, under the plan's lock; every launcher passes `yin ? yin : y` to its kernels.
   const double *yin = nullptr;
 };
+// 32-bit gather offsets (device_utils.hpp gather_u32): legal while every column's byte offset 8 * col fits 32 bits; a view whose column count
+// is unknown (n <= 0) keeps the 64-bit form
+inline bool x32_ok(const CsrDev &A) { return A.n > 0 && A.n <= (1 << 29); }
 constexpr int kGuardSamples = 64; // rowptr[k * m / 63], k = 0 .. 63 (includes rowptr[0] and rowptr[m] = nnz)
 void launch_guard_fill(hipStream_t stream, const int *rp, int m, int *d_guard);
 void launch_guard_check(hipStream_t stream, const CsrDev &A); // the check alone, for paths whose SpMV kernels run on derived matrices
@@ -133,9 +136,10 @@ struct RowDigest {
   unsigned char *lens = nullptr;        // m bytes: min(row length, 255)
   int *base = nullptr;                  // nblocks + 1 ints: rowptr[b * rpb]; bit 31 = a row of the block is longer than 255
 };
+struct Col16; // (below) the plan's 16-bit column encoding: non-null + built = the kernel streams it instead of colindex
 void launch_rowblock_stream(hipStream_t stream, const CsrDev &A, int vec, int rows_per_block, int flags,
                             double alpha, double beta, const double *x, double *y, const RowDigest *digest = nullptr,
-                            int cache_ends = 0);
+                            int cache_ends = 0, const Col16 *col16 = nullptr);
 void launch_row_digest(hipStream_t stream, const int *rp, int m, int rows_per_block, unsigned char *lens, int *base);
 void pick_rowblock_shape(int m, int nnz, int target_products, int *vec, int *rows_per_block);
 
@@ -149,16 +153,41 @@ constexpr int kRowblockMaxRounds = 8;
 // (hip-flat/flat_imp.inl:108-131) computed by one binary search per entry; no memset needed.
 void launch_break_points(hipStream_t stream, const int *rp, int m, int nnz, int stride, int *bp, int bp_len);
 
-// ---- opt-in 16-bit column encoding (k_col16.hip; flat family only) ---------------------------------------------------------
-constexpr int kCol16Chunk = 256; // non-zeros per base column: one wavefront's step of the tile kernels (64 lanes x 4)
+// ---- 16-bit column encoding (k_col16.hip builds it, tile_stage.hpp stage_products_c16 reads it) -----------------------------------
+constexpr int kCol16Chunk = 256; // non-zeros per base column: one wavefront's step of the tile kernels (64 lanes x 4), aligned in the absolute non-zero index
 struct Col16 {
+  int state = -1;                // -1 not looked at, 0 not worth it on this matrix (too many escapes, x of 4 GB or more), 1 built
+  int chunk0 = 0;                // the view's first chunk: A.nnz0 rounded down to a flat tile (2048), in chunks (0 unless the matrix is an un-rebased row sub-range); tables are indexed by chunk - chunk0
   int nchunks = 0;
-  unsigned short *d16 = nullptr; // nchunks * 256 offsets from base[chunk]; 0xFFFF = escape
-  int *base = nullptr;           // nchunks
-  int *esc_start = nullptr;      // nchunks + 1: first escape of the chunk in esc_cols
-  int *esc_cols = nullptr;       // the escaped columns in non-zero order
-  int escapes = 0;
+  int rec_ints = 0;              // R: ints per chunk record (16, 32 or 64): {base, escapes, overflow start, 0, first R - 4 escaped columns}
+  unsigned short *d16 = nullptr; // nchunks * 256 offsets from the chunk's base; 0xFFFF = escape
+  int *rec = nullptr;            // nchunks * R
+  int *ovf = nullptr;            // escapes beyond R - 4 per chunk, chunk by chunk (+ 64 entries of padding)
+  int *ci_guard = nullptr;       // 64 samples of colindex taken at build time (stale-plan guard of the kernels that no longer read colindex)
+  long long escapes = 0;         // all escapes of the view
+  long long overflow = 0;        // of them in the overflow list
+  size_t bytes = 0;              // what the encoding holds on the device
 };
+// what a kernel gets (by value): the tables pre-offset so that the kernel indexes them by ABSOLUTE chunk / non-zero index
+struct Col16Dev {
+  const unsigned short *d16;
+  const int *rec;
+  const int *ovf;
+  const int *ci_guard;
+  int rec_ints;
+  int guard_lo, guard_span; // colindex[guard_lo + k * guard_span / 63] == ci_guard[k], k = 0 .. 63
+};
+inline Col16Dev col16_dev(const Col16 &C, const CsrDev &A) {
+  Col16Dev d;
+  d.d16 = C.d16 - static_cast<long long>(C.chunk0) * kCol16Chunk;
+  d.rec = C.rec - static_cast<long long>(C.chunk0) * C.rec_ints;
+  d.ovf = C.ovf;
+  d.ci_guard = C.ci_guard;
+  d.rec_ints = C.rec_ints;
+  d.guard_lo = A.nnz0;
+  d.guard_span = A.count() > 0 ? A.count() - 1 : 0;
+  return d;
+}
 // gather hints (k_hint.hip)
 constexpr int kHintLineShift = 4;       // an x line = 16 columns = 128 B (the L2 line)
 constexpr int kHintBins = 4096;         // census histogram: lines / sampled hits per count value, last bin open-ended
@@ -168,10 +197,12 @@ void launch_hint_hist(hipStream_t stream, const unsigned *counts, int nlines, un
 void launch_hint_bits(hipStream_t stream, const int *ci, int nnz, int ncols, const unsigned *counts, unsigned threshold, unsigned char *bits);
 
 size_t col16_scan_bytes(int nchunks);
-void launch_col16_base(hipStream_t stream, const int *ci, int nnz, int nchunks, int *base, int *esc_count);
+void launch_col16_base(hipStream_t stream, const int *ci, int nnz, int chunk0, int nchunks, int *base, int *esc_count, unsigned long long *stats);
+void launch_col16_overflow(hipStream_t stream, int *cnt, int nchunks, int E);
 bool launch_col16_scan(hipStream_t stream, int nchunks, const int *esc_count, int *esc_start, void *tmp, size_t tmp_bytes);
-void launch_col16_encode(hipStream_t stream, const int *ci, int nnz, int nchunks, const int *base, const int *esc_start,
-                         unsigned short *d16, int *esc_cols);
+void launch_col16_encode(hipStream_t stream, const int *ci, int nnz, int chunk0, int nchunks, const int *base, const int *ovf_start, int R,
+                         unsigned short *d16, int *rec, int *ovf);
+void launch_col16_guard(hipStream_t stream, const int *ci, int lo, int span, int *out);
 
 // flat family: one workgroup per `stride` non-zeros (stride = kThreads * {4, 8, 16}); complete rows are
 // stored directly, the two possible partial rows per tile go to head/tail carries that a small second
@@ -198,7 +229,7 @@ struct FlatPlan {
   bool reverse = false;     // this launch walks the tiles in reverse order (zigzag, set per launch by the engine)
   int cache_ends = 0;       // tiles at each end of the grid that stay cacheable under the non-temporal policy (set per launch)
   bool segment_sum = false; // rows reduced by the segmented scan over the tile (reference option FLAT_SEGMENT_SUM_REDUCE), 2048-tile only
-  const Col16 *col16 = nullptr; // opt-in: columns from the plan's 16-bit encoding instead of colindex (NPT 8 tiles only)
+  const Col16 *col16 = nullptr; // columns from the plan's 16-bit encoding instead of colindex (NPT 8 tiles only; set per launch by the engine)
   bool mode_tuned[2] = {false, false};  // per beta class ([0]: beta == 0): tuned_fixup holds the timed choice
   bool tuned_fixup[2] = {true, true};
 };

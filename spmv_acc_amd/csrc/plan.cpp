@@ -113,7 +113,7 @@ void tune_load_locked() {
       char tag[32];
       unsigned long long key = 0;
       int used = 0;
-      if (std::sscanf(line, "%31s %llx%n", tag, &key, &used) != 2 || std::strcmp(tag, "spmvacc3") != 0) continue;
+      if (std::sscanf(line, "%31s %llx%n", tag, &key, &used) != 2 || std::strcmp(tag, "spmvacc4") != 0) continue;
       TuneRecord r;
       bool ok = true;
       const char *at = line + used;
@@ -142,7 +142,7 @@ unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *sample
     const unsigned char *c = static_cast<const unsigned char *>(p);
     for (size_t i = 0; i < bytes; ++i) h = (h ^ c[i]) * 1099511628211ULL;
   };
-  static const char kVersion[] = "spmv_acc_amd 0.5 tune v5";
+  static const char kVersion[] = "spmv_acc_amd 0.6 tune v6";
   mix(kVersion, sizeof(kVersion));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
@@ -187,6 +187,8 @@ TuneRecord tune_snapshot(const Plan &p) {
   for (int f = 0; f < 3; ++f) r.v[k++] = p.hint_use[f];
   r.v[k++] = p.flat_rowblock_choice;
   r.v[k++] = p.seg_choice;
+  r.v[k++] = p.c16_use[kFamRowblock];
+  r.v[k++] = p.c16_use[kFamFlat];
   return r;
 }
 } // namespace detail
@@ -230,6 +232,10 @@ void tune_adopt(Plan &p) {
   p.flat_rowblock_choice = in(r.v[k], 0, 1) ? r.v[k] : -1;
   ++k;
   p.seg_choice = in(r.v[k], 0, 1) ? r.v[k] : -1;
+  ++k;
+  p.c16_use[kFamRowblock] = in(r.v[k], 0, 1) ? r.v[k] : -1;
+  ++k;
+  p.c16_use[kFamFlat] = in(r.v[k], 0, 1) ? r.v[k] : -1;
   tune_log("m %d nnz %d: choices adopted from the tune cache (key %016llx)", p.A.m, p.A.nnz, p.tune_key);
 }
 // after a call that did plan work: keep what the plan now knows
@@ -242,7 +248,7 @@ void tune_store(const Plan &p) {
   if (it != g_tune_db.end() && it->second == r) return;
   g_tune_db[p.tune_key] = r;
   if (FILE *f = std::fopen(g_tune_path.c_str(), "a")) { // one line, one write: concurrent processes interleave whole lines
-    std::string line = "spmvacc3 ";
+    std::string line = "spmvacc4 ";
     char buf[32];
     std::snprintf(buf, sizeof(buf), "%016llx", p.tune_key);
     line += buf;
@@ -519,6 +525,7 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->adaptive_family_beta0 = p.adaptive_family[0];
       out->settled = p.calls > 0 && !p.tuning_open ? 1 : 0;
       out->last_kernel = p.last_kernel;
+      out->col16 = p.last_c16;
       out->slab_passes = p.seg_state == 1 && (tun(kT_slab_segments) >= 1 || (tun(kT_slab_segments) < 0 && p.seg_choice == 1)) ? p.seg_slabs - (p.seg_rest_below > 0 ? 1 : 0) : 0; // (column slabs: the whole-row pass of the two-class form is not counted)
       return true;
     }

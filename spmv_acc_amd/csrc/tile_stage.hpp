@@ -10,6 +10,7 @@
 #pragma once
 
 #include "device_utils.hpp"
+#include "kernels.hpp"
 
 namespace spmv_acc {
 namespace dev {
@@ -29,7 +30,7 @@ template <int THREADS, int NPT, bool NTC = true, bool NTV = true, bool HINT = fa
 __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0, int hi, int nnz,
                                                const int *__restrict__ ci, const double *__restrict__ v,
                                                const double *__restrict__ x, bool allow_fast = true,
-                                               const unsigned char *__restrict__ cold = nullptr) {
+                                               const unsigned char *__restrict__ cold = nullptr, bool x32 = false) {
   static_assert(NPT % 4 == 0, "NPT must be a multiple of 4");
   constexpr int K = NPT / 4;
   // Branch-free form (wave-uniform test): a0 is a multiple of 4, so the last 4-group that starts below `hi` ends at
@@ -40,7 +41,7 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
   // so hipcc places exact s_waitcnt counts: all stream loads of the wave, then all its gathers in flight.  (With
   // per-lane branches it waited for half of the first step's gathers before issuing the second step's.)  Products of
   // re-loaded groups land in slots >= hi - a0 that no reader touches.
-  if (allow_fast && ((hi + 3) & ~3) <= nnz) {
+  if (allow_fast && x32 && ((hi + 3) & ~3) <= nnz) {
     int4v c[K];
     double2v va[K], vb[K];
     unsigned nib[K]; // HINT: the cold bits of this lane's four non-zeros
@@ -68,18 +69,11 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
           xg[k][1] = gather_hinted(xr, c[k].y, nib[k] & 2u);
           xg[k][2] = gather_hinted(xr, c[k].z, nib[k] & 4u);
           xg[k][3] = gather_hinted(xr, c[k].w, nib[k] & 8u);
-        } else {
-#ifdef SPMV_ACC_EXP_NO_GATHER // (dissection builds only: every gather an L1 hit, the dependency on the column load kept)
-          xg[k][0] = x[c[k].x & 1023];
-          xg[k][1] = x[c[k].y & 1023];
-          xg[k][2] = x[c[k].z & 1023];
-          xg[k][3] = x[c[k].w & 1023];
-#else
-          xg[k][0] = x[c[k].x];
-          xg[k][1] = x[c[k].y];
-          xg[k][2] = x[c[k].z];
-          xg[k][3] = x[c[k].w];
-#endif
+        } else { // one VGPR and one shift per gather address (the caller vouches for 8 * n < 2^32: x32)
+          xg[k][0] = gather_u32(x, c[k].x);
+          xg[k][1] = gather_u32(x, c[k].y);
+          xg[k][2] = gather_u32(x, c[k].z);
+          xg[k][3] = gather_u32(x, c[k].w);
         }
       }
     }
@@ -99,51 +93,28 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
     }
     return;
   }
-  {
-    int4v c[K];
-    double2v va[K], vb[K];
-    bool full[K];
+  // General form: the tile that holds the ragged end of the arrays (one in the grid), `stage_fast = 0` (tests), and x of 4 GB and more
+  // (64-bit gather addresses).  One step at a time (the loop is NOT unrolled), so that its two address registers per gather never set the
+  // kernel's register count: the branch-free form above decides that (55-59 VGPRs in the row-block kernel's instances, 8 waves per SIMD).
+#pragma nounroll
+  for (int k = 0; k < K; ++k) {
+    const int g = threadIdx.x + k * THREADS;
+    const int j = a0 + 4 * g;
+    if (j < hi && j + 4 <= nnz) {
+      const int4v c = load_stream_i4<NTC>(ci + j);
+      const double2v va = load_stream_d2<NTV>(v + j), vb = load_stream_d2<NTV>(v + j + 2);
+      double2v p0, p1;
+      p0.x = va.x * x[c.x];
+      p0.y = va.y * x[c.y];
+      p1.x = vb.x * x[c.z];
+      p1.y = vb.y * x[c.w];
+      double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
+      dst[0] = p0;
+      dst[1] = p1;
+    } else if (j < hi) { // ragged end of the arrays (at most one group in the whole grid)
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int j = a0 + 4 * (threadIdx.x + k * THREADS);
-      full[k] = (j < hi) && (j + 4 <= nnz);
-      if (full[k]) {
-        c[k] = load_stream_i4<NTC>(ci + j);
-        va[k] = load_stream_d2<NTV>(v + j);
-        vb[k] = load_stream_d2<NTV>(v + j + 2);
-      }
-    }
-    double xg[K][4];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (full[k]) {
-        xg[k][0] = x[c[k].x];
-        xg[k][1] = x[c[k].y];
-        xg[k][2] = x[c[k].z];
-        xg[k][3] = x[c[k].w];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int g = threadIdx.x + k * THREADS;
-      if (full[k]) {
-        double2v p0, p1;
-        p0.x = va[k].x * xg[k][0];
-        p0.y = va[k].y * xg[k][1];
-        p1.x = vb[k].x * xg[k][2];
-        p1.y = vb[k].y * xg[k][3];
-        double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
-        dst[0] = p0;
-        dst[1] = p1;
-      } else {
-        // ragged end of the arrays (at most one group in the whole grid)
-        const int j = a0 + 4 * g;
-        if (j < hi) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (j + e < nnz) lds[4 * g + e] = v[j + e] * x[ci[j + e]];
-          }
-        }
+      for (int e = 0; e < 4; ++e) {
+        if (j + e < nnz) lds[4 * g + e] = v[j + e] * x[ci[j + e]];
       }
     }
   }
@@ -210,73 +181,87 @@ __device__ __forceinline__ void stage_finish(double *__restrict__ lds, const Str
   }
 }
 
-// ---- staging from the 16-bit column encoding (k_col16.hip) ---------------------------------------------------------------------
-// Same step as the branch-free form of stage_products with the colindex stream replaced by the plan's encoding: one 8-B load
-// of four 16-bit offsets per lane per step (instead of 16 B) and the chunk's base from a wave-uniform load (a0 is a multiple of
-// 256, so a wavefront's step is exactly one chunk).  Escapes must not lengthen the load chain (a first form that fetched
-// esc_cols[rank] AFTER decoding ran 12 % SLOWER than the 4-byte columns: at 2 % far columns nearly every wavefront holds an
-// escape and paid a third dependent round trip): each wavefront PRELOADS its chunk's first 64 escapes together with the
-// stream (lane l takes esc_cols[esc_start + l]; the list is padded by 64 entries), and an escaped entry picks its column out
-// of the preloaded registers by rank -- ballots + popcounts for the rank, one ds_bpermute per element slot that holds an escape
-// anywhere in the wavefront.  Only a chunk with more than 64 escapes (random columns) reads esc_cols a second time.
-// Precondition (checked by the caller): every 4-group below `hi` lies inside the arrays (stage_fast_ok).
-typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
-typedef ushort4v ushort4v_a2 __attribute__((aligned(2)));
+// ---- staging from the 16-bit column encoding (k_col16.hip, kernels.hpp Col16) --------------------------------------------------------
+// The branch-free step of stage_products with the colindex stream (4 B per non-zero) replaced by the plan's encoding: per lane and step one
+// 8-B load of four 16-bit offsets, per wavefront and step ONE load of the chunk's record (R ints: base, escape count, overflow start, the
+// chunk's first R - 4 escaped columns).  The tile origin a0 is a multiple of 256, so a wavefront's step is exactly one chunk and the
+// record's address depends on nothing but the step: records, offsets and values are all requested before anything is waited for (records
+// first: they come back first and the gathers need only them and the offsets).  Decoding: base from lane 0 of the record (a scalar), column
+// = base + offset; in a chunk WITH escapes (wave-uniform test on the record's count) an escaped entry takes its column out of the record by
+// rank -- ballots + popcounts for the rank, one ds_bpermute per element slot that holds an escape anywhere in the wavefront; only a chunk
+// with more than R - 4 escapes reads the overflow list (a dependent load, <= 1 % of the chunks by the choice of R).
+// (Round 2's form -- base[] and esc_start[] arrays, one escape list -- needed two scalars back before it could ask for the escapes, and those
+// before the first gather: profiles/r06_col16_counters.md.)
+//   a0  : tile origin, multiple of 256;   lo4 : first group the workgroup needs (multiple of 4, a0 <= lo4);   hi : exclusive bound
+// Lanes whose group lies outside [lo4, hi) still load their own offsets (the ranks count every escape of the chunk) but re-read the values of
+// group lo4 and gather the chunk's base column (L1 hits, no extra lines); their products land in slots no reader touches.
+// Preconditions (checked by the caller): every 4-group below `hi` lies inside the arrays (stage_fast_ok) and 8 * n < 2^32 (x32_ok).
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+typedef uint2v uint2v_a2 __attribute__((aligned(2)));
 
-template <int THREADS, int NPT, bool NTV>
-__device__ __forceinline__ void stage_products_col16(double *__restrict__ lds, int a0, int hi, const unsigned short *__restrict__ d16,
-                                                     const int *__restrict__ base, const int *__restrict__ esc_start,
-                                                     const int *__restrict__ esc_cols, const double *__restrict__ v,
-                                                     const double *__restrict__ x) {
+template <int THREADS, int NPT, bool NTC, bool NTV>
+__device__ __forceinline__ void stage_products_c16(double *__restrict__ lds, int a0, int lo4, int hi, const Col16Dev &C,
+                                                   const double *__restrict__ v, const double *__restrict__ x) {
   constexpr int K = NPT / 4;
-  ushort4v d[K];
+  uint2v d[K];
   double2v va[K], vb[K];
-  int bs[K], es[K], pre[K];
+  int rv[K];
   bool has[K];
   const int lane = threadIdx.x & (kWave - 1);
+  const int R = C.rec_ints;
+  const int rl = lane < R ? lane : 0; // (lanes past the record re-read its first entry: no branch, no extra line)
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int wave_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + k * THREADS));
     has[k] = wave_j < hi;
+    if (has[k]) rv[k] = C.rec[static_cast<long long>(wave_j >> 8) * R + rl];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
     if (has[k]) {
       const int j = a0 + 4 * (threadIdx.x + k * THREADS);
-      const int chunk = wave_j >> 8;
-      bs[k] = base[chunk];
-      es[k] = esc_start[chunk];
-      d[k] = __builtin_nontemporal_load(reinterpret_cast<const ushort4v_a2 *>(d16 + j)); // (d16 is padded to whole chunks)
-      const int jv = (j < hi) ? j : a0; // lanes past hi re-read the tile's first group of values (as stage_products does)
+      const uint2v_a2 *p = reinterpret_cast<const uint2v_a2 *>(C.d16 + j); // (the offsets are padded to whole chunks)
+      d[k] = NTC ? __builtin_nontemporal_load(p) : *p;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (has[k]) {
+      const int j = a0 + 4 * (threadIdx.x + k * THREADS);
+      const int jv = (j >= lo4 && j < hi) ? j : lo4;
       va[k] = load_stream_d2<NTV>(v + jv);
       vb[k] = load_stream_d2<NTV>(v + jv + 2);
     }
   }
-#pragma unroll
-  for (int k = 0; k < K; ++k)
-    if (has[k]) pre[k] = esc_cols[es[k] + lane]; // speculative: the chunk's first 64 escapes, one coalesced 256-B load
   double xg[K][4];
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     if (has[k]) {
-      int c[4] = {bs[k] + d[k].x, bs[k] + d[k].y, bs[k] + d[k].z, bs[k] + d[k].w};
-      const bool e[4] = {d[k].x == 0xFFFF, d[k].y == 0xFFFF, d[k].z == 0xFFFF, d[k].w == 0xFFFF};
-      const unsigned long long b0 = __ballot(e[0]), b1 = __ballot(e[1]), b2 = __ballot(e[2]), b3 = __ballot(e[3]);
-      if (b0 | b1 | b2 | b3) { // wave-uniform
-        // rank of this lane's first escape in the chunk's list: escapes held by lower lanes (the list is in non-zero order)
-        int r = __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
-        const unsigned long long slot[4] = {b0, b1, b2, b3};
+      const int j = a0 + 4 * (threadIdx.x + k * THREADS);
+      const int bs = __builtin_amdgcn_readlane(rv[k], 0);
+      const int nesc = __builtin_amdgcn_readlane(rv[k], 1);
+      const int dq[4] = {static_cast<int>(d[k].x & 0xFFFFu), static_cast<int>(d[k].x >> 16), static_cast<int>(d[k].y & 0xFFFFu),
+                         static_cast<int>(d[k].y >> 16)};
+      int c[4] = {bs + dq[0], bs + dq[1], bs + dq[2], bs + dq[3]};
+      if (nesc > 0) { // wave-uniform
+        const bool e[4] = {dq[0] == 0xFFFF, dq[1] == 0xFFFF, dq[2] == 0xFFFF, dq[3] == 0xFFFF};
+        const unsigned long long slot[4] = {__ballot(e[0]), __ballot(e[1]), __ballot(e[2]), __ballot(e[3])};
+        // rank of this lane's first escape in the chunk: the escapes held by lower lanes (records list them in non-zero order)
+        int r = __popcll(slot[0] & lt) + __popcll(slot[1] & lt) + __popcll(slot[2] & lt) + __popcll(slot[3] & lt);
+        const int E = R - 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (slot[q]) { // wave-uniform: some lane's q-th entry is an escape
-            const int got = __shfl(pre[k], r & (kWave - 1), kWave);
-            if (e[q]) c[q] = r < kWave ? got : esc_cols[es[k] + r];
+            const int got = __shfl(rv[k], (4 + r) & (kWave - 1), kWave);
+            if (e[q]) c[q] = r < E ? got : C.ovf[__builtin_amdgcn_readlane(rv[k], 2) + r - E];
           }
           r += e[q] ? 1 : 0;
         }
       }
-      xg[k][0] = x[c[0]];
-      xg[k][1] = x[c[1]];
-      xg[k][2] = x[c[2]];
-      xg[k][3] = x[c[3]];
+      const bool mine = j >= lo4 && j < hi;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xg[k][q] = gather_u32(x, mine ? c[q] : bs);
     }
   }
 #pragma unroll
@@ -295,6 +280,16 @@ __device__ __forceinline__ void stage_products_col16(double *__restrict__ lds, i
   }
 }
 
+// Stale-plan guard of the kernels that read the encoding: they no longer read colindex, so an in-place edit of the column indices (same rowptr)
+// would go unnoticed; the first wavefront of block 0 compares 64 samples of colindex with the plan's copies and raises the plan's flag
+// (device_utils.hpp check_plan_guard does the same for rowptr).  64 4-byte loads per SpMV.
+__device__ __forceinline__ void check_ci_guard(const int *__restrict__ ci, const Col16Dev &C, int *__restrict__ stale) {
+  if (C.ci_guard != nullptr && stale != nullptr && blockIdx.x == 0 && threadIdx.x < kWave) {
+    const int idx = C.guard_lo + static_cast<int>(static_cast<long long>(threadIdx.x) * C.guard_span / (kWave - 1));
+    if (ci[idx] != C.ci_guard[threadIdx.x]) __hip_atomic_store(stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ---- per-row sums over a staged tile ---------------------------------------------------------------------------------------
 // Every lane group (w lanes, w wave-uniform or compile-time) sums its row's span [lo, hi) of the tile.  A span of more than
 // max(63, 16 w) products would keep w lanes busy for dozens of dependent LDS reads while the rest of the workgroup idles (a
@@ -308,14 +303,18 @@ __device__ __forceinline__ void stage_products_col16(double *__restrict__ lds, i
 // leader lane (lane == 0) when the span was posted, the lane's strided partial otherwise; the caller's later group_sum over
 // the w lanes is unaffected (non-leader lanes of a posted span contribute 0).  Costs one barrier when nothing is posted.
 constexpr int kTileSpans = 64; // the largest tile any caller stages is 4096 products (flat_npt 16)
-struct TileSpans {
+template <int N> struct TileSpansN {
   int n;
-  int lo[kTileSpans], hi[kTileSpans];
-  double sum[kTileSpans];
+  int lo[N], hi[N];
+  double sum[N];
 };
+typedef TileSpansN<kTileSpans> TileSpans;
+// (the row-block kernel's tile is 2048 products: 32 spans.  The 512 B matter: 16 KB of tile + this + the wave totals stay below 17 KB, nine
+// workgroups' worth of the CU's 160 KB where the 64-span form was 20 bytes above it)
+typedef TileSpansN<32> TileSpans2K;
 
-template <int THREADS>
-__device__ __forceinline__ double tile_row_sum(const double *__restrict__ lds, TileSpans &sh, int lo, int hi, int lane, int w) {
+template <int THREADS, class Spans>
+__device__ __forceinline__ double tile_row_sum(const double *__restrict__ lds, Spans &sh, int lo, int hi, int lane, int w) {
   const int span = hi - lo;
   const bool posted = w < kWave && span >= 64 && span > 16 * w;
   int slot = -1;
@@ -352,8 +351,8 @@ __device__ __forceinline__ double tile_row_sum(const double *__restrict__ lds, T
 
 // The same for lane groups that own R rows each (vector-row tile kernel): all R spans are summed or posted first, ONE barrier
 // counts the posting lanes, and only then -- every thread being on the slow path -- is the shared post counter read.
-template <int THREADS, int R>
-__device__ __forceinline__ void tile_rows_sum(const double *__restrict__ lds, TileSpans &sh, const int (&lo)[R], const int (&hi)[R],
+template <int THREADS, int R, class Spans>
+__device__ __forceinline__ void tile_rows_sum(const double *__restrict__ lds, Spans &sh, const int (&lo)[R], const int (&hi)[R],
                                               int lane, int w, double (&acc)[R]) {
   int slot[R];
   bool posted_any = false;

@@ -65,7 +65,7 @@ thread_local bool t_flat_segment_sum = false; // this thread is inside segment_s
 
 int flat_stride_for(const Plan &p) {
   if (flat_segment_sum()) return kThreads * kNnzPerThread; // the scan is written for the 2048-non-zero tile
-  if (tun(kT_col16) > 0) return kThreads * kNnzPerThread; // the 16-bit encoding is read by the 2048-non-zero tile
+  if (tun(kT_col16) > 0) return kThreads * kNnzPerThread; // the 16-bit encoding (forced) is read by the 2048-non-zero tile
   int npt = tun(kT_flat_npt);
   if (npt < 0) npt = p.flat_npt_choice > 0 ? p.flat_npt_choice : kNnzPerThread;
   return kThreads * ((npt == 4 || npt == 16) ? npt : kNnzPerThread);
@@ -296,49 +296,88 @@ void release_tune_scratch() {
 
 
 
-// Opt-in 16-bit column encoding of the whole matrix (k_col16.hip): base + escape count per 256-non-zero chunk, exclusive scan
-// of the counts, then the offsets and the escape list.  One synchronisation (the escape total sizes the last allocation).
+// The 16-bit column encoding of the view's non-zeros (k_col16.hip): base + escape count per 256-non-zero chunk (and the escape statistics
+// that choose the record size), exclusive scan of the overflow counts, then offsets, records and overflow list.  Two synchronisations
+// (the statistics choose R, the overflow total sizes the last allocation).  Leaves state 0 where the encoding cannot pay: x of 4 GB or
+// more (the kernels' 32-bit gather offsets), fewer than 64 chunks, or more than 1 % of the chunks overflowing even the 64-int record.
 bool ensure_col16(Plan &p, hipStream_t st) {
-  constexpr size_t kWarpPad = 64;
-  if (p.col16.d16) return true;
-  if (!plan_work_allowed("the 16-bit column encoding")) return false;
-  ++t_plan_work;
   Col16 &C = p.col16;
-  const int nchunks = (p.A.nnz + kCol16Chunk - 1) / kCol16Chunk;
-  int *esc_count = nullptr;
+  if (C.state >= 0) return true;
+  if (!plan_work_allowed("the 16-bit column encoding")) return false;
+  const CsrDev &A = p.A;
+  // (the first chunk: aligned down to a whole 2048-non-zero flat tile -- 8 chunks -- because a flat tile's origin is a multiple of 2048 and its first
+  // wavefronts stage from there; the row blocks' tile origins are multiples of 256 at or above nnz0's chunk)
+  const int chunk0 = A.nnz0 / (kThreads * kNnzPerThread) * (kThreads * kNnzPerThread / kCol16Chunk);
+  const int nchunks = (A.nnz + kCol16Chunk - 1) / kCol16Chunk - chunk0;
+  if (!x32_ok(A) || nchunks < 64) {
+    C.state = 0;
+    return true;
+  }
+  ++t_plan_work;
+  int *base = nullptr, *cnt = nullptr, *ovf_start = nullptr;
+  unsigned long long *stats = nullptr;
   void *tmp = nullptr;
   const size_t tmp_bytes = col16_scan_bytes(nchunks);
-  bool ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&C.d16), sizeof(unsigned short) * static_cast<size_t>(nchunks) * kCol16Chunk),
-                   "hipMalloc col16 offsets") &&
-            hip_ok(hipMalloc(reinterpret_cast<void **>(&C.base), sizeof(int) * static_cast<size_t>(nchunks)), "hipMalloc col16 bases") &&
-            hip_ok(hipMalloc(reinterpret_cast<void **>(&C.esc_start), sizeof(int) * (static_cast<size_t>(nchunks) + 1)),
-                   "hipMalloc col16 escape offsets") &&
-            hip_ok(hipMalloc(reinterpret_cast<void **>(&esc_count), sizeof(int) * (static_cast<size_t>(nchunks) + 1)),
-                   "hipMalloc col16 escape counts") &&
+  const size_t n1 = static_cast<size_t>(nchunks) + 1;
+  bool ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&base), sizeof(int) * n1), "hipMalloc col16 bases") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&cnt), sizeof(int) * n1), "hipMalloc col16 escape counts") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&ovf_start), sizeof(int) * n1), "hipMalloc col16 overflow offsets") &&
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&stats), sizeof(unsigned long long) * 4), "hipMalloc col16 statistics") &&
             hip_ok(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16), "hipMalloc col16 scan workspace") &&
-            hip_ok(hipMemsetAsync(esc_count + nchunks, 0, sizeof(int), st), "memset col16");
-  int total = 0;
+            hip_ok(hipMemsetAsync(cnt + nchunks, 0, sizeof(int), st), "memset col16") &&
+            hip_ok(hipMemsetAsync(stats, 0, sizeof(unsigned long long) * 4, st), "memset col16 statistics");
+  unsigned long long h_stats[4] = {0, 0, 0, 0};
+  int R = 0, total = 0;
   if (ok) {
-    launch_col16_base(st, p.A.ci, p.A.nnz, nchunks, C.base, esc_count);
-    ok = launch_col16_scan(st, nchunks, esc_count, C.esc_start, tmp, tmp_bytes) &&
-         hip_ok(hipMemcpyAsync(&total, C.esc_start + nchunks, sizeof(int), hipMemcpyDeviceToHost, st), "read col16 escape total") &&
-         hip_ok(hipStreamSynchronize(st), "sync col16") &&
-         // (+ 64: every wavefront preloads 64 entries from its chunk's first escape on, also at the very end of the list)
-         hip_ok(hipMalloc(reinterpret_cast<void **>(&C.esc_cols), sizeof(int) * (static_cast<size_t>(total) + kWarpPad)), "hipMalloc col16 escapes") &&
-         hip_ok(hipMemsetAsync(C.esc_cols, 0, sizeof(int) * (static_cast<size_t>(total) + kWarpPad), st), "memset col16 escapes");
+    launch_col16_base(st, A.ci, A.nnz, chunk0, nchunks, base, cnt, stats);
+    ok = hip_ok(hipMemcpyAsync(h_stats, stats, sizeof(h_stats), hipMemcpyDeviceToHost, st), "read col16 statistics") &&
+         hip_ok(hipStreamSynchronize(st), "sync col16 statistics");
   }
   if (ok) {
-    launch_col16_encode(st, p.A.ci, p.A.nnz, nchunks, C.base, C.esc_start, C.d16, C.esc_cols);
-    ok = hip_ok(hipStreamSynchronize(st), "sync col16 encode");
+    const unsigned long long limit = static_cast<unsigned long long>(nchunks) / 100; // chunks allowed to overflow their record
+    R = h_stats[1] <= limit ? 16 : (h_stats[2] <= limit ? 32 : (h_stats[3] <= limit ? 64 : 0));
+    const int forced = tun(kT_col16) > 1 ? tun(kT_col16) : 0; // (tests: col16 = 16 / 32 / 64 pins the record size, overflow or not)
+    if (forced == 16 || forced == 32 || forced == 64) R = forced;
+    tune_log("m %d nnz %d 16-bit columns: %llu escapes in %d chunks, %llu / %llu / %llu chunks above 12 / 28 / 60 -> %s", A.m, A.nnz, h_stats[0], nchunks,
+             h_stats[1], h_stats[2], h_stats[3], R ? (R == 16 ? "16-int records" : (R == 32 ? "32-int records" : "64-int records")) : "not encoded");
   }
-  if (esc_count) (void)hipFree(esc_count);
-  if (tmp) (void)hipFree(tmp);
+  if (ok && R > 0) {
+    launch_col16_overflow(st, cnt, nchunks, R - 4);
+    ok = launch_col16_scan(st, nchunks, cnt, ovf_start, tmp, tmp_bytes) &&
+         hip_ok(hipMemcpyAsync(&total, ovf_start + nchunks, sizeof(int), hipMemcpyDeviceToHost, st), "read col16 overflow total") &&
+         hip_ok(hipStreamSynchronize(st), "sync col16");
+    const size_t d16_bytes = sizeof(unsigned short) * static_cast<size_t>(nchunks) * kCol16Chunk;
+    const size_t rec_bytes = sizeof(int) * static_cast<size_t>(nchunks) * R;
+    const size_t ovf_bytes = sizeof(int) * (static_cast<size_t>(total) + 64);
+    ok = ok && hip_ok(hipMalloc(reinterpret_cast<void **>(&C.d16), d16_bytes), "hipMalloc col16 offsets") &&
+         hip_ok(hipMalloc(reinterpret_cast<void **>(&C.rec), rec_bytes), "hipMalloc col16 records") &&
+         hip_ok(hipMalloc(reinterpret_cast<void **>(&C.ovf), ovf_bytes), "hipMalloc col16 overflow list") &&
+         hip_ok(hipMalloc(reinterpret_cast<void **>(&C.ci_guard), sizeof(int) * kGuardSamples), "hipMalloc col16 guard") &&
+         hip_ok(hipMemsetAsync(C.rec, 0, rec_bytes, st), "memset col16 records") && hip_ok(hipMemsetAsync(C.ovf, 0, ovf_bytes, st), "memset col16 overflow");
+    if (ok) {
+      launch_col16_encode(st, A.ci, A.nnz, chunk0, nchunks, base, ovf_start, R, C.d16, C.rec, C.ovf);
+      launch_col16_guard(st, A.ci, A.nnz0, A.count() > 0 ? A.count() - 1 : 0, C.ci_guard);
+      ok = hip_ok(hipStreamSynchronize(st), "sync col16 encode");
+    }
+    C.bytes = d16_bytes + rec_bytes + ovf_bytes;
+  }
+  for (void *q : {static_cast<void *>(base), static_cast<void *>(cnt), static_cast<void *>(ovf_start), static_cast<void *>(stats), tmp})
+    if (q) (void)hipFree(q);
   if (!ok) {
     p.free_col16();
     return false;
   }
+  if (R == 0) {
+    p.free_col16();
+    C.state = 0;
+    return true;
+  }
+  C.state = 1;
+  C.chunk0 = chunk0;
   C.nchunks = nchunks;
-  C.escapes = total;
+  C.rec_ints = R;
+  C.escapes = static_cast<long long>(h_stats[0]);
+  C.overflow = total;
   return true;
 }
 

@@ -63,6 +63,14 @@ SIZE_RULES = [
      ["test_plan_cache_is_lru_bounded"], "the least recently used plan is dropped beyond this many"),
     ("kMaxTimed / trial launches by launch duration", CSRC + "engine_internal.hpp", r"if \(first >= 4\.0f\) \{",
      ["test_first_call_is_bounded_and_later_calls_finish_the_timings"], "trial launches per timing: fewer for long kernels"),
+    ("32-bit gather offsets (x32_ok)", CSRC + "kernels.hpp", r"inline bool x32_ok\(const CsrDev &A\) \{ return A\.n > 0 && A\.n <= \(1 << 29\); \}",
+     ["test_x_beyond_the_hinted_gathers_reach"], "x of 4 GB and more: the general staging form (64-bit gather addresses), no 16-bit column encoding"),
+    ("col16: fewer than 64 chunks", CSRC + "tuner.cpp", r"if \(!x32_ok\(A\) \|\| nchunks < 64\)",
+     ["test_record_size_follows_the_escape_statistics", "test_row_shards_without_rebasing"], "no encoding below 64 chunks of 256 non-zeros"),
+    ("col16: record size by escapes per chunk", CSRC + "tuner.cpp", r"R = h_stats\[1\] <= limit \? 16 : \(h_stats\[2\] <= limit \? 32 : \(h_stats\[3\] <= limit \? 64 : 0\)\);",
+     ["test_record_size_follows_the_escape_statistics", "test_encoding_matches_colindex"], "16 / 32 / 64 ints per chunk record: the smallest that at most 1 % of the chunks overflow (12 / 28 / 60 escapes); none: not encoded"),
+    ("col16: first chunk of a view", CSRC + "tuner.cpp", r"const int chunk0 = A\.nnz0 / \(kThreads \* kNnzPerThread\) \* \(kThreads \* kNnzPerThread / kCol16Chunk\);",
+     ["test_row_shards_without_rebasing"], "the encoding of an un-rebased row sub-range starts at the flat tile that holds its first non-zero"),
     ("first non-zero of a view (A.nnz0)", CSRC + "tuner.cpp", r"const int tile0 = A\.nnz0 / stride;",
      ["test_chunk_views_are_sized_by_their_own_non_zeros", "test_row_shard_without_rebasing"], "flat: an un-rebased row sub-range starts at its own first tile"),
 ]
@@ -76,9 +84,9 @@ NOT_SIZE_RULES = {
     "kDigestMaxParts": "guard_full: workgroups of the digest pass (a grid-stride loop covers any m; test_guard_full_notices_an_edit_between_the_samples)",
     "kStreamPolicyNt": "enum", "kStreamPolicyDefault": "enum", "kStreamPolicyIndexDefault": "enum", "kStreamPolicyValueDefault": "enum",
     "kThreads": "workgroup size", "kNnzPerThread": "tile geometry", "kTile": "tile geometry", "kPlusThreads": "analysis geometry (reference instance)",
-    "kPlusR": "analysis geometry", "kPlusMinNnz": "analysis geometry (tunable plus_min_nnz, timed)", "kCol16Chunk": "opt-in encoding geometry",
+    "kPlusR": "analysis geometry", "kPlusMinNnz": "analysis geometry (tunable plus_min_nnz, timed)", "kCol16Chunk": "16-bit column encoding geometry",
     "kHintLineShift": "x line = 16 columns", "kPage": "host page size (pin table)", "kChunk": "staging bounce buffer / col16 chunk", "kNcclFloat64": "RCCL enum",
-    "kFlatReduceBuilt": "build option", "kWarpPad": "padding of the col16 escape list", "kLightRowsPerGroup": "LIGHT geometry", "kWaves": "waves per workgroup",
+    "kFlatReduceBuilt": "build option", "kLightRowsPerGroup": "LIGHT geometry", "kWaves": "waves per workgroup",
     "kPlusNpt": "tile geometry", "kPlusTile": "tile geometry", "kPlusMaxRows": "tile geometry", "kSegTile": "tile geometry",
     "kSegCost": "slab passes: cost units per workgroup (balance only)", "kSegMinCost": "slab passes: cost floor of a run (balance only)",
     "kSegEntries": "slab passes: runs per workgroup (tile capacity; test_slab_segments_match_the_oracle fills it)", "kVecTileRows": "vector tile geometry",

@@ -40,7 +40,10 @@ PY
   rm -rf $OUT/trace
   i=0
   # PMC_LEAN=1: the traffic counters only (request sizes, FETCH_SIZE, WRITE_SIZE) -- the per-stand-in table of moved bytes over all twelve
-  if [ "${PMC_LEAN:-0}" = "1" ]; then PASSES=("$GROUPS_TC4" "FETCH_SIZE" "WRITE_SIZE"); else
+  # PMC_LEAN=2: the wait split + the traffic counters (round 6: the 16-bit column kernel); PMC_LEAN=3: no counter pass (timing + kernel trace only)
+  if [ "${PMC_LEAN:-0}" = "1" ]; then PASSES=("$GROUPS_TC4" "FETCH_SIZE" "WRITE_SIZE");
+  elif [ "${PMC_LEAN:-0}" = "2" ]; then PASSES=("$GROUPS_SQ1" "$GROUPS_SQ2" "$GROUPS_TC4" "FETCH_SIZE" "WRITE_SIZE");
+  elif [ "${PMC_LEAN:-0}" = "3" ]; then PASSES=(); else
     PASSES=("$GROUPS_SQ1" "$GROUPS_SQ2" "$GROUPS_SQ3" "$GROUPS_SQ4" "$GROUPS_TC1" "$GROUPS_TC2" "$GROUPS_TC3" "$GROUPS_TC4" "$GROUPS_TC5" "FETCH_SIZE" "WRITE_SIZE"); fi
   for C in "${PASSES[@]}"; do
     i=$((i+1))
@@ -65,5 +68,5 @@ PY
     rm -rf $D
   done
   unset SPMV_ACC_TUNABLES
-  echo "== $W $S"; cat $OUT/kernel_stats_spmv.csv $OUT/counters.txt
+  echo "== $W $S"; cat $OUT/kernel_stats_spmv.csv; [ -f $OUT/counters.txt ] && cat $OUT/counters.txt; true
 done
