@@ -39,6 +39,73 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+# ---- the clocks, FROZEN as of round 5 (tests/test_bench_launch.py::test_roofline_frac_keeps_its_source pins this table and
+# roofline_block below: a figure may move only because a kernel's microseconds moved, never because a definition did) -----------------------------
+#   back_to_back      one hipEvent pair around the K launches of the timed region, y never reset, median of REGION_REPS regions / K
+#                     = `value`, `ms_per_step`, `roofline.achieved`, `roofline.frac` (since round 5; rounds 1-4 quoted per_launch on that key:
+#                     their lines' roofline.frac is this record's roofline.per_launch_protocol.frac)
+#   per_launch        the reference harness's protocol (benchmark/csr_spmv.hpp:66-74, benchmark/utils/benchmark_time.cpp:23-43): y restored by a
+#                     non-temporal device copy before EVERY launch, outside the event pair; one default hipEvent pair per launch; median
+#                     = every extra leg's `us` / `frac` and every `ge_0.70` count
+#   kernel_clock      the same launches' own start / stop timestamps (hipExtLaunchKernelGGL), summed per call, median
+#   cold              per_launch with 1 GiB of default-policy scratch traffic between the y reset and the start event (round 6): the launch starts with
+#                     nothing of the matrix in the L2s or the 256 MB Infinity Cache.  Context (`*_cold` keys), never a gate.
+ROOFLINE_DEFINITION = {
+    "version": "r05",
+    "frac": "back_to_back",
+    "achieved": "algorithmic bytes (12 nnz + 4 (m + 1) + 8 n + 16 m; 8 m for y at beta = 0) / back_to_back launch time",
+    "legs_and_gates": "per_launch",
+    "earlier_rounds": "rounds 1-4 quoted roofline.frac on per_launch: compare their lines with roofline.per_launch_protocol.frac (r04's 0.5461 -> this key)",
+}
+FLUSH_BYTES = 1 << 30
+
+
+def roofline_block(b_alg, b2b_ms, kernel_ms, ev_ms, cold=None):
+    """The roofline object of the line from the four clocks (milliseconds per launch).  `frac` / `achieved` come from b2b_ms and from nothing else."""
+    gbs = lambda ms: round(b_alg / (ms * 1e-3) / 1e9, 2)  # noqa: E731
+    fr = lambda ms: round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)  # noqa: E731
+    out = {"bound": "hbm", "achieved": gbs(b2b_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(b2b_ms) / HBM_PEAK_GBS, 4),
+           "definition": dict(ROOFLINE_DEFINITION),
+           "kernel_clock_reset_protocol": {"what": "the kernel's own start / stop events (hipExtLaunchKernelGGL), y reset by a device copy before each launch, median",
+                                           "launch_ms_median": round(kernel_ms, 6), "achieved": gbs(kernel_ms), "frac": fr(kernel_ms)},
+           "per_launch_protocol": {"what": "event pair around each call, y reset before it, median (benchmark/csr_spmv.hpp:66-74): kernel + the protocol's floor",
+                                   "launch_ms_median": round(ev_ms, 6), "achieved": gbs(ev_ms), "frac": fr(ev_ms)},
+           "algorithmic_bytes_per_launch": b_alg, "launch_ms_mean": round(b2b_ms, 6),
+           "back_to_back": {"launch_ms_mean": round(b2b_ms, 6), "achieved": gbs(b2b_ms), "frac": fr(b2b_ms)}}
+    if cold is not None:
+        out["cold_protocol"] = {"what": f"per-launch protocol with {FLUSH_BYTES >> 20} MiB of default-policy scratch traffic before every timed launch: nothing of the "
+                                        "matrix in the L2s or the Infinity Cache when it starts (context, never a gate)",
+                                "launch_ms_median": round(cold, 6), "achieved": gbs(cold), "frac": fr(cold)}
+        out["frac_cold"] = fr(cold)
+        out["cached_share_of_frac"] = round(1.0 - fr(cold) / fr(ev_ms), 4)  # how much of the per-launch figure the caches' carry-over is worth
+    return out
+
+
+_FLUSH = {}
+
+
+def flush_buffer(torch, device):
+    """1 GiB of device scratch for the cold protocol (once per process; None if it cannot be had)."""
+    key = str(device)
+    if key not in _FLUSH:
+        try:
+            _FLUSH[key] = torch.zeros(FLUSH_BYTES, dtype=torch.uint8, device=device)
+        except RuntimeError:
+            _FLUSH[key] = None
+    return _FLUSH[key]
+
+
+def cold_ms(torch, strat, A, x, y, y0, iters, alpha=1.0, beta=1.0):
+    """Median per-launch time under the cold protocol (spmv_acc_time_spmv_cold), or None without the scratch buffer."""
+    import spmv_acc_amd
+
+    m, n, nnz, rp, ci, v = A
+    flush = flush_buffer(torch, x.device)
+    if flush is None:
+        return None
+    per = spmv_acc_amd.time_spmv_cold(strat, iters, alpha, beta, m, n, nnz, rp, ci, v, x, y, y0, flush)
+    return float(np.median(per))
 REGION_REPS = 7        # `value` / `ms_per_step`: median over this many repetitions of the K-step region (benchmark_time.cpp:23-43: the reference reports a median)
 T_START = time.perf_counter()
 
@@ -301,6 +368,7 @@ def timed_leg(torch, strat, A, x, y0, iters, warm=10, beta=1.0, cols_touched=Non
     nf_ms = nofence_ms(strat, A, x, y, y0, 20, beta=beta)
     _, kn, kl = spmv_acc_amd.time_spmv_kernels(strat, max(20, iters // 3), 1.0, beta, m, n, nnz, rp, ci, v, x, y, y0=y0)
     kn_ms = float(np.median(kn))
+    c_ms = cold_ms(torch, strat, A, x, y, y0, max(8, min(20, iters // 3)), beta=beta)
     # (a row shard with global column ids reads only the columns its rows reference, not all n entries of x)
     b = synth.algorithmic_bytes(m, n if cols_touched is None else cols_touched, nnz, beta_nonzero=beta != 0.0)
     info = spmv_acc_amd.query_plan(rp, m) or {}
@@ -310,6 +378,9 @@ def timed_leg(torch, strat, A, x, y0, iters, warm=10, beta=1.0, cols_touched=Non
             "us_back_to_back": round(b2b_ms * 1e3, 2), "frac_back_to_back": frac(b2b_ms),
             "us_events_without_system_fence": round(nf_ms * 1e3, 2), "frac_events_without_system_fence": frac(nf_ms),
             "us_kernel_clock": round(kn_ms * 1e3, 2), "frac_kernel_clock": frac(kn_ms), "launches_per_spmv": int(np.median(kl)),
+            "us_cold": None if c_ms is None else round(c_ms * 1e3, 2), "frac_cold": None if c_ms is None else frac(c_ms),
+            "cached_share_of_frac": None if c_ms is None else round(1.0 - reset_ms / c_ms, 4),
+            "col16": info.get("col16", -1),  # ints per chunk record if the kernel reads the plan's 16-bit column encoding, 0 = the caller's colindex
             "gflops": round(2.0 * nnz / (reset_ms * 1e-3) / 1e9, 1),
             "plan": [info.get(k, -1) for k in ("stream_policy", "adaptive_family", "flat_fixup")], "kernel": info.get("last_kernel"),
             "settled": bool(info.get("settled"))}
@@ -347,14 +418,14 @@ def leg_sweep(torch, device, name, A=None, light=False):
         row["flat_tile_kernel"] = timed_leg(torch, "flat", A, x, y0, iters)
     finally:
         lib.spmv_acc_set_tunable(b"flat_rowblock", -1)
-    # opt-in leg, never the headline: flat over the plan's 16-bit column encoding (tunable col16; the plan then holds a copy
-    # derived from colindex).  frac stays algorithmic bytes of the CSR format (12 B per non-zero) over time.
+    # the 16-bit column encoding is the library's timed choice since round 6 (tunable col16 = -1; `col16` in every leg says whether the kernel reads it):
+    # this leg pins the caller's colindex (col16 = 0), so that the record shows what the encoding is worth where a plan keeps it
     spmv_acc_amd.release_plans(A[3])
-    lib.spmv_acc_set_tunable(b"col16", 1)
+    lib.spmv_acc_set_tunable(b"col16", 0)
     try:
-        row["flat_col16_opt_in"] = timed_leg(torch, "flat", A, x, y0, iters)
+        row["adaptive_colindex_only"] = timed_leg(torch, "adaptive", A, x, y0, iters)
     finally:
-        lib.spmv_acc_set_tunable(b"col16", 0)
+        lib.spmv_acc_set_tunable(b"col16", -1)
     spmv_acc_amd.release_plans(A[3])
     return row
 
@@ -504,7 +575,8 @@ def extra_legs(torch, device, headline, in_process=False):
             sweep[name] = leg(f"sweep:{name}", lambda name=name: leg_sweep(torch, device, name))
         progress(f"sweep {name}: flat {sweep[name]['flat']['us']} us ({sweep[name]['flat']['frac']}; tile kernel alone {sweep[name]['flat_tile_kernel']['us']} us), "
                  f"adaptive {sweep[name]['adaptive']['us']} us ({sweep[name]['adaptive']['frac']}), "
-                 f"flat+col16 {sweep[name]['flat_col16_opt_in']['us']} us ({sweep[name]['flat_col16_opt_in']['frac']})")
+                 f"adaptive on colindex only {sweep[name]['adaptive_colindex_only']['us']} us ({sweep[name]['adaptive_colindex_only']['frac']}); "
+                 f"col16 flat / adaptive {sweep[name]['flat']['col16']} / {sweep[name]['adaptive']['col16']}; cold {sweep[name]['flat']['frac_cold']} / {sweep[name]['adaptive']['frac_cold']}")
     out["sweep"] = sweep
     # The same 12 stand-ins once more with every matrix measured IN THIS PROCESS, one after the other (what a solver holding several
     # matrices sees): the >= 0.70 count is quoted for both regimes, because placement moves the 65 M-non-zero stand-ins by 2-4 %.
@@ -522,8 +594,12 @@ def extra_legs(torch, device, headline, in_process=False):
             "ge_0.70_back_to_back": sum(1 for r in sweep.values() if r[s]["frac_back_to_back"] >= 0.70),
             "ge_0.70_kernel_clock": sum(1 for r in sweep.values() if r[s]["frac_kernel_clock"] >= 0.70),
             "median_frac_kernel_clock": float(np.median([r[s]["frac_kernel_clock"] for r in sweep.values()])),
-            "median_frac_back_to_back": float(np.median([r[s]["frac_back_to_back"] for r in sweep.values()]))}
-        for s in ("flat", "adaptive", "flat_tile_kernel", "flat_col16_opt_in")}
+            "median_frac_back_to_back": float(np.median([r[s]["frac_back_to_back"] for r in sweep.values()])),
+            "ge_0.70_cold": sum(1 for r in sweep.values() if (r[s].get("frac_cold") or 0.0) >= 0.70),
+            "median_frac_cold": float(np.median([r[s].get("frac_cold") or 0.0 for r in sweep.values()])),
+            "median_cached_share_of_frac": float(np.median([r[s].get("cached_share_of_frac") or 0.0 for r in sweep.values()])),
+            "stand_ins_on_16_bit_columns": sum(1 for r in sweep.values() if (r[s].get("col16") or 0) > 0)}
+        for s in ("flat", "adaptive", "flat_tile_kernel", "adaptive_colindex_only")}
     for s in ("flat", "adaptive"):
         rows = (inproc or sweep).values()
         out["sweep_summary"][s]["ge_0.70_in_process"] = sum(1 for r in rows if r[s]["frac"] >= 0.70)
@@ -646,11 +722,7 @@ def copy_ceiling_gbs(torch, device):
     a = torch.empty(n, dtype=torch.float64, device=device).normal_()
     b = torch.empty_like(a)
     lib = spmv_acc_amd.load_library()
-    best = 0.0
-    for nt in (1, 0):  # non-temporal and default-policy copies: report the faster one
-        lib.spmv_acc_set_tunable(b"copy_nt", nt)
-        best = max(best, spmv_acc_amd.copy_ceiling_gbs(b, a, reps=5))
-    lib.spmv_acc_set_tunable(b"copy_nt", 1)
+    best = spmv_acc_amd.copy_ceiling_gbs(b, a, reps=5)  # (the entry times the non-temporal and the default-policy copy and returns the faster)
     return best
 
 
@@ -670,7 +742,8 @@ def compact_line(full):
                         "vs_baseline", "dtype", "data", "config", "region_reps", "ms_per_step_events"))
     r = full["roofline"]
     line["roofline"] = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_lower_bound",
-                                 "algorithmic_bytes_per_launch", "launch_ms_mean"))
+                                 "algorithmic_bytes_per_launch", "launch_ms_mean", "frac_cold", "cached_share_of_frac"))
+    line["roofline"]["definition"] = _pick(r.get("definition", {}), ("version", "frac", "legs_and_gates"))
     line["roofline"]["back_to_back"] = _pick(r.get("back_to_back", {}), ("frac",))
     line["roofline"]["per_launch_protocol"] = _pick(r.get("per_launch_protocol", {}), ("frac", "launch_ms_median"))
     line["roofline"]["kernel_clock_reset_protocol"] = _pick(r.get("kernel_clock_reset_protocol", {}), ("frac", "launch_ms_median"))
@@ -683,17 +756,17 @@ def compact_line(full):
     if "sweep" in full:  # configs[2]: name -> [flat frac, adaptive frac] under the per-launch protocol
         line["sweep"] = {k: [row["flat"]["frac"], row["adaptive"]["frac"]] for k, row in full["sweep"].items()}
         line["sweep_summary"] = {s: _pick(v, ("ge_0.70", "ge_0.70_in_process", "median_frac", "min_frac", "median_frac_in_process", "ge_0.70_kernel_clock",
-                                              "median_frac_kernel_clock"))
+                                              "median_frac_kernel_clock", "ge_0.70_cold", "median_frac_cold", "stand_ins_on_16_bit_columns"))
                                  for s, v in full["sweep_summary"].items() if s in ("flat", "adaptive")}
         # (`flat` as shipped runs the row-block kernel on balanced rows where the plan-time timing prefers it: flat's own tile kernel ALONE beside it)
         if "flat_tile_kernel" in full["sweep_summary"]:
             line["sweep_summary"]["flat"]["ge_0.70_tile_kernel_alone"] = full["sweep_summary"]["flat_tile_kernel"]["ge_0.70"]
     if "rmat25" in full:  # configs[3]
         le = full["rmat25"]["line_enhance"]
-        line["rmat25"] = {"us": le["us"], "frac": le["frac"], "nnz": full["rmat25"]["nnz"]}
+        line["rmat25"] = {"us": le["us"], "frac": le["frac"], "nnz": full["rmat25"]["nnz"], "frac_cold": le.get("frac_cold")}
     if "banded_shard" in full:  # configs[4], one shard
         ad = full["banded_shard"]["adaptive"]
-        line["banded_shard"] = {"us": ad["us"], "frac": ad["frac"]}
+        line["banded_shard"] = {"us": ad["us"], "frac": ad["frac"], "frac_cold": ad.get("frac_cold")}
     if "sensitivity" in full:
         line["no_far_columns_frac"] = full["sensitivity"]["frac"]
     # N > 1
@@ -943,7 +1016,8 @@ def main():
         out_extra["ms_per_step_wall_all"] = [round(w / args.steps * 1e3, 6) for w in walls]
         out_extra["ms_per_step_events_all"] = [round(e / args.steps, 6) for e in region_event_ms]
         # the reference harness's protocol (csr_spmv.hpp:66-74): y reset by a device copy before every launch, one event pair
-        # per launch, median -- what roofline.frac is quoted on
+        # per launch, median -- roofline.per_launch_protocol (rounds 1-4 quoted roofline.frac on it; since round 5 roofline.frac is the timed
+        # region's back-to-back figure: ROOFLINE_DEFINITION above, frozen)
         ms = spmv_acc_amd.time_spmv(strat, max(20, min(args.steps, 50)), alpha, beta, m, n, nnz, W["rp"], W["ci"], W["v"], x, y, y0=y0)
         ev_ms = float(np.median(ms))
         # the same protocol with the library's kernel clock on: each launch's own start / stop timestamps
@@ -957,6 +1031,9 @@ def main():
         out_extra["back_to_back_ms_mean"] = round(b2b_ms, 6)
         out_extra["per_launch_reset_ms_median_events_without_system_fence"] = round(
             nofence_ms(strat, (m, n, nnz, W["rp"], W["ci"], W["v"]), x, y, y0, 20, alpha, beta), 6)
+        _cold = cold_ms(torch, strat, (m, n, nnz, W["rp"], W["ci"], W["v"]), x, y, y0, 20, alpha, beta)
+        if _cold is not None:
+            out_extra["per_launch_cold_ms_median"] = round(_cold, 6)
     elif args.exchange == "ghost":
         # square workloads only: x partitioned like the rows, x <- alpha * A * x, each rank receiving just the entries its
         # columns reference (BASELINE configs[4]: 4 + 3 doubles per neighbour instead of an allgather of 256 MB slices)
@@ -1104,7 +1181,15 @@ def main():
     # pair around them, median repetition) -- the contract's definition, and the figure the rocprofv3 summary of the same command averages to
     # (the region's launches are most of the kernel's dispatches).  The reference harness's protocol stands beside it (per_launch_protocol,
     # kernel_clock_reset_protocol): under it the same kernel is 1-3 % slower (the y reset passes through the caches between two SpMVs).
-    achieved = b_alg / (b2b_ms * 1e-3) / 1e9
+    roofline = roofline_block(b_alg, b2b_ms, kernel_ms, ev_ms, out_extra.get("per_launch_cold_ms_median"))
+    roofline.update({
+        "unit_note": "algorithmic bytes / launch time; a working set of <= 256 MB is served by the Infinity Cache between "
+                     "launches, so small matrices can show more than the HBM rate -- it is a rate of useful bytes, not a PMC reading",
+        "protocol": "hipEvents around the timed region's K back-to-back launches on the library stream, per launch, median of the repetitions"
+                    if not dist_leg else "per-launch events around the local SpMV, y not reset",
+        "traffic": pmc_traffic(args.workload, strat) if args.scale == 1.0 else None,
+        "traffic_lower_bound": pmc_traffic(args.workload, strat, "lower_bound_bytes") if args.scale == 1.0 else None,
+        "traffic_source": "profiles/pmc_traffic.json (builder-run rocprofv3 --pmc passes, tools/profile_round.sh; not measured by this run)"})
     result = {
         "metric": "CSR SpMV GFLOP/s (fp64, int32 indices; achieved HBM GB/s in roofline)",
         "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1113,25 +1198,7 @@ def main():
         "config": {"workload": W["name"], "rows_per_gpu": m, "cols": n, "nnz_per_gpu": nnz, "strategy": strat,
                    "alpha": alpha, "beta": beta, "scale": args.scale,
                    "parallelism": "single GPU" if world == 1 else f"row-range shard x{world} + allgather(y) over {'RCCL' if backend == 'nccl' else backend}"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s",
-                     "unit_note": "algorithmic bytes / launch time; a working set of <= 256 MB is served by the Infinity Cache between "
-                                  "launches, so small matrices can show more than the HBM rate -- it is a rate of useful bytes, not a PMC reading",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "protocol": "hipEvents around the timed region's K back-to-back launches on the library stream, per launch, median of the repetitions"
-                                 if not dist_leg else "per-launch events around the local SpMV, y not reset",
-                     "kernel_clock_reset_protocol": {"what": "the kernel's own start / stop events (hipExtLaunchKernelGGL), y reset by a device copy before each launch, median",
-                                                     "launch_ms_median": round(kernel_ms, 6), "achieved": round(b_alg / (kernel_ms * 1e-3) / 1e9, 2),
-                                                     "frac": round(b_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                     "per_launch_protocol": {"what": "event pair around each call, y reset before it, median (benchmark/csr_spmv.hpp:66-74): kernel + the protocol's floor",
-                                             "launch_ms_median": round(ev_ms, 6), "achieved": round(b_alg / (ev_ms * 1e-3) / 1e9, 2),
-                                             "frac": round(b_alg / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                     "traffic": pmc_traffic(args.workload, strat) if args.scale == 1.0 else None,
-                     "traffic_lower_bound": pmc_traffic(args.workload, strat, "lower_bound_bytes") if args.scale == 1.0 else None,
-                     "traffic_source": "profiles/pmc_traffic.json (builder-run rocprofv3 --pmc passes, tools/profile_round.sh; not measured by this run)",
-                     "algorithmic_bytes_per_launch": b_alg, "launch_ms_mean": round(b2b_ms, 6),
-                     "back_to_back": {"launch_ms_mean": round(b2b_ms, 6), "achieved": round(b_alg / (b2b_ms * 1e-3) / 1e9, 2),
-                                      "frac": round(b_alg / (b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+        "roofline": roofline,
         "protocol": "value / ms_per_step / roofline: K back-to-back SpMVs on one matrix resident in HBM (a solver loop: y is iterated in place, never reset; "
                     "consecutive SpMVs on a plan walk the matrix in alternating directions -- library default, tunable zigzag), wall clock and event time of "
                     "the same region, median of the repetitions.  Every extra leg's us / frac and roofline.per_launch_protocol: the reference harness's "
@@ -1143,7 +1210,7 @@ def main():
     result.update(out_extra)
     info = spmv_acc_amd.query_plan(W["rp"], m) if args.exchange != "ghost" else None
     if info:  # what the first call measured and kept for this matrix (kernel family: 0 fixed row blocks, 1 row-block-plus, 2 flat)
-        result["plan"] = {k: info[k] for k in ("stream_policy", "adaptive_family", "flat_fixup", "plus_blocks", "flat_tiles", "slab_passes", "settled", "last_kernel")}
+        result["plan"] = {k: info[k] for k in ("stream_policy", "adaptive_family", "flat_fixup", "plus_blocks", "flat_tiles", "slab_passes", "settled", "last_kernel", "col16")}
     if rank == 0:
         result["copy_ceiling_gbs"] = round(copy_ceiling_gbs(torch, device), 1)
         # the same achieved rates against what THIS box copies at (boxes of this pool read 6.25 .. 6.66 TB/s; the large sweep stand-ins

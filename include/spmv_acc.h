@@ -356,6 +356,15 @@ int spmv_acc_time_spmv_events(int strategy, int iters, double alpha, double beta
                               const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
                               const double *dx, double *dy, const double *d_y0, float *ms_out, unsigned event_flags);
 
+/* The per-launch protocol with a COLD cache hierarchy (round 6; context for every fraction, never a gate): after y has been restored and before the
+ * start event, flush_bytes of scratch traffic under the default cache policy (the copy kernel: second half of d_flush overwritten with the first)
+ * displace what the previous launch left in the L2s and the 256 MB Infinity Cache.  The reference's protocol (benchmark/csr_spmv.hpp:49-74) repeats
+ * one SpMV on one matrix, so its launches start in whatever the previous one left; this entry says how much of a figure that is.  d_flush: device
+ * memory, 16-byte aligned, flush_bytes >= 2 x the Infinity Cache (the bench passes 1 GiB).  No reference counterpart. */
+int spmv_acc_time_spmv_cold(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,
+                            const int *h_rowptr, const int *d_rowptr, const int *d_colindex, const double *d_value,
+                            const double *dx, double *dy, const double *d_y0, void *d_flush, long long flush_bytes, float *ms_out);
+
 /* One event pair around all `iters` back-to-back launches (no per-launch markers): *total_ms_out / iters is
  * the average launch duration a solver loop sees. */
 int spmv_acc_time_spmv_total(int strategy, int iters, double alpha, double beta, int m, int n, int nnz,

@@ -36,7 +36,7 @@ C_ABI_SYMBOLS = (
     "spmv_acc_set_stream", "spmv_acc_get_stream", "spmv_acc_last_error", "spmv_acc_last_error_string",
     "spmv_acc_clear_error", "spmv_acc_time_spmv", "spmv_acc_version", "spmv_acc_set_tunable",
     "spmv_acc_get_tunable", "spmv_acc_reset_tunables", "spmv_acc_time_spmv_total", "spmv_acc_copy_ceiling_gbs", "spmv_acc_adaptive_plus_analyze_device", "spmv_acc_prepare",
-    "spmv_acc_last_prepare_us", "spmv_acc_sharded_spmv", "spmv_acc_shard_prepare", "spmv_acc_csr_spmv_chunks", "spmv_acc_query_plan_settled", "spmv_acc_query_plan_col16", "spmv_acc_csr_spmv_oop", "spmv_acc_check_plans",
+    "spmv_acc_last_prepare_us", "spmv_acc_sharded_spmv", "spmv_acc_shard_prepare", "spmv_acc_csr_spmv_chunks", "spmv_acc_query_plan_settled", "spmv_acc_query_plan_col16", "spmv_acc_time_spmv_cold", "spmv_acc_csr_spmv_oop", "spmv_acc_check_plans",
     "spmv_acc_query_plan_beta0", "spmv_acc_query_plan_slab_passes", "spmv_acc_shard_create", "spmv_acc_shard_step", "spmv_acc_shard_pipeline",
     "spmv_acc_shard_destroy", "spmv_acc_rccl_comm_init_all", "spmv_acc_rccl_comm_destroy", "spmv_acc_set_tune_cache",
     "spmv_acc_prepare_beta", "spmv_acc_time_spmv_events", "spmv_acc_refresh_values", "spmv_acc_time_spmv_region", "spmv_acc_query_plan_last_kernel", "spmv_acc_time_spmv_kernels",
@@ -101,6 +101,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.spmv_acc_clear_error.restype = None
     lib.spmv_acc_time_spmv.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.spmv_acc_time_spmv_events.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint]
+    lib.spmv_acc_time_spmv_cold.argtypes = [ci, ci, cd, cd, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, vp]
     lib.spmv_acc_version.restype = ctypes.c_char_p
     lib.spmv_acc_set_tunable.argtypes = [ctypes.c_char_p, ci]
     lib.spmv_acc_get_tunable.argtypes = [ctypes.c_char_p]
@@ -329,6 +330,22 @@ def time_spmv(strategy, iters: int, alpha: float, beta: float, m: int, n: int, n
     if rc != 0:
         msg = lib.spmv_acc_last_error_string().decode()
         raise SpmvAccError(f"time_spmv failed ({rc}): {msg}")
+    return list(out)
+
+
+def time_spmv_cold(strategy, iters: int, alpha: float, beta: float, m: int, n: int, nnz: int, rowptr, colindex, value, x, y, y0, flush,
+                   h_rowptr=None) -> Sequence[float]:
+    """The per-launch protocol with a cold cache hierarchy (spmv_acc_time_spmv_cold): before every timed launch, after y has been restored, the copy
+    kernel moves `flush` (a device tensor of >= 2 x the 256 MB Infinity Cache; its second half is overwritten with its first) under the default
+    cache policy.  Context for the fractions, never a gate."""
+    lib = load_library()
+    _csr_args(lib, m, n, nnz, rowptr, colindex, value, x, y, y0)
+    out = (ctypes.c_float * iters)()
+    rc = lib.spmv_acc_time_spmv_cold(strategy_id(strategy), iters, alpha, beta, m, n, nnz, _ptr(h_rowptr), _ptr(rowptr), _ptr(colindex),
+                                     _ptr(value), _ptr(x), _ptr(y), _ptr(y0), _ptr(flush), int(flush.numel() * flush.element_size()),
+                                     ctypes.cast(out, ctypes.c_void_p))
+    if rc != 0:
+        raise SpmvAccError(f"time_spmv_cold failed ({rc}): {lib.spmv_acc_last_error_string().decode()}")
     return list(out)
 
 

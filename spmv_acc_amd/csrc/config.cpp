@@ -90,25 +90,18 @@ constexpr int kFlatReduceBuilt = 1;
 constexpr int kFlatReduceBuilt = 0;
 #endif
 Tunable g_tunables[] = {
-    {"xcd_remap", 0, 0},       // row-block family: XCD-contiguous block order (A/B: -1% .. +4% time; off)
-    {"xcd_chunk", 16, 16},     // row-block family: each XCD takes this many consecutive blocks per super-chunk (0 = off)
-    {"xcd_chunk_tiles", 16, 16}, // same order for the flat / row-block-plus grids (A/B after the cache-policy autotune,
-                               // 9 stand-ins: 0 .. -4 % time on every one, none slower)
+    {"xcd_chunk", 16, 16},     // row blocks, flat tiles, row-block-plus blocks: each XCD takes this many consecutive blocks per super-chunk (0 = off; one knob
+                               // since round 6: `xcd_chunk_tiles` is gone)
     {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
     {"rowblock_target", 1500, 1500}, // products a row block should bring to its 2048-product tile.  Round 1 measured 1900 best (fullest tile); with
                                // round 2-3's kernels (zigzag, per-matrix cache policy) and the per-launch protocol 1500 is 1-2 % faster on ten of
                                // eleven sweep stand-ins and 2.8 % on the banded shard, +0.8 % on TSOPF (tools/param_sweep_reset.py, fresh plans on
                                // the same arrays, profiles/r03_rowblock_target.txt); 1600 / 1400 / 1300 / 1700 / 2040 are not better
     {"stream_plain", -1, -1},  // stream-load cache policy: -1 = timed once per matrix; 0 nt, 1 default, 2 index default, 3 value default
-    {"copy_nt", 1, 1},         // copy-ceiling probe: non-temporal loads/stores (0 = default cache policy)
-    {"stage_fast", 1, 1},      // tile staging: wave-skip + branch-free form (0: per-lane predicated loads)
-    {"early_y", 1, 1},         // row-block kernel: load the old y before the tile instead of after it
     {"rowblock_guard", 1, 1},  // imbalance probe + rescue for the row-block family
     {"adaptive_timed", 1, 1},  // adaptive: 1 = time row blocks / row-block-plus / flat on the matrix and keep the fastest;
                                // 0 = decide from the four rowptr samples and the balance probe only
     {"adaptive_split", 0, 0},  // adaptive, halves differing >= 4x: 1 = the reference's two-width vector-row split
-    {"rescue_flat", 0, 0},     // 1: the rescue is flat (nnz-cut tiles) instead of the row-block-plus kernel
-    {"plus_ref_vec", 0, 0},    // 1: row-block-plus analysis with the reference's VEC_SIZE pick (pow2 >= avg/2)
     {"plus_min_nnz", 0, 0},    // adaptive-plus analysis: MIN_NNZ_PER_BLOCK; 0 = time 1024 (the reference's instance) / 1536 /
                                // 1920 on the matrix and keep the fastest
     {"plus_host_analysis", 0, 0}, // 1: run the row-block analysis on the host (the reference's form)
@@ -152,8 +145,6 @@ Tunable g_tunables[] = {
                                // matrix' shape instead (strategy_picker.cpp:19-65: the reference's choice is a pure function of its
                                // inputs), so two processes run the same kernels in the same configuration and y is bitwise equal
                                // across processes and runs.  Costs the per-matrix optimum (a few per cent on most stand-ins)
-    {"tune_protocol", 1, 1},   // how the per-matrix timings are taken: 1 = the reference harness's protocol (y rewritten before each launch, one
-                               // event pair per launch, median), 0 = one event pair around back-to-back launches (rounds 1-2)
     {"col_slabs", 0, 0},       // OPT-IN column-slab blocking (k_slab.hip): S >= 2 = the plan holds a re-ordered COPY of colindex and values,
                                // A = sum of S column-range slabs, and an SpMV is S consecutive SpMVs of the named strategy, each gathering
                                // from 1/S of x (power-law columns: the L2s then hold a hot set S times deeper; R-MAT scale 25 7.2 -> 4.4 ms
@@ -166,10 +157,6 @@ Tunable g_tunables[] = {
                                // 7-11 % per launch on the small sweep stand-ins, 3-6 % on the large ones under the per-launch protocol); 0 = always
                                // the flat tile kernel; 1 = always the row blocks where balanced.  (Until late in round 3 only grids below 24 Mi
                                // non-zeros were timed.)  A caller that pins any of the tile kernel's own choices gets the tile kernel
-    {"legacy_kernels", 1, 1},  // KERNEL_STRATEGY LIGHT / BLOCK_ROW_ORDINARY / THREAD_ROW: 1 = what the names mean in the reference (k_legacy.hip: rows
-                               // handed out by an atomic counter; one workgroup per row; THREAD_ROW: one lane per row at every row length), 0 = the
-                               // round-1/2 stand-ins (the vector-row tile kernel; one wavefront per row; the row-block kernel's own lanes-per-row
-                               // pick), which are faster on most matrices (THREAD_ROW: by 0-4.5 %)
     {"guard_full", 0, 0},      // OPT-IN: 1 = every SpMV re-reads ALL of rowptr and compares a 64-bit digest with the plan's (k_guard.hip) -- an
                                // in-place edit of the structure is then always noticed, not only where it touches one of the 64 samples of the
                                // guard the kernels carry.  4 * (m + 1) bytes and two small launches more per call
@@ -181,9 +168,6 @@ Tunable g_tunables[] = {
                                // times nothing, the row-block-plus kernel stays); 0 = off; 1 = always, with the AUTOMATIC slab count (the x-size
                                // rule, tunable slab_kb: what tests use to reach the maximum count at test size); S >= 2 = always,
                                // whatever the strategy (rows that are not ordered: the ordinary path)
-    {"vector_target", 1900, 1900}, // vector-row tile kernel: products a workgroup's rows should bring to its 2048-product tile (the row-block family's
-                               // `rowblock_target` went to 1500 in round 3; this kernel, with two rows per lane group, keeps the fuller tile:
-                               // 1900 against 1500 is 3-5.5 % faster on four of five sweep stand-ins, equal on the fifth)
     {"first_call_budget", 20, 20}, // what the FIRST call on a matrix may spend on per-matrix timings, in SpMV-equivalents (wall time since the call began against
                                // N x the first trial launch it measured).  Once it is spent the call finishes by RULE -- every choice still open takes the
                                // `deterministic` rule for now and stays open -- and the following calls resume the timings, `later_call_budget`
@@ -214,9 +198,10 @@ static_assert(sizeof(g_tunables) / sizeof(g_tunables[0]) == kTunableCount, "Tuna
 inline bool tunable_order_ok() {
   return std::strcmp(g_tunables[kT_first_call_budget].name, "first_call_budget") == 0 && std::strcmp(g_tunables[kT_later_call_budget].name, "later_call_budget") == 0 &&
          std::strcmp(g_tunables[kT_slab_whole_below].name, "slab_whole_below") == 0 && std::strcmp(g_tunables[kT_strict_strategy].name, "strict_strategy") == 0 &&
-         std::strcmp(g_tunables[kT_flat_small_nnz_k].name, "flat_small_nnz_k") == 0 && std::strcmp(g_tunables[kT_max_grid_blocks].name, "max_grid_blocks") == 0 && std::strcmp(g_tunables[kT_vector_target].name, "vector_target") == 0 &&
+         std::strcmp(g_tunables[kT_flat_small_nnz_k].name, "flat_small_nnz_k") == 0 && std::strcmp(g_tunables[kT_max_grid_blocks].name, "max_grid_blocks") == 0 && std::strcmp(g_tunables[kT_hint_min_x_mb].name, "hint_min_x_mb") == 0 &&
          std::strcmp(g_tunables[kT_slab_segments].name, "slab_segments") == 0 && std::strcmp(g_tunables[kT_deterministic].name, "deterministic") == 0 &&
-         std::strcmp(g_tunables[kT_zigzag].name, "zigzag") == 0 && std::strcmp(g_tunables[kT_xcd_remap].name, "xcd_remap") == 0;
+         std::strcmp(g_tunables[kT_zigzag].name, "zigzag") == 0 && std::strcmp(g_tunables[kT_xcd_chunk].name, "xcd_chunk") == 0 &&
+         std::strcmp(g_tunables[kT_col16].name, "col16") == 0;
 }
 void apply_env_tunables();
 

@@ -121,18 +121,9 @@ __device__ __forceinline__ double gather_hinted(const XGather &g, int col, unsig
 }
 
 // ---- XCD-aware block remap ------------------------------------------------------------------------
-// Hardware deals block b to XCD (b mod 8).  Neighbouring row blocks share x[] lines, so give each
-// XCD one contiguous chunk of the logical block range (bijective for any nblocks).  Placement is a
-// speed matter only: any mapping is correct.
-__device__ __forceinline__ int xcd_contiguous_block(int b, int nblocks) {
-  const int q = nblocks / kXcds;
-  const int rem = nblocks % kXcds;
-  const int xcd = b % kXcds;
-  const int idx = b / kXcds;
-  return xcd * q + (xcd < rem ? xcd : rem) + idx;
-}
-
-// Chunked variant: the 8 XCDs walk the grid together in super-chunks of 8*C blocks, each XCD taking C consecutive
+// Hardware deals block b to XCD (b mod 8).  Neighbouring row blocks share x[] lines.  (Round 1's first remap gave each XCD one contiguous
+// eighth of the grid: -1 ... +4 % time, never the default, removed in round 6.)
+// Chunked order: the 8 XCDs walk the grid together in super-chunks of 8*C blocks, each XCD taking C consecutive
 // logical blocks of the super-chunk.  Neighbouring row blocks (shared x[] lines at their common edge) then hit the same
 // L2 inside a chunk, while all XCDs stay within the same few MB of the streamed arrays (DRAM pages stay hot, which
 // the fully contiguous split above gives up).  Bijective; the ragged tail of the grid keeps the identity order.

@@ -20,7 +20,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
   if (p.flat.max_tile_rows > kFlatMaxTileRows && tun(kT_rowblock_guard) && !strict) {
     // (guard against mutual recursion: the row-block rescue goes to row-block-plus unless rescue_flat is set, and a matrix with
     // such tiles has no row-block imbalance of the hub-row kind)
-    if (!(tun(kT_rescue_flat) && p.rowblock_ok == 0)) return run_rowblock(st, p, nullptr, alpha, beta, x, y, false, 0);
+    return run_rowblock(st, p, nullptr, alpha, beta, x, y, false, 0);
   }
   p.A.cold = nullptr; // (the plan-time timings below run without gather hints)
   p.flat.col16 = nullptr;
@@ -43,7 +43,7 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
   // (a caller that pins any of the tile kernel's own choices -- cut-row form, tile size, staging order -- is asking for that kernel)
   const bool tile_pinned = tun(kT_flat_finish) >= 0 || tun(kT_flat_npt) >= 0 || tun(kT_flat_early) >= 0;
   if (rb_mode != 0 && (rb_mode > 0 || !tile_pinned) && !flat_segment_sum() && tun(kT_col16) <= 0 &&
-      !tun(kT_rescue_flat) && !t_coarse_tuning && !strict) {
+      !t_coarse_tuning && !strict) {
     if (rb_mode > 0) {
       int vec = 1, rpb = kThreads;
       pick_rowblock_shape(p.A.m, p.A.count(), tun(kT_rowblock_target), &vec, &rpb);
@@ -220,11 +220,11 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
     // kernel over analysed row blocks, long rows cut into dedicated blocks) -- which measures 1 % (R-MAT scale 25),
     // 5 % (scale 22) and 17 % (scale 20) faster than the nnz-cut tiles of flat; `rescue_flat` keeps the older choice.
     if (p.rowblock_ok == 0)
-      return tun(kT_rescue_flat) ? run_flat(st, p, alpha, beta, x, y) : run_plus(st, p, h_rowptr, alpha, beta, x, y);
+      return run_plus(st, p, h_rowptr, alpha, beta, x, y);
     // Uneven but not pathological (striped densities: 60 / 20 nnz per row alternating every 300 or 5000 rows ran 196 us here and
     // 177 us in row-block-plus; 30 / 10 every 64 rows 108 vs 97 us): same answer, for the strategies that leave the choice to
     // the engine.  line / line-enhance / thread_row keep their fixed row blocks.
-    if (p.rowblock_uneven && allow_uneven_switch && !tun(kT_rescue_flat)) return run_plus(st, p, h_rowptr, alpha, beta, x, y);
+    if (p.rowblock_uneven && allow_uneven_switch) return run_plus(st, p, h_rowptr, alpha, beta, x, y);
   }
   const RowDigest *dg = nullptr;
   const int want_lens = tun(kT_rowlen);
@@ -246,8 +246,7 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
     cache_ends = static_cast<int>(tun(kT_cache_ends_mb) * 1048576.0 / bytes_per_block);
   }
   const int chunk = tun(kT_xcd_chunk);
-  const int base_flags = (tun(kT_xcd_remap) ? 1 : 0) | (tun(kT_early_y) ? 2 : 0) |
-                         (chunk > 0 ? (4 | (chunk << 8)) : 0) | (tun(kT_stage_fast) ? 0 : 8);
+  const int base_flags = chunk > 0 ? (4 | (chunk << 8)) : 0; // (bit 0 -- XCD-contiguous order --, bit 1 -- late y load -- and bit 3 -- per-lane predicated staging -- were A/B switches until round 5)
   p.A.cold = nullptr; // (the policy timing runs without gather hints)
   if (!autotune_policy(p, kFamRowblock, st, [&](int pol, double *ys) {
         const int zz = next_reverse(p) ? 64 : 0;
@@ -279,11 +278,11 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
 // so the candidates are timed once per matrix like the cache policy.
 bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double *x) {
   auto launch = [&](int pol, double *ys) {
-    launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk_tiles), pol,
+    launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk), pol,
                 p.d_ppartial, 1.0, trial_beta(), x, ys, next_reverse(p));
   };
   const int forced = tun(kT_plus_min_nnz);
-  if (forced > 0 || tun(kT_plus_ref_vec)) {
+  if (forced > 0) {
     return ensure_plus(p, h_rowptr, st, forced > 0 ? forced : kPlusMinNnz) && autotune_policy(p, kFamPlus, st, launch);
   }
   if (tun(kT_deterministic)) {
@@ -387,7 +386,7 @@ int seg_auto_slabs(int n) {
 bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y) {
   p.A.cold = nullptr; // (the prepare timings run without hints)
   auto launch_here = [&](double a, double b, double *yy) {
-    launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk_tiles), policy_for(p, kFamPlus),
+    launch_plus(st, p.A, p.d_pbp, p.d_pfbr, p.d_pblk, p.plus_blocks, p.plus_has_long, tun(kT_xcd_chunk), policy_for(p, kFamPlus),
                 p.d_ppartial, a, b, x, yy, next_reverse(p));
   };
   // Builds the run lists (once) and times the slab passes against this kernel as it stands; ms[0] row-block-plus, ms[1] the passes.
@@ -812,7 +811,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     (void)hipGetLastError();
     return cus * 8;
   };
-  if (strategy == kLight && tun(kT_legacy_kernels)) {
+  if (strategy == kLight) {
     // LightSpMV (hip-light/light_spmv.cpp:16-41): lanes per row from the average row length (its thresholds: vector_row.cpp's
     // table), rows handed out by the plan's counter
     if (!p->d_light_counter) {
@@ -826,7 +825,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     launch_light(st, p->A, classic_vec(avg), resident_blocks(), p->d_light_counter, alpha, beta, dx, dy);
     p->last_kernel = kKernelLight;
     strategy = -1; // handled
-  } else if (strategy == kBlockRowOrdinary && tun(kT_legacy_kernels)) {
+  } else if (strategy == kBlockRowOrdinary) {
     launch_block_row(st, p->A, resident_blocks(), alpha, beta, dx, dy); // hip-block-row-ordinary/spmv_hip_acc_imp.cpp:16-75
     p->last_kernel = kKernelBlockRow;
     strategy = -1;
@@ -834,15 +833,14 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   switch (strategy) {
   case -1:
     break;
-  case kLight:
-  case kVectorRow:
+  case kVectorRow: // (LIGHT and BLOCK_ROW_ORDINARY were served above: k_legacy.hip, what the names mean in the reference)
   {
     const int forced_w = tun(kT_vector_width);
     const bool tile_form = tun(kT_vector_tile) != 0;
     const int w = (forced_w >= 1 && forced_w <= 64 && (forced_w & (forced_w - 1)) == 0) ? forced_w
                   : tile_form ? tile_vec(avg) : classic_vec(avg);
     if (tun(kT_rowblock_guard) && !probe_rowblock(*p, kThreads / w, st)) return;
-    if (tile_form && p->rowblock_ok == 0 && !tun(kT_rescue_flat)) {
+    if (tile_form && p->rowblock_ok == 0) {
       // very uneven rows (hub rows of a power-law matrix): w lanes walking a row of 10^5 non-zeros serialise the kernel (5.8 ms
       // on a 60 000-row power-law matrix that the other families run in 30 us); same rescue as the row-block family
       run_plus(st, *p, h_rowptr, alpha, beta, dx, dy);
@@ -850,7 +848,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
       // the reference's lane width per row (vector_row.cpp:15-27) on the tile machinery
       const double a = static_cast<double>(p->A.count()) / m;
       auto launch = [&](int pol, double al, double be, double *yy) {
-        launch_vector_tile(st, p->A, m, w, w, a, a, tun(kT_vector_target), tun(kT_xcd_chunk), pol, al, be, dx, yy,
+        launch_vector_tile(st, p->A, m, w, w, a, a, kVectorTarget, tun(kT_xcd_chunk), pol, al, be, dx, yy,
                            next_reverse(*p));
       };
       if (!autotune_policy(*p, kFamVector, st, [&](int pol, double *ys) { launch(pol, 1.0, trial_beta(), ys); })) return;
@@ -863,7 +861,6 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     break;
   }
   case kWfRow:
-  case kBlockRowOrdinary:
     launch_wave_row(st, p->A, alpha, beta, dx, dy);
     p->last_kernel = kKernelWaveRow;
     break;
@@ -875,8 +872,8 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     // KERNEL_STRATEGY THREAD_ROW (hip-thread-row/thread_row.cpp:17-48, thread_row_block.hpp): ONE lane sums each row -- the reference's
     // block-level form: the workgroup's non-zeros staged through LDS by coalesced loads, then a thread per row.  Up to 5.8 non-zeros
     // per row that is the row-block kernel's own shape; beyond, where the reference falls back to a 128-block naive loop, the name
-    // keeps its meaning here (rows longer than a wavefront are handed to whole waves by tile_row_sum) unless legacy_kernels is 0
-    run_rowblock(st, *p, h_rowptr, alpha, beta, dx, dy, false, tun(kT_legacy_kernels) ? 1 : 0);
+    // keeps its meaning here (rows longer than a wavefront are handed to whole waves by tile_row_sum)
+    run_rowblock(st, *p, h_rowptr, alpha, beta, dx, dy, false, 1);
     break;
   case kLineEnhance:
   case kLine:
@@ -905,7 +902,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
         if (tun(kT_vector_tile)) {
           const double f0 = half_rows > 0 ? static_cast<double>(p->samples.half) / half_rows : 0.0;
           const double f1 = (static_cast<double>(p->samples.last) - p->samples.half) / (m - half_rows);
-          launch_vector_tile(st, p->A, half_rows, tile_vec(a0), tile_vec(a1), f0, f1, tun(kT_vector_target),
+          launch_vector_tile(st, p->A, half_rows, tile_vec(a0), tile_vec(a1), f0, f1, kVectorTarget,
                              tun(kT_xcd_chunk), policy_for(*p, kFamVector), alpha, beta, dx, dy);
         } else {
           launch_vector_row(st, p->A, half_rows, classic_vec(a0), classic_vec(a1), alpha, beta, dx, dy);

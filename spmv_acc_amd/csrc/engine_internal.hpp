@@ -46,9 +46,9 @@ struct Tunable {
 };
 // indices into g_tunables, in table order (the kernels' hot path reads tunables by index, not by name)
 enum TunableId {
-  kT_xcd_remap, kT_xcd_chunk, kT_xcd_chunk_tiles, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, kT_copy_nt,
-  kT_stage_fast, kT_early_y, kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, kT_rescue_flat, kT_plus_ref_vec,
-  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_tune_protocol, kT_col_slabs, kT_flat_rowblock, kT_legacy_kernels, kT_guard_full, kT_slab_segments, kT_vector_target, kT_first_call_budget, kT_later_call_budget, kT_slab_whole_below, kT_strict_strategy, kT_slab_kb, kT_hint_min_x_mb, kT_max_grid_blocks, kT_flat_small_nnz_k, kTunableCount
+  kT_xcd_chunk, kT_rowblock_vec, kT_rowblock_target, kT_stream_plain, 
+  kT_rowblock_guard, kT_adaptive_timed, kT_adaptive_split, 
+  kT_plus_min_nnz, kT_plus_host_analysis, kT_flat_finish, kT_flat_npt, kT_validate, kT_rowlen, kT_flat_early, kT_vector_tile, kT_col16, kT_vector_width, kT_zigzag, kT_cache_ends_mb, kT_flat_reduce, kT_gather_hint, kT_hint_budget_kb, kT_deterministic, kT_col_slabs, kT_flat_rowblock, kT_guard_full, kT_slab_segments, kT_first_call_budget, kT_later_call_budget, kT_slab_whole_below, kT_strict_strategy, kT_slab_kb, kT_hint_min_x_mb, kT_max_grid_blocks, kT_flat_small_nnz_k, kTunableCount
 };
 extern Tunable g_tunables[];
 void apply_env_tunables();
@@ -334,7 +334,7 @@ struct TuneTimer {
     for (auto &e : per)
       if (e) (void)hipEventDestroy(e);
   }
-  // The trial launches write a scratch y.  With a reset buffer set (and tunable tune_protocol 1, the default) the timed launches
+  // The trial launches write a scratch y.  With a reset buffer set the timed launches
   // follow the REFERENCE HARNESS'S protocol -- the one every figure of this repository is quoted on (benchmark/csr_spmv.hpp:66-74):
   // the scratch y is rewritten before each launch, each launch has its own event pair, the median counts -- instead of one event
   // pair around back-to-back launches.  Back-to-back timing favours whatever profits most from the previous launch's cache
@@ -363,7 +363,7 @@ struct TuneTimer {
       // a decision that is kept and persisted gets a second sample, the smaller counts)
       for (int extra = 1; extra < at_least; ++extra) {
         float again = 0.f;
-        if (reset_ptr && tun(kT_tune_protocol) == 1) (void)hipMemsetAsync(reset_ptr, 0, reset_bytes, st);
+        if (reset_ptr) (void)hipMemsetAsync(reset_ptr, 0, reset_bytes, st);
         (void)hipEventRecord(e0, st);
         fn();
         (void)hipEventRecord(e1, st);
@@ -381,7 +381,7 @@ struct TuneTimer {
     // medians of five, where candidates 1-2 % apart used to change places between processes on medians of three)
     const int timed = first < 0.1f ? 5 : (first < 0.5f ? (lean ? 2 : 5) : (first < 2.0f ? (lean ? 2 : 3) : 1));
     for (int w = 0; w < warm; ++w) fn();
-    if (reset_ptr && tun(kT_tune_protocol) == 1) {
+    if (reset_ptr) {
       for (int t = 0; t < timed; ++t) {
         (void)hipMemsetAsync(reset_ptr, 0, reset_bytes, st);
         (void)hipEventRecord(per[2 * t], st);

@@ -71,7 +71,6 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
 
   int b = blockIdx.x;
   if (flags & 64) b = zigzag_block(b, nblocks); // every other SpMV on a plan walks the matrix backwards (dispatch.cpp)
-  if (flags & 1) b = xcd_contiguous_block(b, nblocks);
   if (flags & 4) b = xcd_chunked_block(b, nblocks, flags >> 8);
   // (Tried in round 5 and removed: workgroups walking GROUPS of 2 ... 8 consecutive row blocks, so that the stores of block i travel while block
   // i + 1 streams and s_endpgm's wait for outstanding stores is paid once per group: 2-14 % SLOWER on every stand-in, small and large --
@@ -106,8 +105,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
   // the old y is needed only at the very end: ask for it now so its latency hides behind the whole tile
   const bool writer = live && lane == 0;
   double y_old = 0.0;
-  const bool early_y = (flags & 2) && beta != 0.0;
-  if (early_y && writer) y_old = yin[row]; // (non-temporal y loads / stores were A/B-tested in round 2: no effect on any stand-in)
+  if (beta != 0.0 && writer) y_old = yin[row]; // (asked for now, used at the very end; loading it late was an A/B switch until round 5: never faster)
 
   double acc = 0.0;
   int incl = 0;
@@ -131,9 +129,9 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
       if (cached_end) stage_products_c16<kThreads, kNnzPerThread, false, false>(lds, off, lo4 > off ? lo4 : off, s1, c16, v, x);
       else stage_products_c16<kThreads, kNnzPerThread, NTC, NTV>(lds, off, lo4 > off ? lo4 : off, s1, c16, v, x);
     } else if (cached_end)
-      stage_products<kThreads, kNnzPerThread, false, false, HINT>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0, cold, (flags & 128) != 0);
+      stage_products<kThreads, kNnzPerThread, false, false, HINT>(lds, off, s1, nnz, ci, v, x, true, cold, (flags & 128) != 0);
     else
-      stage_products<kThreads, kNnzPerThread, NTC, NTV, HINT>(lds, off, s1, nnz, ci, v, x, (flags & 8) == 0, cold, (flags & 128) != 0);
+      stage_products<kThreads, kNnzPerThread, NTC, NTV, HINT>(lds, off, s1, nnz, ci, v, x, true, cold, (flags & 128) != 0);
     __syncthreads();
     if (LENS && from_lens && off == off0) {
       const int w = threadIdx.x / kWave;
@@ -153,7 +151,7 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
     // non-temporal store (round 5): a write stream beside a read stream costs the memory system ~3 x its bytes (read_write_mix_bench.hip: 24 KB read +
     // 2 KB written per workgroup reads at 5.1-5.7 TB/s, 5.4-5.9 with non-temporal stores); in this kernel: banded shard -2.1 %, the other stand-ins
     // -0.1 ... -0.6 %, none slower (two builds A/B-ed in one process, profiles/r05_short_row_dissection.txt)
-    __builtin_nontemporal_store(early_y ? alpha * acc + beta * y_old : (beta == 0.0 ? alpha * acc : alpha * acc + beta * yin[row]), y + row);
+    __builtin_nontemporal_store(beta == 0.0 ? alpha * acc : alpha * acc + beta * y_old, y + row);
   }
 }
 
@@ -245,7 +243,7 @@ void launch_vec(hipStream_t stream, const CsrDev &A, const RowDigest *D, const C
   if (D && D->rpb != rpb) D = nullptr; // a digest built for another block size does not apply
   const int nblocks = static_cast<int>((static_cast<long long>(A.m) + rpb - 1) / rpb);
   if (nblocks == 0) return;
-  const int remap = ((xcd & 1) && nblocks >= 64 ? 1 : 0) | (xcd & ~1) | (x32_ok(A) ? 128 : 0); // bit 7: 32-bit gather offsets
+  const int remap = (xcd & ~0xb) | (x32_ok(A) ? 128 : 0); // bit 2 + bits 8..: XCD-chunked order, bits 4-5: stream policy, bit 6: zigzag, bit 7: 32-bit gather offsets
   // bits 4-5 of the flags: cache policy of the stream loads (0 nt/nt, 1 plain/plain, 2 colindex plain + values nt,
   // 3 colindex nt + values plain).  One set of kernels for every base-pointer alignment: their 16-B loads go through under-aligned
   // vector types (device_utils.hpp), the same instruction with the same cache policy whether or not the caller's arrays are 16-B aligned

@@ -99,6 +99,8 @@ constexpr int kMaxGridBlocks = 8388593;
 int max_grid_blocks(); // = kMaxGridBlocks unless a test lowered it (tunable max_grid_blocks, config.cpp): what the launchers clamp their grids to
 constexpr int kNnzPerThread = 8;          // two 4-wide steps per lane per round
 constexpr int kTile = kThreads * kNnzPerThread; // 2048 products = 16 KB of LDS per workgroup
+constexpr int kVectorTarget = 1900;       // vector-row tile kernel: products a workgroup's rows should bring to its tile (a tunable until round 5: 1900 against
+                                          // the row-block family's 1500 is 3-5.5 % faster on four of five sweep stand-ins, equal on the fifth)
 constexpr int kPlusThreads = 256;         // row-block-plus ANALYSIS geometry: the reference's (THREADS 256, R 2,
 constexpr int kPlusR = 2;                 // MIN_NNZ 1024) instance (csr_adaptive_plus_spmv.cpp:195-202)
 constexpr int kPlusMinNnz = 2 * kPlusR * kPlusThreads; // MIN_NNZ_PER_BLOCK 1024

@@ -158,8 +158,8 @@ unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *sample
   if (col_samples) mix(col_samples, sizeof(int) * kGuardSamples);
   static const char kBuild[] = __DATE__ " " __TIME__;
   mix(kBuild, sizeof(kBuild));
-  for (TunableId id : {kT_rowblock_target, kT_vector_target, kT_hint_budget_kb, kT_tune_protocol, kT_cache_ends_mb, kT_zigzag, kT_xcd_chunk, kT_xcd_chunk_tiles,
-                       kT_slab_whole_below, kT_rowlen, kT_legacy_kernels, kT_slab_kb, kT_hint_min_x_mb, kT_flat_small_nnz_k, kT_max_grid_blocks}) {
+  for (TunableId id : {kT_rowblock_target, kT_hint_budget_kb, kT_cache_ends_mb, kT_zigzag, kT_xcd_chunk, kT_slab_whole_below, kT_rowlen, kT_slab_kb,
+                       kT_hint_min_x_mb, kT_flat_small_nnz_k, kT_max_grid_blocks, kT_strict_strategy, kT_col16}) {
     const int v = tun(id);
     mix(&v, sizeof(int));
   }

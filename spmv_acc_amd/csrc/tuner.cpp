@@ -149,7 +149,7 @@ namespace detail {
 bool ensure_plus(Plan &p, const int *h_rowptr, hipStream_t stream, int min_nnz) {
   if (min_nnz < 256 || min_nnz > kTile) min_nnz = kPlusMinNnz;
   const int want_vec =
-      tun(kT_plus_ref_vec) ? plus_pick_vec(p.A.m, p.A.count()) : plus_pick_vec_tuned(p.A.m, p.A.count(), min_nnz);
+      plus_pick_vec_tuned(p.A.m, p.A.count(), min_nnz);
   if (p.plus_blocks >= 0 && p.plus_vec == want_vec && p.plus_min == min_nnz) return true;
   if (!plan_work_allowed("row-block analysis")) return false;
   ++t_plan_work;
@@ -385,7 +385,7 @@ bool ensure_col16(Plan &p, hipStream_t st) {
 
 void launch_flat_plan(hipStream_t st, const CsrDev &A, FlatPlan &F, int policy, double alpha, double beta, const double *x,
                       double *y, bool reverse) {
-  F.xcd_chunk = tun(kT_stage_fast) ? tun(kT_xcd_chunk_tiles) : -1; // -1: per-lane predicated staging (A/B)
+  F.xcd_chunk = tun(kT_xcd_chunk);
   F.stream_policy = policy;
   const int early = tun(kT_flat_early);
   if (early >= 0) F.early_stream = early != 0; // pinned (A/B runs); otherwise the plan's timed choice

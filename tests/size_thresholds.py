@@ -87,7 +87,7 @@ NOT_SIZE_RULES = {
     "kPlusR": "analysis geometry", "kPlusMinNnz": "analysis geometry (tunable plus_min_nnz, timed)", "kCol16Chunk": "16-bit column encoding geometry",
     "kHintLineShift": "x line = 16 columns", "kPage": "host page size (pin table)", "kChunk": "staging bounce buffer / col16 chunk", "kNcclFloat64": "RCCL enum",
     "kFlatReduceBuilt": "build option", "kLightRowsPerGroup": "LIGHT geometry", "kWaves": "waves per workgroup",
-    "kPlusNpt": "tile geometry", "kPlusTile": "tile geometry", "kPlusMaxRows": "tile geometry", "kSegTile": "tile geometry",
+    "kVectorTarget": "vector tile geometry (a tunable until round 5)", "kPlusNpt": "tile geometry", "kPlusTile": "tile geometry", "kPlusMaxRows": "tile geometry", "kSegTile": "tile geometry",
     "kSegCost": "slab passes: cost units per workgroup (balance only)", "kSegMinCost": "slab passes: cost floor of a run (balance only)",
     "kSegEntries": "slab passes: runs per workgroup (tile capacity; test_slab_segments_match_the_oracle fills it)", "kVecTileRows": "vector tile geometry",
 }

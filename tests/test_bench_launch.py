@@ -138,3 +138,41 @@ def test_the_stdout_line_fits_the_drivers_tail():
     assert line["rccl"]["ranks"] == dist["rccl"]["nranks_seen"] and line["spmv_plus_exchange_ms_per_step"] == dist["spmv_plus_exchange_ms_per_step"]
     assert line["banded"]["spmv_only_frac_of_hbm_peak"] == 0.7 and line["strong_scaling"]["gflops_total"] == 3000.0
     assert "roofline" in line and "cpu_baseline" in line
+
+
+def test_roofline_frac_keeps_its_source():
+    """the protocol stopped being a lever in round 5 and stays frozen -- `roofline.frac` / `achieved` are the timed region's back-to-back
+    figure, every extra leg's `us` / `frac` and every `ge_0.70` count are the reference harness's per-launch protocol (benchmark/csr_spmv.hpp:66-74,
+    benchmark/utils/benchmark_time.cpp:23-43), the kernel clock and the cold-cache column stand beside them.  This test fails when the definition table,
+    the field a figure is computed from, or the keys of the line change: any further movement of a gate has to come from a kernel's microseconds."""
+    bench = _bench_module()
+    assert bench.ROOFLINE_DEFINITION == {
+        "version": "r05", "frac": "back_to_back",
+        "achieved": "algorithmic bytes (12 nnz + 4 (m + 1) + 8 n + 16 m; 8 m for y at beta = 0) / back_to_back launch time",
+        "legs_and_gates": "per_launch",
+        "earlier_rounds": "rounds 1-4 quoted roofline.frac on per_launch: compare their lines with roofline.per_launch_protocol.frac (r04's 0.5461 -> this key)"}
+    assert bench.HBM_PEAK_GBS == 8000.0 and bench.REGION_REPS == 7
+    b_alg = 710_508_500  # the headline stand-in's algorithmic bytes (12 * 40,451,632 + 4 * 8,217,821 + 8 * 7,591,564 + 16 * 8,217,820)
+    r = bench.roofline_block(b_alg, b2b_ms=0.150, kernel_ms=0.155, ev_ms=0.160, cold=0.170)
+    assert r["frac"] == round(b_alg / 0.150e-3 / 1e9 / 8000.0, 4) == r["back_to_back"]["frac"] and r["launch_ms_mean"] == 0.150
+    assert abs(r["achieved"] - b_alg / 0.150e-3 / 1e9) < 0.01
+    assert r["per_launch_protocol"]["launch_ms_median"] == 0.160 and r["per_launch_protocol"]["frac"] == round(b_alg / 0.160e-3 / 1e9 / 8000.0, 4)
+    assert r["kernel_clock_reset_protocol"]["launch_ms_median"] == 0.155 and r["kernel_clock_reset_protocol"]["frac"] == round(b_alg / 0.155e-3 / 1e9 / 8000.0, 4)
+    assert r["cold_protocol"]["launch_ms_median"] == 0.170 and r["frac_cold"] == round(b_alg / 0.170e-3 / 1e9 / 8000.0, 4) < r["per_launch_protocol"]["frac"]
+    assert r["definition"]["frac"] == "back_to_back" and abs(r["cached_share_of_frac"] - (1 - 0.160 / 0.170)) < 2e-3
+    # no other input moves frac: the three other clocks may be anything
+    assert bench.roofline_block(b_alg, 0.150, 9.0, 9.0, 9.0)["frac"] == r["frac"] and bench.roofline_block(b_alg, 0.150, 9.0, 9.0)["frac"] == r["frac"]
+    assert "frac_cold" not in bench.roofline_block(b_alg, 0.150, 0.155, 0.160)
+    # the line carries the definition's short form, the cold column and the cold count next to the gate's count
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_final_runs.jsonl")).readline())
+    full["roofline"] = dict(r, traffic=None, traffic_lower_bound=None)
+    for s in ("flat", "adaptive"):
+        full["sweep_summary"][s].update({"ge_0.70_cold": 7, "median_frac_cold": 0.71, "stand_ins_on_16_bit_columns": 4})
+    line = json.loads(bench.compact_line(full))
+    assert line["roofline"]["definition"] == {"version": "r05", "frac": "back_to_back", "legs_and_gates": "per_launch"}
+    assert line["roofline"]["frac_cold"] == r["frac_cold"] and line["sweep_summary"]["flat"]["ge_0.70_cold"] == 7
+    # the legs' `frac` is computed from the per-launch median and from nothing else (timed_leg)
+    src = open(BENCH).read()
+    assert '"us": round(reset_ms * 1e3, 2), "frac": frac(reset_ms)' in src
+    assert 'roofline = roofline_block(b_alg, b2b_ms, kernel_ms, ev_ms, out_extra.get("per_launch_cold_ms_median"))' in src
+    assert '"ge_0.70": sum(1 for r in sweep.values() if r[s]["frac"] >= 0.70)' in src

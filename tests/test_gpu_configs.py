@@ -370,3 +370,16 @@ def test_bench_line_carries_every_baseline_config(torch_dev):
     cb = d["cpu_baseline"]
     assert cb["bitwise_equal_to_sequential"] and cb["stream_triad_gbs"] > 0 and len(cb["value_median_per_round"]) == 3 and cb["cores"] >= 1
     assert "builder-run" in d["roofline"]["traffic_source"]
+    # round 6: the frozen definition travels with the figure, and a cold-cache column stands beside every fraction (context, never a gate)
+    assert line["roofline"]["definition"] == {"version": "r05", "frac": "back_to_back", "legs_and_gates": "per_launch"}
+    assert 0 < d["roofline"]["frac_cold"] <= 1.02 * d["roofline"]["per_launch_protocol"]["frac"], d["roofline"]
+    assert line["roofline"]["frac_cold"] == d["roofline"]["frac_cold"] and -0.05 < d["roofline"]["cached_share_of_frac"] < 0.6
+    for name, row in d["sweep"].items():
+        for strat in ("flat", "adaptive"):
+            assert 0 < row[strat]["frac_cold"] <= 1.03 * row[strat]["frac"] + 0.01, (name, strat, row[strat])  # a cold start is never faster (up to noise)
+            assert row[strat]["col16"] in (0, 16, 32, 64), (name, strat, row[strat])
+        assert row["adaptive_colindex_only"]["col16"] == 0 and row["adaptive_colindex_only"]["us"] > 0
+    for strat in ("flat", "adaptive"):
+        assert 0 <= line["sweep_summary"][strat]["ge_0.70_cold"] <= line["sweep_summary"][strat]["ge_0.70_kernel_clock"] + 1
+        assert 0 <= line["sweep_summary"][strat]["stand_ins_on_16_bit_columns"] <= 12
+    assert d["rmat25"]["line_enhance"]["frac_cold"] > 0 and line["banded_shard"]["frac_cold"] > 0

@@ -499,21 +499,15 @@ def test_rmat_power_law_parity(torch_dev, oracle):
         assert err <= SCALED_TOL, (strat, err)
         assert oracle.verify_y(y.cpu().numpy(), ref)[2] == 0, strat
     spmv_acc_amd.release_plans(rp)
-    # the balance probe sends line_enhance / adaptive to the row-block-plus kernel (tunable rescue_flat: to the nnz-cut tiles)
-    lib = spmv_acc_amd.load_library()
-    for rescue_flat, built, not_built in ((0, "plus_blocks", "flat_tiles"), (1, "flat_tiles", "plus_blocks")):
-        assert lib.spmv_acc_set_tunable(b"rescue_flat", rescue_flat) == 0
-        try:
-            # (adaptive times every family on the matrix and so builds both plans, whatever the rescue is)
-            for strat in ("line_enhance", "line"):
-                y = y0.clone()
-                spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
-                torch.cuda.synchronize()
-                assert oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 1.0, hrp, hci, hv, hx, hy0) <= SCALED_TOL, (strat, rescue_flat)
-            info = spmv_acc_amd.query_plan(rp, m)
-            assert info[built] > 0 and info[not_built] <= 0, (rescue_flat, info)
-        finally:
-            lib.spmv_acc_reset_tunables()
+    # the balance probe sends line_enhance / line to the row-block-plus kernel (until round 5 a tunable could send them to flat's nnz-cut tiles instead)
+    # (adaptive times every family on the matrix and so builds both plans)
+    for strat in ("line_enhance", "line"):
+        y = y0.clone()
+        spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, rp, ci, v, x, y, strategy=strat)
+        torch.cuda.synchronize()
+        assert oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 1.0, hrp, hci, hv, hx, hy0) <= SCALED_TOL, strat
+    info = spmv_acc_amd.query_plan(rp, m)
+    assert info["plus_blocks"] > 0 and info["flat_tiles"] <= 0, info
             spmv_acc_amd.release_plans(rp)
 
 
@@ -681,12 +675,11 @@ def test_measurement_switches_keep_parity(torch_dev, oracle, hiplib):
     drp, dci, dv, dx = (dev(torch, a) for a in (rowptr, cols, vals, x))
     nnz = int(rowptr[-1])
     ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
-    variants = [("flat", {"flat_npt": 4}), ("flat", {"flat_npt": 16}), ("flat", {"xcd_chunk_tiles": 0}), ("flat", {"xcd_chunk_tiles": 5}),
-                ("flat", {"stage_fast": 0}), ("line_enhance", {"xcd_remap": 1, "xcd_chunk": 0}),
+    variants = [("flat", {"flat_npt": 4}), ("flat", {"flat_npt": 16}), ("flat", {"xcd_chunk": 0}), ("flat", {"xcd_chunk": 5}),
+                ("line_enhance", {"xcd_chunk": 0}),
                 ("line_enhance", {"xcd_chunk": 64}), ("line_enhance", {"rowblock_guard": 0}),
                 ("line_enhance", {"rowblock_vec": 8}), ("line_enhance", {"rowblock_target": 600}),
-                ("line_enhance", {"stage_fast": 0, "early_y": 0}), ("adaptive_plus", {"plus_host_analysis": 1}),
-                ("adaptive_plus", {"plus_ref_vec": 1}), ("adaptive_plus", {"xcd_chunk_tiles": 0}), ("adaptive_plus", {"xcd_chunk_tiles": 3}),
+                ("adaptive_plus", {"plus_host_analysis": 1}), ("adaptive_plus", {"xcd_chunk": 0}), ("adaptive_plus", {"xcd_chunk": 3}),
                 # round 2: row digest on / off, vector-row forms, flat's stream-first staging and tile sizes, 16-bit columns
                 ("line_enhance", {"rowlen": 1, "rowblock_guard": 0}), ("line_enhance", {"rowlen": 0, "rowblock_guard": 0}),
                 ("line_enhance", {"rowlen": 1, "rowblock_vec": 4, "rowblock_guard": 0}), ("line_enhance", {"rowlen": 1, "rowblock_vec": 64, "rowblock_guard": 0}),
@@ -701,7 +694,7 @@ def test_measurement_switches_keep_parity(torch_dev, oracle, hiplib):
                 ("flat", {"cache_ends_mb": 1, "stream_plain": 0}), ("flat", {"cache_ends_mb": 4000, "stream_plain": 0}),
                 # the segmented-scan reduction of a flat tile (the reference's FLAT_SEGMENT_SUM_REDUCE)
                 ("flat", {"flat_reduce": 1}), ("flat", {"flat_reduce": 1, "flat_finish": 0}), ("flat", {"flat_reduce": 1, "flat_finish": 1, "stream_plain": 1}),
-                ("flat", {"flat_reduce": 1, "flat_npt": 4}), ("flat", {"flat_reduce": 1, "stage_fast": 0}),
+                ("flat", {"flat_reduce": 1, "flat_npt": 4}),
                 # gather hints (cold gathers non-temporal): forced on, tiny and huge hot sets
                 ("adaptive_plus", {"gather_hint": 1}), ("adaptive_plus", {"gather_hint": 1, "hint_budget_kb": 1}),
                 ("adaptive_plus", {"gather_hint": 1, "hint_budget_kb": 100000}), ("flat", {"gather_hint": 1, "flat_npt": 8, "flat_early": 0}),

@@ -1108,7 +1108,7 @@ def test_light_and_block_row_run_their_own_kernels(torch_dev, oracle, hiplib):
     exercise their corners -- every lane width of LIGHT (average row length 1 .. 200), rows far longer than a workgroup's step, empty
     rows, a row count that is not a multiple of the fetch size, fewer rows than the resident grid -- with general alpha / beta, out of
     place, inside a hipGraph (LIGHT's counter is left at zero by the kernel's last wavefront: one node), and bitwise reproducible although LIGHT's row-to-wave
-    assignment changes from launch to launch.  `legacy_kernels = 0` brings the round-2 stand-ins back."""
+    assignment changes from launch to launch.  (The round-2 stand-ins behind `legacy_kernels = 0` went in round 6.)"""
     torch = torch_dev
     cases = []
     for avg, m in ((1, 50_001), (3, 40_000), (7, 30_011), (14, 20_000), (30, 9_000), (60, 5_000), (200, 1_500)):
@@ -1147,13 +1147,6 @@ def test_light_and_block_row_run_their_own_kernels(torch_dev, oracle, hiplib):
                     g.replay()
                     torch.cuda.synchronize()
                     assert torch.equal(static_y, eager), (tag, strat, "graph replay")
-            # the stand-ins are still there
-            hiplib.spmv_acc_set_tunable(b"legacy_kernels", 0)
-            y = dy0.clone()
-            spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, y, strategy="light")
-            torch.cuda.synchronize()
-            ref = oracle.host_spmv(1.0, 1.0, rowptr, cols, vals, x, y0)
-            assert oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, tag
             hiplib.spmv_acc_reset_tunables()
             spmv_acc_amd.release_plans(drp)
     finally:

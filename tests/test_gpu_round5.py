@@ -121,7 +121,7 @@ def test_grid_stride_paths_at_test_size(torch_dev, oracle, hiplib):
     cols, vals = _sorted_rows(rowptr, cols, vals)
     mat = (rowptr, cols, vals, 100_000)
     cap = {"max_grid_blocks": 256}
-    _check(torch_dev, oracle, hiplib, mat, dict(cap, legacy_kernels=0), ("wf_row", "block_row_ordinary"), "wave rows", want_kernel=("wave_row",))
+    _check(torch_dev, oracle, hiplib, mat, cap, ("wf_row",), "wave rows", want_kernel=("wave_row",))
     _check(torch_dev, oracle, hiplib, mat, dict(cap, vector_tile=0, vector_width=64), ("vector_row",), "direct vector rows", want_kernel=("vector_row",))
     _check(torch_dev, oracle, hiplib, mat, dict(cap, vector_tile=0, vector_width=2, rowblock_guard=0), ("vector_row",), "narrow vector rows",
            want_kernel=("vector_row",))

@@ -263,7 +263,7 @@ def test_round3_switches_and_entry_points_without_a_gpu(hiplib, tmp_path):
         assert r.returncode == 0 and r.stdout.split() == [want, "0"], (r.stdout, r.stderr[-500:])
     # the late round-3 switches and their shipped values: the full row-pointer check is opt-in, the slab passes are automatic (-1),
     # the slab-major copy is opt-in; SPMV_ACC_TUNABLES seeds any of them for a process that cannot call the setter
-    assert [hiplib.spmv_acc_get_tunable(n) for n in (b"guard_full", b"slab_segments", b"col_slabs", b"legacy_kernels", b"rowblock_target")] == [0, -1, 0, 1, 1500]
+    assert [hiplib.spmv_acc_get_tunable(n) for n in (b"guard_full", b"slab_segments", b"col_slabs", b"col16", b"rowblock_target")] == [0, -1, 0, -1, 1500]
     assert hiplib.spmv_acc_query_plan_slab_passes(None, 5) == -2  # no such plan
     assert hiplib.spmv_acc_query_plan_settled(None, 5) == -2
     code = "import spmv_acc_amd as s; l = s.load_library(); print(l.spmv_acc_get_tunable(b'slab_segments'), l.spmv_acc_get_tunable(b'guard_full'))"
@@ -378,3 +378,24 @@ def test_row_block_kernel_instances_fit_eight_waves_per_simd(tmp_path):
         assert k["agprs"] == 0, k
         assert k["vgprs"] <= (72 if hint else 64), k
         assert k["occupancy"] >= (7 if hint else 8), k
+
+
+def test_tunable_table_stays_small_and_documented():
+    """the engine's state space is what has to be tested, so the tunable table is capped (45 in round 5, 35 since round 6: ten A/B
+    switches whose sweeps had flat-lined became constants) and every entry is documented in INTEGRATION.md's table under its name and default."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "spmv_acc_amd", "csrc", "config.cpp")).read()
+    table = src[src.index("Tunable g_tunables[] = {"):src.index("static_assert(sizeof(g_tunables)")]
+    entries = re.findall(r'^\s*\{"(\w+)",\s*([^,]+),', table, flags=re.M)
+    names = [n for n, _ in entries]
+    assert len(names) == len(set(names)) and len(names) <= 35, (len(names), names)
+    for gone in ("xcd_remap", "xcd_chunk_tiles", "copy_nt", "stage_fast", "early_y", "rescue_flat", "plus_ref_vec", "tune_protocol", "legacy_kernels", "vector_target"):
+        assert gone not in names, gone
+    enum = src_enum = open(os.path.join(root, "spmv_acc_amd", "csrc", "engine_internal.hpp")).read()
+    ids = re.findall(r"kT_(\w+)", enum[enum.index("enum TunableId {"):enum.index("kTunableCount")])
+    assert ids == names, "TunableId and the table must list the same names in the same order"
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    for n, default in entries:
+        assert re.search(r"^\| `%s` \| " % re.escape(n), doc, flags=re.M), f"INTEGRATION.md's tunable table lacks `{n}`"
+    listed = re.findall(r"^\| `(\w+)` \| [^|]+ \| ", doc[doc.index("| name | default | meaning |"):].split("\n\n")[0], flags=re.M)
+    assert [n for n in listed if n not in names] == [], "INTEGRATION.md documents tunables that no longer exist"

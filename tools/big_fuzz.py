@@ -117,7 +117,7 @@ for case in range(cases):
                 ("flat", {"strict_strategy": 1}), ("line_enhance", {"strict_strategy": 1, "slab_segments": 4}), ("line", {"strict_strategy": 1, "calls": 2}),
                 ("adaptive", {"slab_segments": 1, "slab_kb": 16}), ("line_enhance", {"slab_segments": 1, "slab_kb": 1, "slab_whole_below": 0}),
                 ("adaptive_plus", {"slab_kb": 64, "hint_min_x_mb": 0, "hint_budget_kb": 64, "calls": 3}), ("adaptive", {"hint_min_x_mb": 0, "slab_kb": 4096, "calls": 3}),
-                ("wf_row", {"max_grid_blocks": 96, "legacy_kernels": 0}), ("vector_row", {"max_grid_blocks": 64, "vector_tile": 0}),
+                ("wf_row", {"max_grid_blocks": 96}), ("vector_row", {"max_grid_blocks": 64, "vector_tile": 0}),
                 ("line_enhance", {"max_grid_blocks": 200, "col_slabs": 3}), ("flat", {"max_grid_blocks": 128, "slab_segments": 6}),
                 ("flat", {"flat_small_nnz_k": 1, "flat_rowblock": 0}), ("flat", {"flat_small_nnz_k": 1 << 20, "flat_rowblock": 0, "calls": 2})]
     for strat, knobs in [(s_, dict(k_, call=c_)) for s_, k_ in variants for c_ in range(k_.get("calls", 1))]:
