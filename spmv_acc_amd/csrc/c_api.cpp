@@ -662,14 +662,29 @@ int spmv_acc_time_spmv_region(int strategy, int iters, double alpha, double beta
   thread_local hipEvent_t ev[2] = {nullptr, nullptr};
   thread_local int ev_device = -1;
   int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || ((!ev[0] || ev_device != dev) &&
-                                           (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess))) {
-    set_error(kErrHip, "spmv_acc_time_spmv_region: hipEventCreate failed");
+  if (hipGetDevice(&dev) != hipSuccess) {
+    set_error(kErrHip, "spmv_acc_time_spmv_region: hipGetDevice failed");
     return kErrHip;
   }
-  ev_device = dev;
+  if (!ev[0] || !ev[1] || ev_device != dev) { // (events belong to a device: a thread that moved on drops the old pair before it makes a new one)
+    for (auto &e : ev) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+    if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) {
+      for (auto &e : ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+      }
+      (void)hipGetLastError();
+      set_error(kErrHip, "spmv_acc_time_spmv_region: hipEventCreate failed");
+      return kErrHip;
+    }
+    ev_device = dev;
+  }
   hipStream_t st = get_stream();
   clear_error();
+  const unsigned work0 = plan_work_count();
   (void)hipEventRecord(ev[0], st);
   for (int i = 0; i < iters; ++i)
     run_spmv(strategy, 0, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy);
@@ -678,6 +693,12 @@ int spmv_acc_time_spmv_region(int strategy, int iters, double alpha, double beta
   if (hipEventSynchronize(ev[1]) != hipSuccess || hipEventElapsedTime(total_ms_out, ev[0], ev[1]) != hipSuccess) rc = kErrHip;
   if (rc != kOk) set_error(kErrHip, "spmv_acc_time_spmv_region: HIP failure while timing");
   if (rc == kOk && last_error() != kOk) rc = last_error();
+  // The region is for SETTLED plans (the caller prepares first): plan work inside it -- a structural pass, a deferred timing phase with its trial
+  // launches -- would sit between the two events and inflate the figure without a sign.  Reported as an error; the time is still written.
+  if (rc == kOk && plan_work_count() != work0) {
+    set_error(kErrBadArgument, "spmv_acc_time_spmv_region: the plan was not settled -- plan work ran inside the timed region (call spmv_acc_prepare first)");
+    rc = kErrBadArgument;
+  }
   return rc;
 }
 

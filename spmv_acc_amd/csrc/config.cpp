@@ -57,6 +57,9 @@ int last_error_code_only() { return g_err; }
 thread_local double t_last_prepare_us = 0.0;
 thread_local unsigned t_plan_work = 0; // bumped by every once-per-matrix step (structural pass, probe, timing) that really runs
 } // namespace detail
+unsigned plan_work_count() { return detail::t_plan_work; }
+namespace detail {
+} // namespace detail
 
 double last_prepare_us() { return t_last_prepare_us; }
 
@@ -297,6 +300,13 @@ int set_tunable(const char *name, int value) {
   apply_env_tunables();
   for (auto &t : g_tunables) {
     if (std::strcmp(t.name, name) == 0) {
+      // (the size-rule knobs that tests lower are clamped to what their arithmetic is written for: a negative MB count shifted left, a slab of
+      // zero bytes, a threshold beyond int range -- ADVICE r05)
+      const TunableId id = static_cast<TunableId>(&t - g_tunables);
+      if (id == kT_hint_min_x_mb) value = value < 0 ? 0 : (value > (1 << 20) ? (1 << 20) : value);
+      if (id == kT_slab_kb) value = value < 1 ? 1 : (value > (1 << 22) ? (1 << 22) : value);
+      if (id == kT_flat_small_nnz_k) value = value < 1 ? 1 : (value > (1 << 21) ? (1 << 21) : value);
+      if (id == kT_hint_budget_kb) value = value < 1 ? 1 : value;
       t.val = value;
       return 0;
     }

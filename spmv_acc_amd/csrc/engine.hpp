@@ -146,6 +146,7 @@ struct PlanInfo {
   int settled = 0;                // 1: the plan's latest call left no per-matrix timing open (first_call_budget / later_call_budget); 0: later calls will resume some
 };
 bool query_plan(const int *d_rowptr, int m, PlanInfo *out);
+unsigned plan_work_count(); // this thread's count of once-per-matrix steps (structural passes, probes, timing phases) that really ran: unchanged across a call = launches only
 int cached_plan_count();
 // Persistent per-matrix choices (plan.cpp "tune cache"): path of the text file, null / "" = off; default = environment
 // variable SPMV_ACC_TUNE_CACHE.

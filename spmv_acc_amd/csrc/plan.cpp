@@ -400,7 +400,10 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
   if (nnz < 0) {
     if ((h_rowptr = host_view(h_rowptr)) != nullptr) {
       nnz = h_rowptr[m];
-    } else if (!hip_ok(hipMemcpy(&nnz, rp + m, sizeof(int), hipMemcpyDeviceToHost), "read rowptr[m]")) {
+    } else if (!hip_ok(hipMemcpyAsync(&nnz, rp + m, sizeof(int), hipMemcpyDeviceToHost, t_stream), "read rowptr[m]") ||
+               !hip_ok(hipStreamSynchronize(t_stream), "read rowptr[m]")) {
+      // (on the calling thread's library stream: a rowptr produced on that stream just before the call is read after its producer -- a blocking
+      // null-stream copy is not ordered behind a non-blocking stream)
       return nullptr;
     }
   }
@@ -420,7 +423,9 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
     const int *hv = host_view(h_rowptr);
     int first = 0;
     if (hv) first = hv[0];
-    else if (!hip_ok(hipMemcpy(&first, rp, sizeof(int), hipMemcpyDeviceToHost), "read rowptr[0]")) return nullptr;
+    else if (!hip_ok(hipMemcpyAsync(&first, rp, sizeof(int), hipMemcpyDeviceToHost, t_stream), "read rowptr[0]") ||
+             !hip_ok(hipStreamSynchronize(t_stream), "read rowptr[0]"))
+      return nullptr; // (ordered on the library stream like the read of rowptr[m] above)
     p->A.nnz0 = (first > 0 && first <= nnz) ? first : 0;
   }
   p->A.rp = rp;

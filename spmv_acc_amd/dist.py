@@ -375,7 +375,11 @@ class RowShardedSpmv:
             if self.world > 1 or self.always_collective:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             result[depth] = float(t.item())
-        self.pipeline = min(result, key=result.get)
+        # Depth 1 unless a deeper pipeline MEASURES at least 3 % faster (round 6): chunking has a fixed cost -- ~8 us per queue
+        # hand-over, 0.159 -> 0.186 / 0.194 / 0.201 ms per step for 2 / 4 / 8 chunks on one rank, DESIGN.md section 5 -- that only an exchange longer
+        # than the kernel repays; where the exchange is short (one rank, few ranks on fast links) every depth loses and the choice is 1.
+        best = min(result, key=result.get)
+        self.pipeline = best if (1 not in result or result[best] < 0.97 * result[1]) else 1
         return result
 
     def set_y(self, y_slice):

@@ -365,7 +365,7 @@ def test_bench_line_carries_every_baseline_config(torch_dev):
     assert d["region_reps"] >= 5 and len(d["ms_per_step_wall_all"]) == d["region_reps"]
     for name, row in d["sweep"].items():
         for strat in ("flat", "adaptive"):
-            assert 0 < row[strat]["us_kernel_clock"] <= 1.03 * row[strat]["us"] + 0.3 and row[strat]["launches_per_spmv"] >= 1, (name, strat, row[strat])
+            assert 0 < row[strat]["us_kernel_clock"] <= 1.05 * row[strat]["us"] + 0.3 and row[strat]["launches_per_spmv"] >= 1, (name, strat, row[strat])
     assert "ge_0.70_kernel_clock" in d["sweep_summary"]["flat"] and "ge_0.70_kernel_clock" in line["sweep_summary"]["adaptive"]
     cb = d["cpu_baseline"]
     assert cb["bitwise_equal_to_sequential"] and cb["stream_triad_gbs"] > 0 and len(cb["value_median_per_round"]) == 3 and cb["cores"] >= 1

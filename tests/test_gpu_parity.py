@@ -508,7 +508,7 @@ def test_rmat_power_law_parity(torch_dev, oracle):
         assert oracle.scaled_error(y.cpu().numpy(), ref, 1.0, 1.0, hrp, hci, hv, hx, hy0) <= SCALED_TOL, strat
     info = spmv_acc_amd.query_plan(rp, m)
     assert info["plus_blocks"] > 0 and info["flat_tiles"] <= 0, info
-            spmv_acc_amd.release_plans(rp)
+    spmv_acc_amd.release_plans(rp)
 
 
 def test_banded_shard_closed_form(torch_dev):

@@ -1,5 +1,6 @@
-"""GPU suite (-m gpu), round-2 additions: the stale-plan guard, the argument checks of the Python plumbing, and the
-stream / event ordering of the row-sharded path on a one-rank RCCL communicator."""
+"""GPU suite (-m gpu): plans and their guards (stale plans detected and rebuilt, the ten-argument entry with a changed nnz, the wrapper's argument
+checks, the library stream following torch's), the one-rank RCCL ordering of the row-sharded step, and kernel invariants that must not leak into a
+sum (walking direction, row digest edge cases, the segmented-scan reduction, gather hints).  (Until round 6: test_gpu_round2.py.)"""
 import os
 import socket
 

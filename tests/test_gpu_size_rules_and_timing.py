@@ -1,4 +1,4 @@
-"""GPU suite, round 5 (-m gpu): what round 4's review asked to be put inside the suite's reach --
+"""GPU suite (-m gpu): size-selected branches at test size, strict strategy names, chunk views, the tune cache's provisional choice, the driver-facing timings (until round 6: test_gpu_round5.py) --
   * every SIZE-SELECTED branch of the plan and the launchers at test size (the round-4 regression -- 17 planes once x >= 496 MB -- passed 153 tests and
     was found by an out-of-suite R-MAT 26 probe): the size rules are tunables now (slab_kb, hint_min_x_mb, max_grid_blocks, flat_small_nnz_k) and this
     file crosses each of them on matrices of 10^4 .. 10^5 rows, against the CPU oracle (tests/size_thresholds.py is the registry the CPU suite checks);
