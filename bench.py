@@ -431,7 +431,9 @@ def leg_sweep(torch, device, name, A=None, light=False):
 
 
 def leg_rmat25(torch, device):
-    """BASELINE configs[3]: R-MAT scale 25 under line_enhance -- the default path, the one-kernel path it is timed against, the opt-in slab-major copy."""
+    """BASELINE configs[3]: R-MAT scale 25 under line_enhance -- the default path (since round 6: the slab-major copy, built inside spmv_acc_prepare where
+    it times faster than the run-list passes and 3 x 12 B per non-zero are free), the run-list passes alone (col_slabs = 0: what rounds 3-5 ran by
+    default), and the one-kernel path both are timed against."""
     import spmv_acc_amd
     from spmv_acc_amd import synth
 
@@ -440,24 +442,26 @@ def leg_rmat25(torch, device):
     out = {"workload": "R-MAT scale 25, edge factor 16 (BASELINE configs[3])", "rows": A[0], "nnz": A[2],
            "line_enhance": timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)}
     info = spmv_acc_amd.query_plan(A[3], A[0]) or {}
-    out["path"] = ("column-slab passes over run lists, no copy of the matrix (k_segment.hip; timed against the row-block-plus "
-                   "kernel at plan time)" if info.get("slab_passes") else "row-block-plus kernel")
+    kernel = info.get("last_kernel")
+    out["path"] = ("slab-major copy of the matrix in %d column slabs, built lazily and timed against the column-slab passes over run lists (k_slab.hip; values "
+                   "guarded by 65,536 samples per call)" % info.get("slab_passes", 0) if kernel == "col_slabs" else
+                   "column-slab passes over run lists, no copy of the matrix (k_segment.hip; timed against the row-block-plus kernel at plan time)"
+                   if info.get("slab_passes") else "row-block-plus kernel")
     spmv_acc_amd.release_plans(A[3])
-    # the same strategy with the slab passes switched off: the one-kernel path of rounds 1-2 (gather hints), for comparison
     lib = spmv_acc_amd.load_library()
+    # the run-list passes alone (no copy of the matrix: the default of rounds 3-5)
+    lib.spmv_acc_set_tunable(b"col_slabs", 0)
+    try:
+        out["line_enhance_slab_passes_only"] = timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)
+    finally:
+        lib.spmv_acc_set_tunable(b"col_slabs", -1)
+        spmv_acc_amd.release_plans(A[3])
+    # the same strategy with neither: the one-kernel path of rounds 1-2 (gather hints), for comparison
     lib.spmv_acc_set_tunable(b"slab_segments", 0)
     try:
         out["line_enhance_without_slab_passes"] = timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)
     finally:
         lib.spmv_acc_set_tunable(b"slab_segments", -1)
-        spmv_acc_amd.release_plans(A[3])
-    # opt-in leg, never the headline of configs[3]: column-slab blocking (tunable col_slabs: the plan holds a re-ordered copy of the
-    # matrix in 8 column ranges and runs 8 consecutive SpMVs, each gathering from an eighth of x).  Same algorithmic bytes.
-    lib.spmv_acc_set_tunable(b"col_slabs", 8)
-    try:
-        out["line_enhance_col_slabs8_opt_in"] = timed_leg(torch, "line_enhance", A, x, y0, iters=10, warm=3)
-    finally:
-        lib.spmv_acc_set_tunable(b"col_slabs", 0)
         spmv_acc_amd.release_plans(A[3])
     return out
 
@@ -606,8 +610,8 @@ def extra_legs(torch, device, headline, in_process=False):
         out["sweep_summary"][s]["median_frac_in_process"] = float(np.median([r[s]["frac"] for r in rows]))
     out["rmat25"] = leg("rmat25", lambda: leg_rmat25(torch, device))
     progress(f"rmat25: {out['rmat25']['line_enhance']} ({out['rmat25']['path']})")
+    progress(f"rmat25, run-list passes only (no copy): {out['rmat25']['line_enhance_slab_passes_only']}")
     progress(f"rmat25 without the slab passes: {out['rmat25']['line_enhance_without_slab_passes']}")
-    progress(f"rmat25 with 8 column slabs (opt-in): {out['rmat25']['line_enhance_col_slabs8_opt_in']}")
     out["banded_shard"] = leg("banded_shard", lambda: leg_banded_shard(torch, device))
     progress(f"banded shard: {out['banded_shard']['adaptive']}")
     return out

@@ -148,12 +148,16 @@ Tunable g_tunables[] = {
                                // matrix' shape instead (strategy_picker.cpp:19-65: the reference's choice is a pure function of its
                                // inputs), so two processes run the same kernels in the same configuration and y is bitwise equal
                                // across processes and runs.  Costs the per-matrix optimum (a few per cent on most stand-ins)
-    {"col_slabs", 0, 0},       // OPT-IN column-slab blocking (k_slab.hip): S >= 2 = the plan holds a re-ordered COPY of colindex and values,
-                               // A = sum of S column-range slabs, and an SpMV is S consecutive SpMVs of the named strategy, each gathering
-                               // from 1/S of x (power-law columns: the L2s then hold a hot set S times deeper; R-MAT scale 25 7.2 -> 4.4 ms
-                               // with S = 8; a slab keeps only the rows that have non-zeros in it).  Costs S passes over y; loses on matrices whose gathers already hit.  After editing values
-                               // in place call spmv_acc_refresh_values, after editing colindex spmv_acc_release_plans.  0 = off (the
-                               // default: plans hold no copy of the matrix)
+    {"col_slabs", -1, -1},     // column-slab blocking with a slab-major COPY of colindex and values (k_slab.hip): A = sum of S column-range slabs, an SpMV is S
+                               // consecutive SpMVs of the named strategy, each gathering from 1/S of x (power-law columns: R-MAT scale 25 5.0 -> 4.4 ms
+                               // with S = 8; a slab keeps only the rows that have non-zeros in it).  -1 (round 6) = automatic: a plan whose own timed
+                               // choice is the slab passes (slab_segments), once it has served 32 calls or inside spmv_acc_prepare, with free device
+                               // memory >= 3 x 12 B per non-zero, builds the copy, times it against the passes and keeps the faster; the copy holds
+                               // VALUES, so every call first compares 65,536 samples of the caller's values with the copy's (one small kernel and a
+                               // stream synchronisation: such calls block) and refreshes the copy when they differ -- an in-place edit of fewer than
+                               // ~1 in 10^4 values can slip through: call spmv_acc_refresh_values after such an edit, or set 0.  Never under
+                               // `deterministic`, `strict_strategy` or inside a stream capture.  0 = never; S >= 2 = always, S slabs (then the caller
+                               // refreshes: spmv_acc_refresh_values after editing values, spmv_acc_release_plans after editing colindex)
     {"flat_rowblock", -1, -1}, // flat on matrices whose fixed row blocks are balanced (nothing for non-zero-cut tiles to repair): -1 = time the flat tile
                                // kernel against the row-block kernel once per matrix and run the row blocks where they are >= 3 % faster (a flat tile
                                // needs one more dependent hop -- tile digest -> row extents -- and its cut rows a second kernel or a neighbour's carry:

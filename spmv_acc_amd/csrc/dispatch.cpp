@@ -633,6 +633,118 @@ UnboundedTuningScope::~UnboundedTuningScope() { --t_unbounded_tuning; }
 FlatSegmentSumScope::FlatSegmentSumScope() : prev(t_flat_segment_sum) { t_flat_segment_sum = true; }
 FlatSegmentSumScope::~FlatSegmentSumScope() { t_flat_segment_sum = prev; }
 
+// Column-slab blocking over the plan's slab-major COPY (k_slab.hip): S consecutive SpMVs of this strategy on the plan's slabs, the first one applying
+// beta (and reading y_in), the others accumulating into y.  Each slab is an ordinary matrix with a plan of its own.
+static bool run_col_slabs(Plan &p, int S, int strategy, hipStream_t st, double alpha, double beta, int m, int n, const double *dx, double *dy) {
+  if (!ensure_slabs(p, S, st)) return false;
+  launch_guard_check(st, p.A); // (the slabs' kernels check the slabs: the caller's rowptr is checked here)
+  // y = beta * y_in first (nothing to do for beta == 1 in place), then every slab: y_s = alpha * A_s x over the slab's non-empty
+  // rows (an ordinary SpMV of a smaller matrix, beta = 0) and y[rowid] += y_s
+  if (beta != 1.0 || p.A.yin) launch_scale_y(st, m, beta, dy, p.A.yin);
+  const bool outer = !t_in_slab;
+  t_in_slab = true;
+  for (int s = 0; s < S && last_error_code_only() == kOk; ++s) {
+    const long long o = p.slab_off[s];
+    const int ms = p.slab_rows[s];
+    if (ms == 0) continue; // an empty slab adds nothing
+    run_spmv(strategy, 0, alpha, 0.0, ms, n, static_cast<int>(p.slab_off[s + 1] - o), nullptr, p.slab_crp[s], p.d_slab_ci + o, p.d_slab_v + o, dx,
+             p.d_slab_ys, nullptr);
+    if (last_error_code_only() == kOk) launch_slab_merge(st, ms, p.slab_rowid[s], p.d_slab_ys, dy);
+  }
+  if (outer) t_in_slab = false;
+  p.last_kernel = kKernelColSlabs;
+  return last_error_code_only() == kOk;
+}
+
+// The AUTOMATIC slab-major copy (round 6; tunable col_slabs = -1, the default).  Round 3 built the copy form and left it opt-in because the plan
+// then holds 12 B per non-zero -- and VALUES; on R-MAT 25 it is 12 % faster than the run-list passes (4.4 against 5.0 ms: every 128-B line of the
+// streams is used whole instead of being fetched by every pass that owns a part of it).  Rule: a plan whose own timed choice is the slab passes
+// (power-law columns, x far beyond the L2s), not under `deterministic` / `strict_strategy`, not inside a capture, once it has served
+// kSlabCopyAfterCalls calls (or inside spmv_acc_prepare: the caller pays up front), on a device with free memory >= 3 x 12 B per non-zero, builds
+// the copy, lets the slabs' plans settle, times copy against passes in turns and keeps the faster by >= 3 %.
+// The values: before EVERY use of the copy kValueSamples evenly spaced samples of the caller's values are compared with what they were when the
+// copy was made (one small kernel + a stream synchronisation: these calls block, which is why captures keep the passes); on a difference the
+// copy's values are scattered again (one pass over the matrix) and the samples retaken, then the call proceeds with the new values.
+// Returns the slab count the copy should serve THIS call with, 0 = the ordinary path.
+static int slab_copy_auto(Plan &p, int strategy, hipStream_t st, int n, const double *dx) {
+  const bool hook = tun(kT_col_slabs) == -2; // (tests: the copy replaces the passes wherever the plan holds run lists, forced or chosen, whatever the timing says)
+  if (p.slab_copy_choice == 0 || p.seg_state != 1 || !(hook || (p.seg_choice == 1 && tun(kT_slab_segments) < 0)) || tun(kT_deterministic) || t_strict_name >= 0 ||
+      t_capturing || !dx)
+    return 0;
+  const int S = p.seg_slabs - (p.seg_rest_below > 0 ? 1 : 0); // the column slabs of the passes this plan already runs
+  if (S < 2 || S > 16) return 0;
+  if (p.slab_copy_choice < 0) {
+    if (!(t_unbounded_tuning > 0 || (p.calls > static_cast<unsigned long long>(kSlabCopyAfterCalls) && !defer_tuning()))) return 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 36ull * static_cast<size_t>(p.A.count())) {
+      (void)hipGetLastError();
+      p.slab_copy_choice = 0;
+      tune_log("m %d nnz %d: slab-major copy not built: %.1f GB free, 3 x 12 B per non-zero = %.1f GB wanted", p.A.m, p.A.nnz, free_b / 1e9, 36e-9 * p.A.count());
+      return 0;
+    }
+    ++t_plan_work;
+    const int count = p.A.count() < kValueSamples ? p.A.count() : kValueSamples;
+    bool ok = ensure_slabs(p, S, st) &&
+              hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_value_samples), sizeof(unsigned long long) * static_cast<size_t>(count)), "hipMalloc value samples") &&
+              hip_ok(hipHostMalloc(reinterpret_cast<void **>(&p.h_values_changed), sizeof(int)), "hipHostMalloc value flag");
+    double *scratch = ok ? tune_scratch(static_cast<size_t>(p.A.m)) : nullptr;
+    ok = ok && scratch != nullptr;
+    if (ok) {
+      *p.h_values_changed = 0;
+      p.value_samples = count;
+      launch_value_samples(st, p.A.v, p.A.nnz0, p.A.count() - 1, count, p.d_value_samples, nullptr);
+      ok = hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
+      // the slabs' own plans settle first (every slab is an ordinary matrix with its own timed choices), outside any budget
+      struct Unbounded {
+        Unbounded() { ++t_unbounded_tuning; }
+        ~Unbounded() { --t_unbounded_tuning; }
+      } unbounded;
+      const double saved_budget = t_budget_spmvs;
+      t_budget_spmvs = 0.0;
+      for (int round = 0; ok && round < 4; ++round) {
+        const unsigned w0 = t_plan_work;
+        ok = run_col_slabs(p, S, strategy, st, 1.0, trial_beta(), p.A.m, n, dx, scratch) && hip_ok(hipStreamSynchronize(st), "settle the slabs' plans");
+        if (t_plan_work == w0) break;
+      }
+      TuneTimer timer;
+      timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
+      float ms[2] = {0.f, 0.f};
+      t_in_segment_timing = true;
+      ok = ok && timer.ok && timer.time_in_turns(st, 2, [&](int c) {
+        if (c == 0) run_segments(st, p, 1.0, trial_beta(), dx, scratch);
+        else (void)run_col_slabs(p, S, strategy, st, 1.0, trial_beta(), p.A.m, n, dx, scratch);
+      }, 2, ms);
+      t_in_segment_timing = false;
+      t_budget_spmvs = saved_budget;
+      if (ok) {
+        p.slab_copy_choice = (ms[1] < 0.97f * ms[0] || tun(kT_col_slabs) == -2) ? 1 : 0; // (-2: tests keep the copy whatever the timing says)
+        tune_log("m %d nnz %d: slab passes over run lists %.1f us, slab-major copy (%d slabs, %.2f GB held) %.1f us -> %s", p.A.m, p.A.nnz, ms[0] * 1e3f, S,
+                 12e-9 * p.A.count(), ms[1] * 1e3f, p.slab_copy_choice ? "the copy (values guarded by samples)" : "the passes");
+      }
+    }
+    if (!ok || p.slab_copy_choice != 1) {
+      if (!ok) {
+        (void)hipGetLastError();
+        clear_error(); // (no room after all, or a failed launch of a trial: the copy is an optimisation, the passes serve)
+      }
+      p.free_slabs();
+      p.slab_copy_choice = 0;
+      return 0;
+    }
+  }
+  // the caller's values against the copy's, before the copy is used
+  *p.h_values_changed = 0;
+  launch_value_samples(st, p.A.v, p.A.nnz0, p.A.count() - 1, p.value_samples, p.d_value_samples, p.h_values_changed);
+  if (!hip_ok(hipStreamSynchronize(st), "compare the value samples")) return 0;
+  if (*p.h_values_changed) {
+    launch_slab_scatter(st, p.A, p.slab_width, p.slab_count, p.d_slab_rp, p.d_slab_off, p.d_slab_ci, p.d_slab_v, /*values_only=*/true);
+    launch_value_samples(st, p.A.v, p.A.nnz0, p.A.count() - 1, p.value_samples, p.d_value_samples, nullptr);
+    ++p.values_refreshed;
+    tune_log("m %d nnz %d: the caller's values changed under the slab-major copy: refreshed (%u so far)", p.A.m, p.A.nnz, p.values_refreshed);
+  }
+  return S;
+}
+
 void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
               const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx, double *dy,
               const double *dy_in) {
@@ -757,6 +869,16 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   if (tun(kT_validate) && !validate_plan(*p, st)) return;
   if (tun(kT_guard_full) && !t_in_slab && !launch_full_guard(*p, st)) return; // (a slab is a derived matrix: its parent was checked)
 
+  int copy_slabs = (tun(kT_col_slabs) >= 2 && !t_in_slab) ? (tun(kT_col_slabs) > 64 ? 64 : tun(kT_col_slabs)) : 0; // (forced: up to 64 slabs -- one lane of the build's wavefront per slab)
+  if (!copy_slabs && tun(kT_col_slabs) < 0 && !t_in_slab) copy_slabs = slab_copy_auto(*p, strategy, st, n, dx); // (round 6: the automatic slab-major copy)
+  if (copy_slabs) {
+    if (!run_col_slabs(*p, copy_slabs, strategy, st, alpha, beta, m, n, dx, dy)) return;
+    t_last_plan = p;
+    t_beta_class = beta != 0.0 ? 1 : 0;
+    if (t_plan_work != prepare_clock.work0 && p->tune_key) tune_store(*p);
+    return;
+  }
+
   if (tun(kT_slab_segments) >= 1 && !t_in_slab && !(t_strict_name == kLineEnhance || t_strict_name == kLine || t_strict_name == kFlat)) {
     // column-slab blocking without a copy: S passes over the plan's run lists (k_segment.hip), whatever the strategy name
     // (1 = the AUTOMATIC slab count -- the x-size rule, seg_auto_slabs -- with the passes always taken: what the timed choice runs where it wins)
@@ -777,31 +899,6 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     // (rows not ordered by column slab: the ordinary path below)
   }
 
-  if (tun(kT_col_slabs) >= 2 && !t_in_slab) {
-    // opt-in column-slab blocking: S consecutive SpMVs of this strategy on the plan's slabs, the first one applying beta (and
-    // reading y_in), the others accumulating into y.  Each slab is an ordinary matrix with a plan of its own.
-    const int S = tun(kT_col_slabs) > 16 ? 16 : tun(kT_col_slabs);
-    if (!ensure_slabs(*p, S, st)) return;
-    launch_guard_check(st, p->A); // (the slabs' kernels check the slabs: the caller's rowptr is checked here)
-    // y = beta * y_in first (nothing to do for beta == 1 in place), then every slab: y_s = alpha * A_s x over the slab's non-empty
-    // rows (an ordinary SpMV of a smaller matrix, beta = 0) and y[rowid] += y_s
-    if (beta != 1.0 || p->A.yin) launch_scale_y(st, m, beta, dy, p->A.yin);
-    t_in_slab = true;
-    for (int s = 0; s < S && last_error_code_only() == kOk; ++s) {
-      const long long o = p->slab_off[s];
-      const int ms = p->slab_rows[s];
-      if (ms == 0) continue; // an empty slab adds nothing
-      run_spmv(strategy, 0, alpha, 0.0, ms, n, static_cast<int>(p->slab_off[s + 1] - o), nullptr, p->slab_crp[s], p->d_slab_ci + o,
-               p->d_slab_v + o, dx, p->d_slab_ys, nullptr);
-      if (last_error_code_only() == kOk) launch_slab_merge(st, ms, p->slab_rowid[s], p->d_slab_ys, dy);
-    }
-    t_in_slab = false;
-    p->last_kernel = kKernelColSlabs;
-    t_last_plan = p;
-    t_beta_class = beta != 0.0 ? 1 : 0;
-    if (t_plan_work != prepare_clock.work0 && p->tune_key) tune_store(*p);
-    return;
-  }
 
   const long long avg = static_cast<long long>(p->A.count()) / m;
   // a resident grid for the two persistent-style legacy kernels: CUs x 8 workgroups of 4 waves

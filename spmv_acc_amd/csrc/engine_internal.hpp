@@ -130,6 +130,13 @@ struct Plan {
   unsigned digest_turn = 0;
   int slab_count = 0;
   int slab_width = 0;
+  // the AUTOMATIC slab-major copy (round 6, dispatch.cpp::slab_copy_auto; tunable col_slabs = -1): -1 not looked at, 0 not used (no room, slower, refused), 1 in use;
+  // the value samples that guard it (device) and the flag their comparison raises (pinned host memory)
+  int slab_copy_choice = -1;
+  unsigned long long *d_value_samples = nullptr;
+  int *h_values_changed = nullptr;
+  int value_samples = 0;
+  unsigned values_refreshed = 0; // how often an in-place edit of the values was noticed and the copy refreshed
   long long *d_slab_off = nullptr; // the slabs' start positions, on the device (kept for spmv_acc_refresh_values)
   // per slab, COMPACT: the rows that have non-zeros in the slab (ascending ids), their row pointers (ms + 1), how many there are;
   // one scratch vector for a slab's compact result

@@ -141,4 +141,25 @@ void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, 
                      rps, off, ci_out, v_out, values_only ? 1 : 0);
 }
 
+
+// ---- value samples of a plan that holds a copy of the values (the automatic slab-major copy, dispatch.cpp::slab_copy_auto) -------------------------
+// The caller may edit VALUES in place between two SpMVs (every other plan survives that: they stream values from the caller's array).  A plan
+// that holds a copy compares `count` evenly spaced samples of the caller's values with what they were when the copy was made, before it uses
+// the copy; *changed (pinned host memory) is raised on the first difference (bitwise comparison: NaNs compare by their bits).
+namespace {
+__global__ __launch_bounds__(256) void value_samples_kernel(const double *__restrict__ v, long long lo, long long span, int count,
+                                                            unsigned long long *__restrict__ saved, int *__restrict__ changed) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= count) return;
+  const long long j = lo + (count > 1 ? static_cast<long long>(k) * span / (count - 1) : 0);
+  const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(v[j]));
+  if (changed == nullptr) saved[k] = bits; // record
+  else if (saved[k] != bits) __hip_atomic_store(changed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+} // namespace
+void launch_value_samples(hipStream_t stream, const double *v, long long lo, long long span, int count, unsigned long long *saved, int *changed) {
+  if (count <= 0) return;
+  SPMV_ACC_LAUNCH(value_samples_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, v, lo, span, count, saved, changed);
+}
+
 } // namespace spmv_acc

@@ -276,6 +276,10 @@ void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, 
 void launch_slab_flags(hipStream_t stream, const int *rps, int m, int *flags);
 void launch_slab_compact(hipStream_t stream, const int *rps, const int *pos, int m, int *rowid, int *crp);
 void launch_slab_merge(hipStream_t stream, int ms, const int *rowid, const double *ys, double *y);
+// value samples of a plan that holds a copy of the values: changed == nullptr records `count` evenly spaced samples of v[lo .. lo + span], else compares
+void launch_value_samples(hipStream_t stream, const double *v, long long lo, long long span, int count, unsigned long long *saved, int *changed);
+constexpr int kValueSamples = 65536;    // samples of the caller's values a plan with a copy of them re-checks before every use
+constexpr int kSlabCopyAfterCalls = 32; // the automatic slab-major copy is built once a plan has served this many calls (or inside spmv_acc_prepare)
 
 // dst = src over `bytes` (16-B granules) with the kernels' streaming load shape: the copy ceiling probe
 void launch_stream_copy(hipStream_t stream, void *dst, const void *src, long long bytes, bool non_temporal);

@@ -284,6 +284,11 @@ void Plan::free_slabs() {
   if (d_slab_v) (void)hipFree(d_slab_v);
   if (d_slab_off) (void)hipFree(d_slab_off);
   d_slab_off = nullptr;
+  if (d_value_samples) (void)hipFree(d_value_samples);
+  d_value_samples = nullptr;
+  if (h_values_changed) (void)hipHostFree(h_values_changed);
+  h_values_changed = nullptr;
+  value_samples = 0;
   d_slab_rp = d_slab_ci = nullptr;
   d_slab_v = nullptr;
   slab_count = 0;

@@ -71,6 +71,10 @@ SIZE_RULES = [
      ["test_record_size_follows_the_escape_statistics", "test_encoding_matches_colindex"], "16 / 32 / 64 ints per chunk record: the smallest that at most 1 % of the chunks overflow (12 / 28 / 60 escapes); none: not encoded"),
     ("col16: first chunk of a view", CSRC + "tuner.cpp", r"const int chunk0 = A\.nnz0 / \(kThreads \* kNnzPerThread\) \* \(kThreads \* kNnzPerThread / kCol16Chunk\);",
      ["test_row_shards_without_rebasing"], "the encoding of an un-rebased row sub-range starts at the flat tile that holds its first non-zero"),
+    ("kSlabCopyAfterCalls", CSRC + "kernels.hpp", r"constexpr int kSlabCopyAfterCalls = 32;",
+     ["test_automatic_slab_major_copy_and_its_value_guard"], "the automatic slab-major copy is built by the call after the 32nd (or inside spmv_acc_prepare)"),
+    ("slab-major copy: free-memory rule", CSRC + "dispatch.cpp", r"free_b < 36ull \* static_cast<size_t>\(p\.A\.count\(\)\)",
+     ["test_automatic_slab_major_copy_and_its_value_guard", "test_configs3_rmat25_line_enhance_full_size"], "no copy unless 3 x 12 B per non-zero of device memory are free"),
     ("first non-zero of a view (A.nnz0)", CSRC + "tuner.cpp", r"const int tile0 = A\.nnz0 / stride;",
      ["test_chunk_views_are_sized_by_their_own_non_zeros", "test_row_shard_without_rebasing"], "flat: an un-rebased row sub-range starts at its own first tile"),
 ]
@@ -87,7 +91,7 @@ NOT_SIZE_RULES = {
     "kPlusR": "analysis geometry", "kPlusMinNnz": "analysis geometry (tunable plus_min_nnz, timed)", "kCol16Chunk": "16-bit column encoding geometry",
     "kHintLineShift": "x line = 16 columns", "kPage": "host page size (pin table)", "kChunk": "staging bounce buffer / col16 chunk", "kNcclFloat64": "RCCL enum",
     "kFlatReduceBuilt": "build option", "kLightRowsPerGroup": "LIGHT geometry", "kWaves": "waves per workgroup",
-    "kVectorTarget": "vector tile geometry (a tunable until round 5)", "kPlusNpt": "tile geometry", "kPlusTile": "tile geometry", "kPlusMaxRows": "tile geometry", "kSegTile": "tile geometry",
+    "kVectorTarget": "vector tile geometry (a tunable until round 5)", "kValueSamples": "value samples of a plan that holds a copy of the values (min(count, this))", "kPlusNpt": "tile geometry", "kPlusTile": "tile geometry", "kPlusMaxRows": "tile geometry", "kSegTile": "tile geometry",
     "kSegCost": "slab passes: cost units per workgroup (balance only)", "kSegMinCost": "slab passes: cost floor of a run (balance only)",
     "kSegEntries": "slab passes: runs per workgroup (tile capacity; test_slab_segments_match_the_oracle fills it)", "kVecTileRows": "vector tile geometry",
 }

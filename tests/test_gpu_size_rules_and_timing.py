@@ -113,6 +113,91 @@ def test_automatic_slab_passes_through_the_timed_choice(torch_dev, oracle, hipli
                want_kernel=("slab_passes", "rowblock_plus", "rowblock", "flat_tile"))
 
 
+def test_automatic_slab_major_copy_and_its_value_guard(torch_dev, oracle, hiplib):
+    """Round 6: a plan whose own timed choice is the slab passes builds, inside spmv_acc_prepare or after 32 calls, the slab-major
+    COPY (k_slab.hip), times it against the passes and keeps the faster (tunable col_slabs = -1, the default; -2 keeps the copy whatever the timing says,
+    which is how this test pins the path at test size).  The copy holds VALUES: before every use 65,536 samples of the caller's values are compared with
+    the copy's and the copy is refreshed when they differ -- a caller who rewrites the values in place is served the NEW values by the very next call,
+    without an error.  `deterministic`, `strict_strategy`, col_slabs = 0 and stream captures keep to the passes (which hold no values at all)."""
+    torch = torch_dev
+    rowptr, cols, vals, n = _powerlaw_sorted(60000, 200000, 3)
+    m, nnz = len(rowptr) - 1, int(rowptr[-1])
+    rng = np.random.default_rng(7)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    drp, dci, dv, dx, dy0 = (dev(torch, a) for a in (rowptr, cols, vals, x, y0))
+    # (slab_segments = 1: the run-list passes with the automatic slab count whatever the timing against row-block-plus says -- at test size the passes do
+    # not win by themselves; with col_slabs = -2 the copy then replaces them as it replaces a plan's own timed choice)
+    size_rules = {"slab_segments": 1, "slab_kb": 64}
+
+    def spmv(values, alpha=0.5, beta=-2.0, expect=None):
+        y = dy0.clone()
+        spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y, strategy="line_enhance")
+        torch.cuda.synchronize()
+        ref = oracle.host_spmv(alpha, beta, rowptr, cols, values, x, y0)
+        assert oracle.scaled_error(y.cpu().numpy(), ref, alpha, beta, rowptr, cols, values, x, y0) <= SCALED_TOL
+        assert hiplib.spmv_acc_last_error() == 0
+        kernel = spmv_acc_amd.query_plan(drp, m)["last_kernel"]
+        if expect is not None:
+            assert kernel in expect, (kernel, expect)
+        return kernel
+
+    try:
+        for k, v in dict(size_rules, col_slabs=-2).items():
+            assert hiplib.spmv_acc_set_tunable(k.encode(), v) == 0
+        spmv_acc_amd.prepare(m, n, nnz, drp, dci, dv, dx, strategy="line_enhance")
+        assert spmv_acc_amd.query_plan(drp, m)["slab_passes"] >= 2
+        spmv(vals, expect=("col_slabs",))
+        # every value rewritten in place: the next call sees it, refreshes the copy and computes with the new values
+        vals2 = vals * -0.75 + 0.125
+        dv.copy_(dev(torch, vals2))
+        spmv(vals2, expect=("col_slabs",))
+        spmv(vals2, alpha=1.0, beta=0.0, expect=("col_slabs",))
+        # a contiguous tenth of the values (wider than the sample spacing of nnz / 65,536): noticed as well
+        vals3 = vals2.copy()
+        vals3[nnz // 3: nnz // 3 + nnz // 10] *= 3.0
+        dv.copy_(dev(torch, vals3))
+        spmv(vals3, expect=("col_slabs",))
+        # inside a capture the passes serve (the guard needs a synchronisation): same result up to the order of the sums
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            ys = dy0.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                spmv_acc_amd.csr_spmv(0.5, -2.0, m, n, nnz, drp, dci, dv, dx, ys, strategy="line_enhance")
+            ys.copy_(dy0)
+            g.replay()
+        torch.cuda.synchronize()
+        ref = oracle.host_spmv(0.5, -2.0, rowptr, cols, vals3, x, y0)
+        assert oracle.scaled_error(ys.cpu().numpy(), ref, 0.5, -2.0, rowptr, cols, vals3, x, y0) <= SCALED_TOL
+        spmv_acc_amd.release_plans(drp)
+        # the switches that keep the copy out
+        for off in ({"col_slabs": 0}, {"deterministic": 1}, {"strict_strategy": 1}):
+            hiplib.spmv_acc_reset_tunables()
+            for k, v in {**size_rules, "col_slabs": -2, **off}.items():
+                assert hiplib.spmv_acc_set_tunable(k.encode(), v) == 0
+            spmv_acc_amd.prepare(m, n, nnz, drp, dci, dv, dx, strategy="line_enhance")
+            assert spmv(vals3) != "col_slabs", off
+            spmv_acc_amd.release_plans(drp)
+        # outside spmv_acc_prepare the copy is built by the call after the 32nd: passes until then, the copy from then on
+        hiplib.spmv_acc_reset_tunables()
+        for k, v in dict(size_rules, col_slabs=-2).items():
+            assert hiplib.spmv_acc_set_tunable(k.encode(), v) == 0
+        kernels = [spmv(vals3, expect=("col_slabs", "slab_passes")) for _ in range(36)]
+        assert kernels[:32] == ["slab_passes"] * 32 and kernels[-1] == "col_slabs", kernels
+        # the default (-1) decides by timing, and only for a plan whose OWN timed choice is the passes: whatever runs matches the oracle
+        spmv_acc_amd.release_plans(drp)
+        hiplib.spmv_acc_reset_tunables()
+        for k, v in {"slab_kb": 64, "hint_min_x_mb": 0, "hint_budget_kb": 64}.items():
+            assert hiplib.spmv_acc_set_tunable(k.encode(), v) == 0
+        spmv_acc_amd.prepare(m, n, nnz, drp, dci, dv, dx, strategy="line_enhance")
+        for _ in range(3):
+            spmv(vals3, expect=("col_slabs", "slab_passes", "rowblock_plus", "rowblock"))
+    finally:
+        hiplib.spmv_acc_set_stream(None)
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans()
+
+
 def test_grid_stride_paths_at_test_size(torch_dev, oracle, hiplib):
     """Kernels whose grid grows with m stride over the rows beyond kMaxGridBlocks workgroups (8,388,593: 33.5 M rows at one wavefront per row; round 3
     found two of them returning wrong results at 70 M rows).  With the cap lowered to 256 workgroups the striding runs at 10^5 rows: wf_row /
