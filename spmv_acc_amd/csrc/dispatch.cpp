@@ -685,14 +685,14 @@ static int slab_copy_auto(Plan &p, int strategy, hipStream_t st, int n, const do
     ++t_plan_work;
     const int count = p.A.count() < kValueSamples ? p.A.count() : kValueSamples;
     bool ok = ensure_slabs(p, S, st) &&
-              hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_value_samples), sizeof(unsigned long long) * static_cast<size_t>(count)), "hipMalloc value samples") &&
+              hip_ok(hipMalloc(reinterpret_cast<void **>(&p.d_value_samples), 12 * static_cast<size_t>(count) + 8), "hipMalloc value samples") &&
               hip_ok(hipHostMalloc(reinterpret_cast<void **>(&p.h_values_changed), sizeof(int)), "hipHostMalloc value flag");
     double *scratch = ok ? tune_scratch(static_cast<size_t>(p.A.m)) : nullptr;
     ok = ok && scratch != nullptr;
     if (ok) {
       *p.h_values_changed = 0;
       p.value_samples = count;
-      launch_value_samples(st, p.A.v, p.A.nnz0, p.A.count() - 1, count, p.d_value_samples, nullptr);
+      launch_value_samples(st, p.A.v, p.A.ci, p.A.nnz0, p.A.count() - 1, count, p.d_value_samples, nullptr);
       ok = hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
       // the slabs' own plans settle first (every slab is an ordinary matrix with its own timed choices), outside any budget
       struct Unbounded {
@@ -734,11 +734,19 @@ static int slab_copy_auto(Plan &p, int strategy, hipStream_t st, int n, const do
   }
   // the caller's values against the copy's, before the copy is used
   *p.h_values_changed = 0;
-  launch_value_samples(st, p.A.v, p.A.nnz0, p.A.count() - 1, p.value_samples, p.d_value_samples, p.h_values_changed);
+  launch_value_samples(st, p.A.v, p.A.ci, p.A.nnz0, p.A.count() - 1, p.value_samples, p.d_value_samples, p.h_values_changed);
   if (!hip_ok(hipStreamSynchronize(st), "compare the value samples")) return 0;
+  if (*p.h_values_changed & 2) {
+    // column indices edited in place: the copy's structure is stale.  It goes; the passes -- which read the caller's arrays, and for which a moved
+    // column only costs locality (k_segment.hip) -- serve from here on.
+    tune_log("m %d nnz %d: the caller's column indices changed under the slab-major copy: the copy is dropped, the run-list passes serve", p.A.m, p.A.nnz);
+    p.free_slabs();
+    p.slab_copy_choice = 0;
+    return 0;
+  }
   if (*p.h_values_changed) {
     launch_slab_scatter(st, p.A, p.slab_width, p.slab_count, p.d_slab_rp, p.d_slab_off, p.d_slab_ci, p.d_slab_v, /*values_only=*/true);
-    launch_value_samples(st, p.A.v, p.A.nnz0, p.A.count() - 1, p.value_samples, p.d_value_samples, nullptr);
+    launch_value_samples(st, p.A.v, p.A.ci, p.A.nnz0, p.A.count() - 1, p.value_samples, p.d_value_samples, nullptr);
     ++p.values_refreshed;
     tune_log("m %d nnz %d: the caller's values changed under the slab-major copy: refreshed (%u so far)", p.A.m, p.A.nnz, p.values_refreshed);
   }

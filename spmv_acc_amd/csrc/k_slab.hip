@@ -147,19 +147,29 @@ void launch_slab_scatter(hipStream_t stream, const CsrDev &A, int width, int S, 
 // that holds a copy compares `count` evenly spaced samples of the caller's values with what they were when the copy was made, before it uses
 // the copy; *changed (pinned host memory) is raised on the first difference (bitwise comparison: NaNs compare by their bits).
 namespace {
-__global__ __launch_bounds__(256) void value_samples_kernel(const double *__restrict__ v, long long lo, long long span, int count,
+// saved: count value samples (64-bit patterns) followed by count colindex samples (32 bits each, two to a word).  *changed: bit 0 = a value differs,
+// bit 1 = a column index differs (the copy's structure is stale: the engine drops it).
+__global__ __launch_bounds__(256) void value_samples_kernel(const double *__restrict__ v, const int *__restrict__ ci, long long lo, long long span, int count,
                                                             unsigned long long *__restrict__ saved, int *__restrict__ changed) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= count) return;
   const long long j = lo + (count > 1 ? static_cast<long long>(k) * span / (count - 1) : 0);
   const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(v[j]));
-  if (changed == nullptr) saved[k] = bits; // record
-  else if (saved[k] != bits) __hip_atomic_store(changed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  int *saved_ci = reinterpret_cast<int *>(saved + count);
+  const int c = ci[j];
+  if (changed == nullptr) { // record
+    saved[k] = bits;
+    saved_ci[k] = c;
+  } else {
+    if (saved[k] != bits) __hip_atomic_fetch_or(changed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (saved_ci[k] != c) __hip_atomic_fetch_or(changed, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 } // namespace
-void launch_value_samples(hipStream_t stream, const double *v, long long lo, long long span, int count, unsigned long long *saved, int *changed) {
+void launch_value_samples(hipStream_t stream, const double *v, const int *ci, long long lo, long long span, int count, unsigned long long *saved,
+                          int *changed) {
   if (count <= 0) return;
-  SPMV_ACC_LAUNCH(value_samples_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, v, lo, span, count, saved, changed);
+  SPMV_ACC_LAUNCH(value_samples_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, v, ci, lo, span, count, saved, changed);
 }
 
 } // namespace spmv_acc

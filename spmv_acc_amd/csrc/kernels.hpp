@@ -277,7 +277,8 @@ void launch_slab_flags(hipStream_t stream, const int *rps, int m, int *flags);
 void launch_slab_compact(hipStream_t stream, const int *rps, const int *pos, int m, int *rowid, int *crp);
 void launch_slab_merge(hipStream_t stream, int ms, const int *rowid, const double *ys, double *y);
 // value samples of a plan that holds a copy of the values: changed == nullptr records `count` evenly spaced samples of v[lo .. lo + span], else compares
-void launch_value_samples(hipStream_t stream, const double *v, long long lo, long long span, int count, unsigned long long *saved, int *changed);
+// (saved: count 64-bit value patterns + count 32-bit column indices = 12 * count bytes; *changed: bit 0 values, bit 1 column indices)
+void launch_value_samples(hipStream_t stream, const double *v, const int *ci, long long lo, long long span, int count, unsigned long long *saved, int *changed);
 constexpr int kValueSamples = 65536;    // samples of the caller's values a plan with a copy of them re-checks before every use
 constexpr int kSlabCopyAfterCalls = 32; // the automatic slab-major copy is built once a plan has served this many calls (or inside spmv_acc_prepare)
 

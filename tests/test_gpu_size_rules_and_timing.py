@@ -157,6 +157,20 @@ def test_automatic_slab_major_copy_and_its_value_guard(torch_dev, oracle, hiplib
         vals3[nnz // 3: nnz // 3 + nnz // 10] *= 3.0
         dv.copy_(dev(torch, vals3))
         spmv(vals3, expect=("col_slabs",))
+        # column indices rewritten in place (same rowptr): the copy's structure is stale -- it is dropped and the run-list passes, which read the caller's
+        # arrays, serve this call and the following ones; then everything back for the rest of the test
+        cols_b = np.concatenate([np.sort(n - 1 - cols[rowptr[i]:rowptr[i + 1]]) for i in range(m)]).astype(np.int32)
+        dci.copy_(dev(torch, cols_b))
+        y = dy0.clone()
+        spmv_acc_amd.csr_spmv(0.5, -2.0, m, n, nnz, drp, dci, dv, dx, y, strategy="line_enhance")
+        torch.cuda.synchronize()
+        ref_b = oracle.host_spmv(0.5, -2.0, rowptr, cols_b, vals3, x, y0)
+        assert oracle.scaled_error(y.cpu().numpy(), ref_b, 0.5, -2.0, rowptr, cols_b, vals3, x, y0) <= SCALED_TOL
+        assert spmv_acc_amd.query_plan(drp, m)["last_kernel"] == "slab_passes"
+        dci.copy_(dev(torch, cols))
+        spmv_acc_amd.release_plans(drp)
+        spmv_acc_amd.prepare(m, n, nnz, drp, dci, dv, dx, strategy="line_enhance")
+        spmv(vals3, expect=("col_slabs",))
         # inside a capture the passes serve (the guard needs a synchronisation): same result up to the order of the sums
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
