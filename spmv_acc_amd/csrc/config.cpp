@@ -96,10 +96,10 @@ Tunable g_tunables[] = {
     {"xcd_chunk", 16, 16},     // row blocks, flat tiles, row-block-plus blocks: each XCD takes this many consecutive blocks per super-chunk (0 = off; one knob
                                // since round 6: `xcd_chunk_tiles` is gone)
     {"rowblock_vec", 0, 0},    // 0 = pick from nnz/m, else force lanes per row
-    {"rowblock_target", 1500, 1500}, // products a row block should bring to its 2048-product tile.  Round 1 measured 1900 best (fullest tile); with
-                               // round 2-3's kernels (zigzag, per-matrix cache policy) and the per-launch protocol 1500 is 1-2 % faster on ten of
-                               // eleven sweep stand-ins and 2.8 % on the banded shard, +0.8 % on TSOPF (tools/param_sweep_reset.py, fresh plans on
-                               // the same arrays, profiles/r03_rowblock_target.txt); 1600 / 1400 / 1300 / 1700 / 2040 are not better
+    {"rowblock_target", -1, -1}, // products a row block should bring to its 2048-product tile: -1 = 1800 and 1500 timed in turns once per plan, the faster stays (rule: 1800);
+                               // a positive value pins it.  Round 1 measured 1900 best, round 3 1500 (1-2 %); with round 6's kernels 1800 is 3-6 % faster than
+                               // 1500 on the stand-ins of 28 and more non-zeros per row and on the banded shard, 1500 1.5 % ahead at 12.6 per row, 1900
+                               // 3-6 % behind (second rounds) -- profiles/r06_rowblock_target_sweep.txt
     {"stream_plain", -1, -1},  // stream-load cache policy: -1 = timed once per matrix; 0 nt, 1 default, 2 index default, 3 value default
     {"rowblock_guard", 1, 1},  // imbalance probe + rescue for the row-block family
     {"adaptive_timed", 1, 1},  // adaptive: 1 = time row blocks / row-block-plus / flat on the matrix and keep the fastest;

@@ -46,12 +46,12 @@ bool run_flat(hipStream_t st, Plan &p, double alpha, double beta, const double *
       !t_coarse_tuning && !strict) {
     if (rb_mode > 0) {
       int vec = 1, rpb = kThreads;
-      pick_rowblock_shape(p.A.m, p.A.count(), tun(kT_rowblock_target), &vec, &rpb);
+      pick_rowblock_shape(p.A.m, p.A.count(), rowblock_target_for(p), &vec, &rpb);
       if (t_capturing ? (p.rowblock_ok == 1 && p.rowblock_rpb == rpb) : (probe_rowblock(p, rpb, st) && p.rowblock_ok == 1))
         return run_rowblock(st, p, nullptr, alpha, beta, x, y, false, 0);
     } else if (p.flat_rowblock_choice < 0 && !t_capturing && !by_rule()) {
       int vec = 1, rpb = kThreads;
-      pick_rowblock_shape(p.A.m, p.A.count(), tun(kT_rowblock_target), &vec, &rpb);
+      pick_rowblock_shape(p.A.m, p.A.count(), rowblock_target_for(p), &vec, &rpb);
       if (!probe_rowblock(p, rpb, st)) return false;
       p.flat_rowblock_choice = 0;
       if (p.rowblock_ok == 1) {
@@ -205,20 +205,23 @@ bool run_plus(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double
 bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, double beta, const double *x, double *y,
                   bool allow_uneven_switch, int lanes_per_row) {
   int vec = 1, rpb = kThreads;
-  pick_rowblock_shape(p.A.m, p.A.count(), tun(kT_rowblock_target), &vec, &rpb);
-  // (THREAD_ROW: one lane per row whatever the row length, the rows per workgroup still from the tile target)
-  if (lanes_per_row > 0) vec = lanes_per_row;
   const int forced = tun(kT_rowblock_vec);
-  if (forced > 0) {
-    vec = forced;
-    rpb = kThreads / forced;
-  }
+  auto shape_for = [&](int target, int *v_out, int *r_out) {
+    pick_rowblock_shape(p.A.m, p.A.count(), target, v_out, r_out);
+    // (THREAD_ROW: one lane per row whatever the row length, the rows per workgroup still from the tile target)
+    if (lanes_per_row > 0) *v_out = lanes_per_row;
+    if (forced > 0) {
+      *v_out = forced;
+      *r_out = kThreads / forced;
+    }
+  };
+  shape_for(rowblock_target_for(p), &vec, &rpb);
   if (tun(kT_rowblock_guard)) {
     if (!probe_rowblock(p, rpb, st)) return false;
     // Imbalanced (power-law) matrix: fixed row blocks would leave a few workgroups with most of the work.  The rescue
     // is the row-block-PLUS kernel -- the reference's own answer to this (hip-csr-adaptive-plus is its line-enhance
     // kernel over analysed row blocks, long rows cut into dedicated blocks) -- which measures 1 % (R-MAT scale 25),
-    // 5 % (scale 22) and 17 % (scale 20) faster than the nnz-cut tiles of flat; `rescue_flat` keeps the older choice.
+    // 5 % (scale 22) and 17 % (scale 20) faster than the nnz-cut tiles of flat.
     if (p.rowblock_ok == 0)
       return run_plus(st, p, h_rowptr, alpha, beta, x, y);
     // Uneven but not pathological (striped densities: 60 / 20 nnz per row alternating every 300 or 5000 rows ran 196 us here and
@@ -227,24 +230,31 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
     if (p.rowblock_uneven && allow_uneven_switch) return run_plus(st, p, h_rowptr, alpha, beta, x, y);
   }
   const RowDigest *dg = nullptr;
-  const int want_lens = tun(kT_rowlen);
-  // (auto: rows of <= 8 non-zeros on average, where rowptr is >= 3.5 % of the traffic; measured at 12.6 per row the scan costs
-  // more than the bytes save -- largebasis-sized 17.8 vs 17.4 us)
-  if (want_lens > 0 || (want_lens < 0 && static_cast<long long>(p.A.count()) <= 8LL * p.A.m)) {
-    // (inside a capture a digest that does not exist yet is simply not used: the kernel reads rowptr, same result)
-    const bool have = p.digest.lens && p.digest.rpb == rpb;
-    if (have || !t_capturing) {
-      if (!ensure_digest(p, rpb, st)) return false;
-      dg = &p.digest;
-    }
-  }
-  // blocks at each end of the grid whose streams stay cacheable (tunable cache_ends_mb; 12 B per non-zero of stream)
   int cache_ends = 0;
-  if (tun(kT_cache_ends_mb) > 0 && tun(kT_zigzag) && p.A.count() > 0) {
-    const long long nblocks = (static_cast<long long>(p.A.m) + rpb - 1) / rpb;
-    const double bytes_per_block = 12.0 * p.A.count() / static_cast<double>(nblocks);
-    cache_ends = static_cast<int>(tun(kT_cache_ends_mb) * 1048576.0 / bytes_per_block);
-  }
+  const int want_lens = tun(kT_rowlen);
+  // what depends on the rows per workgroup: the row digest and the cacheable grid ends
+  auto setup = [&]() {
+    dg = nullptr;
+    // (auto: rows of <= 8 non-zeros on average, where rowptr is >= 3.5 % of the traffic; measured at 12.6 per row the scan costs
+    // more than the bytes save -- largebasis-sized 17.8 vs 17.4 us)
+    if (want_lens > 0 || (want_lens < 0 && static_cast<long long>(p.A.count()) <= 8LL * p.A.m)) {
+      // (inside a capture a digest that does not exist yet is simply not used: the kernel reads rowptr, same result)
+      const bool have = p.digest.lens && p.digest.rpb == rpb;
+      if (have || !t_capturing) {
+        if (!ensure_digest(p, rpb, st)) return false;
+        dg = &p.digest;
+      }
+    }
+    // blocks at each end of the grid whose streams stay cacheable (tunable cache_ends_mb; 12 B per non-zero of stream)
+    cache_ends = 0;
+    if (tun(kT_cache_ends_mb) > 0 && tun(kT_zigzag) && p.A.count() > 0) {
+      const long long nblocks = (static_cast<long long>(p.A.m) + rpb - 1) / rpb;
+      const double bytes_per_block = 12.0 * p.A.count() / static_cast<double>(nblocks);
+      cache_ends = static_cast<int>(tun(kT_cache_ends_mb) * 1048576.0 / bytes_per_block);
+    }
+    return true;
+  };
+  if (!setup()) return false;
   const int chunk = tun(kT_xcd_chunk);
   const int base_flags = chunk > 0 ? (4 | (chunk << 8)) : 0; // (bit 0 -- XCD-contiguous order --, bit 1 -- late y load -- and bit 3 -- per-lane predicated staging -- were A/B switches until round 5)
   p.A.cold = nullptr; // (the policy timing runs without gather hints)
@@ -253,6 +263,60 @@ bool run_rowblock(hipStream_t st, Plan &p, const int *h_rowptr, double alpha, do
         launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (pol << 4) | zz, 1.0, trial_beta(), x, ys, dg, cache_ends);
       }))
     return false;
+  // How full a row block's 2048-product tile should be (round 6): round 3 measured 1500 products per block 1-2 % faster than 1900; with this
+  // round's kernels (eight waves per SIMD, 32-bit gather offsets) 1800 is 3-6 % faster than 1500 on every stand-in of 28 and more non-zeros
+  // per row and on the banded shard, 1500 stays 1.5 % ahead on the largebasis-sized one (12.6 per row), 1900 loses 3-6 % (blocks spill into a
+  // second round) -- profiles/r06_rowblock_target_sweep.txt.  So the two are timed in turns, once per plan, under the policy just chosen; the
+  // rule (`deterministic`, deferred tuning, captures) is 1800.
+  if (tun(kT_rowblock_target) <= 0 && p.rb_target == 0 && p.stream_policy[kFamRowblock][t_beta_class] >= 0 && !t_capturing && !t_coarse_tuning &&
+      !t_no_policy_timing && !by_rule()) {
+    int v2[2], r2[2];
+    const int cand[2] = {kRowblockTargetRule, kRowblockTargetAlt};
+    for (int c = 0; c < 2; ++c) shape_for(cand[c], &v2[c], &r2[c]);
+    if (v2[0] == v2[1] && r2[0] == r2[1]) {
+      p.rb_target = cand[0]; // (short rows: both targets ask for more rows than a workgroup has lanes -- one shape)
+    } else {
+      ++t_plan_work;
+      double *scratch = nullptr;
+      if (!(scratch = tune_scratch(static_cast<size_t>(p.A.m)))) return false;
+      TuneTimer timer;
+      timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
+      bool ok = timer.ok && hip_ok(hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(p.A.m), st), "memset tune y");
+      bool skip[2] = {false, false};
+      // (a candidate whose blocks the balance probe refuses is out; the probe and the digest are per shape: rebuilt per turn, plan time only)
+      float ms[2] = {1e30f, 1e30f};
+      const int pol = policy_for(p, kFamRowblock);
+      for (int c = 0; ok && c < 2; ++c) {
+        vec = v2[c];
+        rpb = r2[c];
+        if (tun(kT_rowblock_guard)) {
+          ok = probe_rowblock(p, rpb, st);
+          skip[c] = ok && p.rowblock_ok == 0;
+        }
+      }
+      for (int round = 0; ok && round < ranking_rounds(); ++round) {
+        for (int c = 0; ok && c < 2; ++c) {
+          if (skip[c]) continue;
+          vec = v2[c];
+          rpb = r2[c];
+          ok = setup();
+          float t = 0.f;
+          ok = ok && timer.time(st, [&] {
+            const int zz = next_reverse(p) ? 64 : 0;
+            launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (pol << 4) | zz, 1.0, trial_beta(), x, scratch, dg, cache_ends);
+          }, &t);
+          if (ok && t < ms[c]) ms[c] = t; // (the smaller of the rounds: the candidates alternate, each turn a median of several launches)
+        }
+      }
+      if (!ok) return false;
+      p.rb_target = (!skip[1] && (skip[0] || ms[1] < 0.985f * ms[0])) ? cand[1] : cand[0];
+      tune_log("m %d nnz %d row blocks: %d products per block %.2f us, %d products %.2f us -> %d", p.A.m, p.A.nnz, cand[0], ms[0] * 1e3f, cand[1], ms[1] * 1e3f,
+               p.rb_target);
+    }
+    shape_for(rowblock_target_for(p), &vec, &rpb);
+    if (tun(kT_rowblock_guard) && !probe_rowblock(p, rpb, st)) return false;
+    if (!setup()) return false;
+  }
   if (!autotune_hint(p, kFamRowblock, st, [&](double *ys) {
         const int zz = next_reverse(p) ? 64 : 0;
         launch_rowblock_stream(st, p.A, vec, rpb, base_flags | (policy_for(p, kFamRowblock) << 4) | zz, 1.0, trial_beta(), x, ys, dg, cache_ends);
@@ -289,7 +353,7 @@ bool run_plus_prepare(Plan &p, const int *h_rowptr, hipStream_t st, const double
     // by rule, and a pure function of the matrix whatever was called on it before: the balance probe of the row-block shape
     // decides (hub rows: the reference's 1024, the block size that wins on power-law matrices; else 1536)
     int vec = 1, rpb = kThreads;
-    pick_rowblock_shape(p.A.m, p.A.count(), tun(kT_rowblock_target), &vec, &rpb);
+    pick_rowblock_shape(p.A.m, p.A.count(), rowblock_target_for(p), &vec, &rpb);
     return probe_rowblock(p, rpb, st) && ensure_plus(p, h_rowptr, st, p.rowblock_ok == 0 ? kPlusMinNnz : 1536);
   }
   if (p.plus_tuned_min > 0) return ensure_plus(p, h_rowptr, st, p.plus_tuned_min) && autotune_policy(p, kFamPlus, st, launch);

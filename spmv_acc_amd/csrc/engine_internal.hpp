@@ -96,6 +96,7 @@ struct Plan {
   // row-block family: -1 unknown, 1 balanced, 0 some workgroup would need too many LDS rounds
   int rowblock_ok = -1;
   int rowblock_rpb = 0;
+  int rb_target = 0; // timed choice between kRowblockTargetRule and kRowblockTargetAlt products per row block (0 = not timed: the rule)
   int max_block_nnz = 0;
   bool rowblock_uneven = false; // many row blocks far from the average block (balance probe)
   // adaptive's timed choice per beta class ([0]: beta == 0, [1]: y is read too -- the ranking flips between the classes where rows
@@ -249,10 +250,10 @@ struct Plan {
 };
 
 struct TuneRecord {
-  int v[24]; // stream_policy[4][2], adaptive_family[2], flat_npt, flat_early, flat_geometry_tuned, flat_mode[2], plus_min, hint_state0, hint_use[3], flat_rowblock, seg_choice, c16_use[row blocks], c16_use[flat]
+  int v[25]; // stream_policy[4][2], adaptive_family[2], flat_npt, flat_early, flat_geometry_tuned, flat_mode[2], plus_min, hint_state0, hint_use[3], flat_rowblock, seg_choice, c16_use[row blocks], c16_use[flat], rb_target
   bool operator==(const TuneRecord &o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
 };
-constexpr int kTuneFields = 24;
+constexpr int kTuneFields = 25;
 bool tune_cache_enabled();
 void tune_adopt(Plan &p);
 void tune_store(const Plan &p);
@@ -275,6 +276,9 @@ extern thread_local bool t_coarse_tuning;
 extern thread_local bool t_no_policy_timing;
 extern thread_local bool t_in_slab;
 inline bool next_reverse(Plan &p) { return tun(kT_zigzag) && (p.launches++ & 1u); }
+// products a row block should bring to its 2048-product tile: the tunable when it pins one, else the plan's timed choice, else the rule (dispatch.cpp::run_rowblock)
+constexpr int kRowblockTargetRule = 1800, kRowblockTargetAlt = 1500;
+inline int rowblock_target_for(const Plan &p) { return tun(kT_rowblock_target) > 0 ? tun(kT_rowblock_target) : (p.rb_target > 0 ? p.rb_target : kRowblockTargetRule); }
 constexpr int kFlatSmallNnz = 24 << 20;
 inline long long flat_small_nnz() { return static_cast<long long>(tun(kT_flat_small_nnz_k)) << 10; } // (tunable: tests cross the rule at test size)
 int policy_for(const Plan &p, int fam);

@@ -113,7 +113,7 @@ void tune_load_locked() {
       char tag[32];
       unsigned long long key = 0;
       int used = 0;
-      if (std::sscanf(line, "%31s %llx%n", tag, &key, &used) != 2 || std::strcmp(tag, "spmvacc4") != 0) continue;
+      if (std::sscanf(line, "%31s %llx%n", tag, &key, &used) != 2 || std::strcmp(tag, "spmvacc5") != 0) continue;
       TuneRecord r;
       bool ok = true;
       const char *at = line + used;
@@ -142,7 +142,7 @@ unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *sample
     const unsigned char *c = static_cast<const unsigned char *>(p);
     for (size_t i = 0; i < bytes; ++i) h = (h ^ c[i]) * 1099511628211ULL;
   };
-  static const char kVersion[] = "spmv_acc_amd 0.6 tune v6";
+  static const char kVersion[] = "spmv_acc_amd 0.6 tune v7";
   mix(kVersion, sizeof(kVersion));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
@@ -189,6 +189,7 @@ TuneRecord tune_snapshot(const Plan &p) {
   r.v[k++] = p.seg_choice;
   r.v[k++] = p.c16_use[kFamRowblock];
   r.v[k++] = p.c16_use[kFamFlat];
+  r.v[k++] = p.rb_target;
   return r;
 }
 } // namespace detail
@@ -236,6 +237,8 @@ void tune_adopt(Plan &p) {
   p.c16_use[kFamRowblock] = in(r.v[k], 0, 1) ? r.v[k] : -1;
   ++k;
   p.c16_use[kFamFlat] = in(r.v[k], 0, 1) ? r.v[k] : -1;
+  ++k;
+  p.rb_target = (r.v[k] == kRowblockTargetRule || r.v[k] == kRowblockTargetAlt) ? r.v[k] : 0;
   tune_log("m %d nnz %d: choices adopted from the tune cache (key %016llx)", p.A.m, p.A.nnz, p.tune_key);
 }
 // after a call that did plan work: keep what the plan now knows
@@ -248,7 +251,7 @@ void tune_store(const Plan &p) {
   if (it != g_tune_db.end() && it->second == r) return;
   g_tune_db[p.tune_key] = r;
   if (FILE *f = std::fopen(g_tune_path.c_str(), "a")) { // one line, one write: concurrent processes interleave whole lines
-    std::string line = "spmvacc4 ";
+    std::string line = "spmvacc5 ";
     char buf[32];
     std::snprintf(buf, sizeof(buf), "%016llx", p.tune_key);
     line += buf;
@@ -519,7 +522,7 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
       out->nnz = p.A.nnz;
       out->adaptive_branch = p.have_samples ? adaptive_branch(m, p.samples) : 0;
       int rb_vec = 1, rb_rows = kThreads;
-      pick_rowblock_shape(m, p.A.count(), tun(kT_rowblock_target), &rb_vec, &rb_rows);
+      pick_rowblock_shape(m, p.A.count(), rowblock_target_for(p), &rb_vec, &rb_rows);
       out->vec = rb_vec; // lanes per row of the row-block family for this matrix
       out->flat_tiles = p.flat_tiles;
       out->plus_blocks = p.plus_blocks;

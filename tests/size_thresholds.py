@@ -75,6 +75,9 @@ SIZE_RULES = [
      ["test_automatic_slab_major_copy_and_its_value_guard"], "the automatic slab-major copy is built by the call after the 32nd (or inside spmv_acc_prepare)"),
     ("slab-major copy: free-memory rule", CSRC + "dispatch.cpp", r"free_b < 36ull \* static_cast<size_t>\(p\.A\.count\(\)\)",
      ["test_automatic_slab_major_copy_and_its_value_guard", "test_configs3_rmat25_line_enhance_full_size"], "no copy unless 3 x 12 B per non-zero of device memory are free"),
+    ("kRowblockTargetRule / kRowblockTargetAlt", CSRC + "engine_internal.hpp", r"constexpr int kRowblockTargetRule = 1800, kRowblockTargetAlt = 1500;",
+     ["test_parity_all_strategies", "test_randomised_shapes_all_strategies", "test_deterministic_switch_is_bitwise_stable_across_processes"],
+     "products per row block: the two candidates a plan times in turns (the rule, 1800, under `deterministic`); with rows per block = target / (nnz / m) the tile's fill follows the matrix"),
     ("first non-zero of a view (A.nnz0)", CSRC + "tuner.cpp", r"const int tile0 = A\.nnz0 / stride;",
      ["test_chunk_views_are_sized_by_their_own_non_zeros", "test_row_shard_without_rebasing"], "flat: an un-rebased row sub-range starts at its own first tile"),
 ]

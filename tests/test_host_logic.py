@@ -263,7 +263,7 @@ def test_round3_switches_and_entry_points_without_a_gpu(hiplib, tmp_path):
         assert r.returncode == 0 and r.stdout.split() == [want, "-1"], (r.stdout, r.stderr[-500:])  # (col_slabs: automatic since round 6)
     # the late round-3 switches and their shipped values: the full row-pointer check is opt-in, the slab passes are automatic (-1),
     # the slab-major copy is opt-in; SPMV_ACC_TUNABLES seeds any of them for a process that cannot call the setter
-    assert [hiplib.spmv_acc_get_tunable(n) for n in (b"guard_full", b"slab_segments", b"col_slabs", b"col16", b"rowblock_target")] == [0, -1, -1, -1, 1500]
+    assert [hiplib.spmv_acc_get_tunable(n) for n in (b"guard_full", b"slab_segments", b"col_slabs", b"col16", b"rowblock_target")] == [0, -1, -1, -1, -1]
     assert hiplib.spmv_acc_query_plan_slab_passes(None, 5) == -2  # no such plan
     assert hiplib.spmv_acc_query_plan_settled(None, 5) == -2
     code = "import spmv_acc_amd as s; l = s.load_library(); print(l.spmv_acc_get_tunable(b'slab_segments'), l.spmv_acc_get_tunable(b'guard_full'))"
