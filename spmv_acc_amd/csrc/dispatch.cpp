@@ -737,7 +737,8 @@ static int slab_copy_auto(Plan &p, int strategy, hipStream_t st, int n, const do
     return 0;
   const int S = p.seg_slabs - (p.seg_rest_below > 0 ? 1 : 0); // the column slabs of the passes this plan already runs
   if (S < 2 || S > 16) return 0;
-  if (p.slab_copy_choice < 0) {
+  const bool adopted = p.slab_copy_choice == 1 && !p.d_slab_rp; // (the tune cache says the copy won on this matrix in an earlier process: built here, not timed again)
+  if (p.slab_copy_choice < 0 || adopted) {
     if (!(t_unbounded_tuning > 0 || (p.calls > static_cast<unsigned long long>(kSlabCopyAfterCalls) && !defer_tuning()))) return 0;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 36ull * static_cast<size_t>(p.A.count())) {
@@ -765,7 +766,7 @@ static int slab_copy_auto(Plan &p, int strategy, hipStream_t st, int n, const do
       } unbounded;
       const double saved_budget = t_budget_spmvs;
       t_budget_spmvs = 0.0;
-      for (int round = 0; ok && round < 4; ++round) {
+      for (int round = 0; ok && round < 4 && !adopted; ++round) {
         const unsigned w0 = t_plan_work;
         ok = run_col_slabs(p, S, strategy, st, 1.0, trial_beta(), p.A.m, n, dx, scratch) && hip_ok(hipStreamSynchronize(st), "settle the slabs' plans");
         if (t_plan_work == w0) break;
@@ -774,13 +775,13 @@ static int slab_copy_auto(Plan &p, int strategy, hipStream_t st, int n, const do
       timer.set_reset(scratch, sizeof(double) * static_cast<size_t>(p.A.m));
       float ms[2] = {0.f, 0.f};
       t_in_segment_timing = true;
-      ok = ok && timer.ok && timer.time_in_turns(st, 2, [&](int c) {
+      ok = ok && timer.ok && (adopted || timer.time_in_turns(st, 2, [&](int c) {
         if (c == 0) run_segments(st, p, 1.0, trial_beta(), dx, scratch);
         else (void)run_col_slabs(p, S, strategy, st, 1.0, trial_beta(), p.A.m, n, dx, scratch);
-      }, 2, ms);
+      }, 2, ms));
       t_in_segment_timing = false;
       t_budget_spmvs = saved_budget;
-      if (ok) {
+      if (ok && !adopted) {
         p.slab_copy_choice = (ms[1] < 0.97f * ms[0] || tun(kT_col_slabs) == -2) ? 1 : 0; // (-2: tests keep the copy whatever the timing says)
         tune_log("m %d nnz %d: slab passes over run lists %.1f us, slab-major copy (%d slabs, %.2f GB held) %.1f us -> %s", p.A.m, p.A.nnz, ms[0] * 1e3f, S,
                  12e-9 * p.A.count(), ms[1] * 1e3f, p.slab_copy_choice ? "the copy (values guarded by samples)" : "the passes");

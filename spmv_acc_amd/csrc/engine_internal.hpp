@@ -250,10 +250,10 @@ struct Plan {
 };
 
 struct TuneRecord {
-  int v[25]; // stream_policy[4][2], adaptive_family[2], flat_npt, flat_early, flat_geometry_tuned, flat_mode[2], plus_min, hint_state0, hint_use[3], flat_rowblock, seg_choice, c16_use[row blocks], c16_use[flat], rb_target
+  int v[26]; // stream_policy[4][2], adaptive_family[2], flat_npt, flat_early, flat_geometry_tuned, flat_mode[2], plus_min, hint_state0, hint_use[3], flat_rowblock, seg_choice, c16_use[row blocks], c16_use[flat], rb_target, slab_copy_choice
   bool operator==(const TuneRecord &o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
 };
-constexpr int kTuneFields = 25;
+constexpr int kTuneFields = 26;
 bool tune_cache_enabled();
 void tune_adopt(Plan &p);
 void tune_store(const Plan &p);

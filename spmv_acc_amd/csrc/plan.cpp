@@ -113,7 +113,7 @@ void tune_load_locked() {
       char tag[32];
       unsigned long long key = 0;
       int used = 0;
-      if (std::sscanf(line, "%31s %llx%n", tag, &key, &used) != 2 || std::strcmp(tag, "spmvacc5") != 0) continue;
+      if (std::sscanf(line, "%31s %llx%n", tag, &key, &used) != 2 || std::strcmp(tag, "spmvacc6") != 0) continue;
       TuneRecord r;
       bool ok = true;
       const char *at = line + used;
@@ -142,7 +142,7 @@ unsigned long long tune_key_of(int dev, int m, int n, int nnz, const int *sample
     const unsigned char *c = static_cast<const unsigned char *>(p);
     for (size_t i = 0; i < bytes; ++i) h = (h ^ c[i]) * 1099511628211ULL;
   };
-  static const char kVersion[] = "spmv_acc_amd 0.6 tune v7";
+  static const char kVersion[] = "spmv_acc_amd 0.6 tune v8";
   mix(kVersion, sizeof(kVersion));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
@@ -190,6 +190,7 @@ TuneRecord tune_snapshot(const Plan &p) {
   r.v[k++] = p.c16_use[kFamRowblock];
   r.v[k++] = p.c16_use[kFamFlat];
   r.v[k++] = p.rb_target;
+  r.v[k++] = tun(kT_col_slabs) == -2 ? -1 : p.slab_copy_choice; // (the tests' hook keeps the copy whatever the timing says: not a measured choice)
   return r;
 }
 } // namespace detail
@@ -239,6 +240,8 @@ void tune_adopt(Plan &p) {
   p.c16_use[kFamFlat] = in(r.v[k], 0, 1) ? r.v[k] : -1;
   ++k;
   p.rb_target = (r.v[k] == kRowblockTargetRule || r.v[k] == kRowblockTargetAlt) ? r.v[k] : 0;
+  ++k;
+  p.slab_copy_choice = in(r.v[k], 0, 1) ? r.v[k] : -1;
   tune_log("m %d nnz %d: choices adopted from the tune cache (key %016llx)", p.A.m, p.A.nnz, p.tune_key);
 }
 // after a call that did plan work: keep what the plan now knows
@@ -251,7 +254,7 @@ void tune_store(const Plan &p) {
   if (it != g_tune_db.end() && it->second == r) return;
   g_tune_db[p.tune_key] = r;
   if (FILE *f = std::fopen(g_tune_path.c_str(), "a")) { // one line, one write: concurrent processes interleave whole lines
-    std::string line = "spmvacc5 ";
+    std::string line = "spmvacc6 ";
     char buf[32];
     std::snprintf(buf, sizeof(buf), "%016llx", p.tune_key);
     line += buf;

@@ -452,7 +452,7 @@ def test_tune_cache_never_keeps_a_provisional_adaptive_choice(torch_dev, tmp_pat
     cache = str(tmp_path / "tune.txt")
     first, log1 = _child(tmp_path, cache, calls=1, prepare=False, extra_env={"SPMV_ACC_TUNABLES": "first_call_budget=1,later_call_budget=1"})
     assert not first["settled"], (first, log1[-1500:])  # (the budget left the comparison open: what this test is about)
-    lines = [ln.split() for ln in open(cache).read().splitlines() if ln.startswith("spmvacc5 ")]
+    lines = [ln.split() for ln in open(cache).read().splitlines() if ln.startswith("spmvacc6 ")]
     assert lines, "the first process stored nothing"
     # fields: tag, key, 8 stream policies, adaptive_family[0], adaptive_family[1], ...
     assert lines[-1][10] == "-1" and lines[-1][11] == "-1", lines[-1]
@@ -460,7 +460,7 @@ def test_tune_cache_never_keeps_a_provisional_adaptive_choice(torch_dev, tmp_pat
     assert "adopted from the tune cache" in log2
     assert "-> family" in log2, log2[-2000:]  # the comparison was (re)done here, not adopted half-done
     assert second["settled"] and second["family"] in (0, 1, 2)
-    lines = [ln.split() for ln in open(cache).read().splitlines() if ln.startswith("spmvacc5 ")]
+    lines = [ln.split() for ln in open(cache).read().splitlines() if ln.startswith("spmvacc6 ")]
     assert lines[-1][11] == str(second["family"]), (lines[-1], second)  # ... and the FINISHED choice is what the cache holds now
     third, log3 = _child(tmp_path, cache, calls=2, prepare=False)
     assert "-> family" not in log3 and third["family"] == second["family"], log3[-1500:]

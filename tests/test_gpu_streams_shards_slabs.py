@@ -736,7 +736,7 @@ def test_tune_cache_is_adopted_by_the_next_process(torch_dev, tmp_path):
     first, log1 = _run_child(tmp_path, "p1", strategies, {"SPMV_ACC_TUNE_CACHE": cache})
     assert "stream policy" in log1 and "adopted" not in log1
     lines = open(cache).read().splitlines()
-    assert lines and all(ln.startswith("spmvacc5 ") and len(ln.split()) == 27 for ln in lines)
+    assert lines and all(ln.startswith("spmvacc6 ") and len(ln.split()) == 28 for ln in lines)
     # a damaged file costs at most the damaged lines: one cut short by a killed writer, one from another version, one of noise
     with open(cache, "w") as f:
         f.write(lines[0][: len(lines[0]) // 2] + "\n" + "spmvacc1 00ff 1 2 3\n" + "\x00\x01 not a record\n\n" + "\n".join(lines) + "\n")

@@ -29,6 +29,9 @@ if a.workload == "banded_shard":  # BASELINE configs[4]: rank 3's 32 M-row shard
     nnz = int(rp[-1].item())
     beta = 0.0
     balg = synth.algorithmic_bytes(m, m + 7, nnz, beta_nonzero=False)
+elif a.workload == "rmat25":  # BASELINE configs[3]
+    m, n, nnz, rp, ci, v = synth.rmat_torch(25, device="cuda", seed=0xC4)
+    balg = synth.algorithmic_bytes(m, n, nnz)
 else:
     m, n, nnz, rp, ci, v = synth.sweep_standin_torch(a.workload, device="cuda")
     balg = synth.algorithmic_bytes(m, n, nnz)

@@ -24,6 +24,9 @@ if [ "$POL" -ge 0 ] 2>/dev/null; then export SPMV_ACC_TUNABLES="stream_plain=$PO
 # ... and with the column-slab passes where the trace pass's plan-time timing chose them (under the counters it can fall the other way)
 SLABS=$(python3 -c "import json,sys; d=json.loads(open('$OUT/bench_under_trace.json').read().strip().splitlines()[-1]); print(d.get('plan',{}).get('slab_passes',0))")
 if [ "$SLABS" -ge 2 ] 2>/dev/null; then export SPMV_ACC_TUNABLES="slab_segments=$SLABS${SPMV_ACC_TUNABLES:+,$SPMV_ACC_TUNABLES}"; fi
+# ... and with the column stream the trace pass's plan settled on (round 6: the 16-bit encoding is a timed choice; col16 = its record size pins it, 0 pins colindex)
+C16=$(python3 -c "import json,sys; d=json.loads(open('$OUT/bench_under_trace.json').read().strip().splitlines()[-1]); print(d.get('plan',{}).get('col16',-1))")
+if [ "$C16" -ge 0 ] 2>/dev/null; then export SPMV_ACC_TUNABLES="col16=$C16${SPMV_ACC_TUNABLES:+,$SPMV_ACC_TUNABLES}"; fi
 echo "[profile_round] counter passes with SPMV_ACC_TUNABLES=$SPMV_ACC_TUNABLES"
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "[profile_round] pmc $c"
