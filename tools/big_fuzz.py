@@ -119,7 +119,13 @@ for case in range(cases):
                 ("adaptive_plus", {"slab_kb": 64, "hint_min_x_mb": 0, "hint_budget_kb": 64, "calls": 3}), ("adaptive", {"hint_min_x_mb": 0, "slab_kb": 4096, "calls": 3}),
                 ("wf_row", {"max_grid_blocks": 96}), ("vector_row", {"max_grid_blocks": 64, "vector_tile": 0}),
                 ("line_enhance", {"max_grid_blocks": 200, "col_slabs": 3}), ("flat", {"max_grid_blocks": 128, "slab_segments": 6}),
-                ("flat", {"flat_small_nnz_k": 1, "flat_rowblock": 0}), ("flat", {"flat_small_nnz_k": 1 << 20, "flat_rowblock": 0, "calls": 2})]
+                ("flat", {"flat_small_nnz_k": 1, "flat_rowblock": 0}), ("flat", {"flat_small_nnz_k": 1 << 20, "flat_rowblock": 0, "calls": 2}),
+                # round 6: the 16-bit column encoding forced in the row blocks and in flat at every record size (16: heavy overflow wherever columns are far),
+                # the automatic slab-major copy kept whatever the timing says (col_slabs -2) over forced run lists, both tile targets pinned
+                ("line_enhance", {"col16": 1}), ("line_enhance", {"col16": 16, "rowlen": 1}), ("default", {"col16": 64, "oop": 1}), ("line", {"col16": 32, "calls": 2}),
+                ("flat", {"col16": 16, "flat_rowblock": 0, "flat_npt": 8}), ("flat", {"col16": 64, "flat_rowblock": 0, "flat_npt": 8, "flat_finish": 0, "oop": 1}),
+                ("adaptive", {"col16": 1, "calls": 3}), ("line_enhance", {"slab_segments": 1, "slab_kb": 16, "col_slabs": -2, "first_call_budget": 0, "calls": 3}),
+                ("line_enhance", {"rowblock_target": 1500}), ("line_enhance", {"rowblock_target": 1800, "col16": 1})]
     for strat, knobs in [(s_, dict(k_, call=c_)) for s_, k_ in variants for c_ in range(k_.get("calls", 1))]:
         lib.spmv_acc_reset_tunables()
         oop = bool(knobs.get("oop"))
