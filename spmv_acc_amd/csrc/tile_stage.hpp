@@ -26,6 +26,66 @@ namespace dev {
 // x line of that non-zero outside the set of hot lines that fit an L2.  Cold gathers are issued non-temporal, so the lines they
 // bring do not displace the hot ones (skewed_gather_bench.hip: 66 -> 74-76 G gathers/s on R-MAT columns; non-temporal for ALL
 // gathers: 43).  The bits only steer the cache policy: stale or arbitrary bits cannot change a sum.
+// The branch-free step.  ALL: every step of this wavefront starts below `hi` (stage_products' wave-uniform test): the body then has no
+// branch on wave_has[k] either.  Across those branches hipcc's waitcnt pass takes the most conservative count: the first gathers waited at
+// vmcnt(2) -- the first step's values AND the second step's colindex back -- where vmcnt(5) is what they need (round 6, found on the 16-bit
+// column path, whose first decode waited at vmcnt(0)).
+template <int THREADS, int NPT, bool NTC, bool NTV, bool HINT, bool ALL>
+__device__ __forceinline__ void stage_products_fast(double *__restrict__ lds, int a0, int hi, const int *__restrict__ ci,
+                                                    const double *__restrict__ v, const double *__restrict__ x,
+                                                    const unsigned char *__restrict__ cold) {
+  constexpr int K = NPT / 4;
+  int4v c[K];
+  double2v va[K], vb[K];
+  unsigned nib[K]; // HINT: the cold bits of this lane's four non-zeros
+  bool wave_has[K]; // wave-uniform: does any lane of this wave have a group below hi in step k?
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int wave_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + k * THREADS));
+    wave_has[k] = ALL || wave_j < hi;
+    if (wave_has[k]) {
+      const int j = a0 + 4 * (threadIdx.x + k * THREADS);
+      const int jc = (j < hi) ? j : a0; // lanes past hi in the boundary wave re-read the tile's first group (L1 hit)
+      c[k] = load_stream_i4<NTC>(ci + jc);
+      va[k] = load_stream_d2<NTV>(v + jc);
+      vb[k] = load_stream_d2<NTV>(v + jc + 2);
+      if (HINT) nib[k] = static_cast<unsigned>(cold[jc >> 3]) >> (jc & 4); // (jc is a multiple of 4; a wave reads 32 consecutive bytes)
+    }
+  }
+  double xg[K][4];
+  const XGather xr = make_xgather(x, HINT);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (wave_has[k]) {
+      if (HINT) {
+        xg[k][0] = gather_hinted(xr, c[k].x, nib[k] & 1u);
+        xg[k][1] = gather_hinted(xr, c[k].y, nib[k] & 2u);
+        xg[k][2] = gather_hinted(xr, c[k].z, nib[k] & 4u);
+        xg[k][3] = gather_hinted(xr, c[k].w, nib[k] & 8u);
+      } else { // one VGPR and one shift per gather address (the caller vouches for 8 * n < 2^32: x32)
+        xg[k][0] = gather_u32(x, c[k].x);
+        xg[k][1] = gather_u32(x, c[k].y);
+        xg[k][2] = gather_u32(x, c[k].z);
+        xg[k][3] = gather_u32(x, c[k].w);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (wave_has[k]) {
+      const int g = threadIdx.x + k * THREADS;
+      double2v p0, p1;
+      p0.x = va[k].x * xg[k][0];
+      p0.y = va[k].y * xg[k][1];
+      p1.x = vb[k].x * xg[k][2];
+      p1.y = vb[k].y * xg[k][3];
+      double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
+      dst[0] = p0;
+      dst[1] = p1;
+    }
+  }
+}
+
 template <int THREADS, int NPT, bool NTC = true, bool NTV = true, bool HINT = false>
 __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0, int hi, int nnz,
                                                const int *__restrict__ ci, const double *__restrict__ v,
@@ -42,55 +102,10 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
   // per-lane branches it waited for half of the first step's gathers before issuing the second step's.)  Products of
   // re-loaded groups land in slots >= hi - a0 that no reader touches.
   if (allow_fast && x32 && ((hi + 3) & ~3) <= nnz) {
-    int4v c[K];
-    double2v va[K], vb[K];
-    unsigned nib[K]; // HINT: the cold bits of this lane's four non-zeros
-    bool wave_has[K]; // wave-uniform: does any lane of this wave have a group below hi in step k?
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int wave_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + k * THREADS));
-      wave_has[k] = wave_j < hi;
-      if (wave_has[k]) {
-        const int j = a0 + 4 * (threadIdx.x + k * THREADS);
-        const int jc = (j < hi) ? j : a0; // lanes past hi in the boundary wave re-read the tile's first group (L1 hit)
-        c[k] = load_stream_i4<NTC>(ci + jc);
-        va[k] = load_stream_d2<NTV>(v + jc);
-        vb[k] = load_stream_d2<NTV>(v + jc + 2);
-        if (HINT) nib[k] = static_cast<unsigned>(cold[jc >> 3]) >> (jc & 4); // (jc is a multiple of 4; a wave reads 32 consecutive bytes)
-      }
-    }
-    double xg[K][4];
-    const XGather xr = make_xgather(x, HINT);
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (wave_has[k]) {
-        if (HINT) {
-          xg[k][0] = gather_hinted(xr, c[k].x, nib[k] & 1u);
-          xg[k][1] = gather_hinted(xr, c[k].y, nib[k] & 2u);
-          xg[k][2] = gather_hinted(xr, c[k].z, nib[k] & 4u);
-          xg[k][3] = gather_hinted(xr, c[k].w, nib[k] & 8u);
-        } else { // one VGPR and one shift per gather address (the caller vouches for 8 * n < 2^32: x32)
-          xg[k][0] = gather_u32(x, c[k].x);
-          xg[k][1] = gather_u32(x, c[k].y);
-          xg[k][2] = gather_u32(x, c[k].z);
-          xg[k][3] = gather_u32(x, c[k].w);
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (wave_has[k]) {
-        const int g = threadIdx.x + k * THREADS;
-        double2v p0, p1;
-        p0.x = va[k].x * xg[k][0];
-        p0.y = va[k].y * xg[k][1];
-        p1.x = vb[k].x * xg[k][2];
-        p1.y = vb[k].y * xg[k][3];
-        double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
-        dst[0] = p0;
-        dst[1] = p1;
-      }
-    }
+    // the wavefront's LAST step starts below hi: so do all its steps (wave-uniform)
+    const int last_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + (K - 1) * THREADS));
+    if (last_j < hi) stage_products_fast<THREADS, NPT, NTC, NTV, HINT, true>(lds, a0, hi, ci, v, x, cold);
+    else stage_products_fast<THREADS, NPT, NTC, NTV, HINT, false>(lds, a0, hi, ci, v, x, cold);
     return;
   }
   // General form: the tile that holds the ragged end of the arrays (one in the grid), `stage_fast = 0` (tests), and x of 4 GB and more
@@ -190,6 +205,9 @@ __device__ __forceinline__ void stage_finish(double *__restrict__ lds, const Str
 // = base + offset; in a chunk WITH escapes (wave-uniform test on the record's count) an escaped entry takes its column out of the record by
 // rank -- ballots + popcounts for the rank, one ds_bpermute per element slot that holds an escape anywhere in the wavefront; only a chunk
 // with more than R - 4 escapes reads the overflow list (a dependent load, <= 1 % of the chunks by the choice of R).
+// (A form whose codes NAME the escape -- 0xFF00 + index, no ranks: 16 instead of ~40 vector instructions per four non-zeros, 4 more registers --
+// measured the same within 0.5 % on eight stand-ins under pinned plans and 2-4 % slower on the long-row one: profiles/r06_col16_counters.md
+// section 5.  The instruction count was not what held this path back; the wait in front of the first decode was: see stage_products_c16_body.)
 // (Round 2's form -- base[] and esc_start[] arrays, one escape list -- needed two scalars back before it could ask for the escapes, and those
 // before the first gather: profiles/r06_col16_counters.md.)
 //   a0  : tile origin, multiple of 256;   lo4 : first group the workgroup needs (multiple of 4, a0 <= lo4);   hi : exclusive bound
@@ -199,9 +217,13 @@ __device__ __forceinline__ void stage_finish(double *__restrict__ lds, const Str
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 typedef uint2v uint2v_a2 __attribute__((aligned(2)));
 
-template <int THREADS, int NPT, bool NTC, bool NTV>
-__device__ __forceinline__ void stage_products_c16(double *__restrict__ lds, int a0, int lo4, int hi, const Col16Dev &C,
-                                                   const double *__restrict__ v, const double *__restrict__ x) {
+// ALL: every step of this wavefront starts below `hi` (the caller's wave-uniform test) -- the body then has no branch on has[k] at all.
+// With the per-step branches the waitcnt pass cannot count across them: it placed s_waitcnt vmcnt(0) in front of the first decode (ALL the
+// value loads back before the first gather leaves) where vmcnt(5) is what the decode needs (record + offsets).  seven of eight wavefront
+// steps of a row-block grid are ALL steps (tiles are filled to 1800 of 2048 products).
+template <int THREADS, int NPT, bool NTC, bool NTV, bool ALL>
+__device__ __forceinline__ void stage_products_c16_body(double *__restrict__ lds, int a0, int lo4, int hi, const Col16Dev &C,
+                                                        const double *__restrict__ v, const double *__restrict__ x) {
   constexpr int K = NPT / 4;
   uint2v d[K];
   double2v va[K], vb[K];
@@ -213,7 +235,7 @@ __device__ __forceinline__ void stage_products_c16(double *__restrict__ lds, int
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int wave_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + k * THREADS));
-    has[k] = wave_j < hi;
+    has[k] = ALL || wave_j < hi;
     if (has[k]) rv[k] = C.rec[static_cast<long long>(wave_j >> 8) * R + rl];
   }
 #pragma unroll
@@ -245,11 +267,11 @@ __device__ __forceinline__ void stage_products_c16(double *__restrict__ lds, int
                          static_cast<int>(d[k].y >> 16)};
       int c[4] = {bs + dq[0], bs + dq[1], bs + dq[2], bs + dq[3]};
       if (nesc > 0) { // wave-uniform
+        const int E = R - 4;
         const bool e[4] = {dq[0] == 0xFFFF, dq[1] == 0xFFFF, dq[2] == 0xFFFF, dq[3] == 0xFFFF};
         const unsigned long long slot[4] = {__ballot(e[0]), __ballot(e[1]), __ballot(e[2]), __ballot(e[3])};
         // rank of this lane's first escape in the chunk: the escapes held by lower lanes (records list them in non-zero order)
         int r = __popcll(slot[0] & lt) + __popcll(slot[1] & lt) + __popcll(slot[2] & lt) + __popcll(slot[3] & lt);
-        const int E = R - 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (slot[q]) { // wave-uniform: some lane's q-th entry is an escape
@@ -278,6 +300,15 @@ __device__ __forceinline__ void stage_products_c16(double *__restrict__ lds, int
       dst[1] = p1;
     }
   }
+}
+
+template <int THREADS, int NPT, bool NTC, bool NTV>
+__device__ __forceinline__ void stage_products_c16(double *__restrict__ lds, int a0, int lo4, int hi, const Col16Dev &C,
+                                                   const double *__restrict__ v, const double *__restrict__ x) {
+  // the wavefront's LAST step starts below hi: so do all its steps (wave-uniform)
+  const int last_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + (NPT / 4 - 1) * THREADS));
+  if (last_j < hi) stage_products_c16_body<THREADS, NPT, NTC, NTV, true>(lds, a0, lo4, hi, C, v, x);
+  else stage_products_c16_body<THREADS, NPT, NTC, NTV, false>(lds, a0, lo4, hi, C, v, x);
 }
 
 // Stale-plan guard of the kernels that read the encoding: they no longer read colindex, so an in-place edit of the column indices (same rowptr)
