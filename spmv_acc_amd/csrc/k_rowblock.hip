@@ -109,10 +109,6 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
 
   double acc = 0.0;
   int incl = 0;
-  if (LENS && from_lens) { // (block-uniform branch; the scan needs every lane of the wave)
-    incl = wave_inclusive_scan(lane == 0 ? len : 0);
-    if ((threadIdx.x & (kWave - 1)) == kWave - 1) wave_tot[threadIdx.x / kWave] = incl;
-  }
   // tile origin aligned down so 16-B loads stay aligned; the (at most 3) extra leading products are never read (C16: aligned down to the
   // chunk, the lanes in front of the block's first group re-read that group)
   const int lo4 = s0 & ~3;
@@ -132,6 +128,12 @@ __global__ __launch_bounds__(kThreads) void rowblock_stream_kernel(int m, int nn
       stage_products<kThreads, kNnzPerThread, false, false, HINT>(lds, off, s1, nnz, ci, v, x, true, cold, (flags & 128) != 0);
     else
       stage_products<kThreads, kNnzPerThread, NTC, NTV, HINT>(lds, off, s1, nnz, ci, v, x, true, cold, (flags & 128) != 0);
+    if (LENS && from_lens && off == off0) { // (block-uniform branch; the scan needs every lane of the wave)
+      // The row lengths are consumed HERE, behind the staging: scanned in front of it (rounds 2-5) the scan's wait for lens[row] stood between
+      // the block's bounds and its first stream load -- one more dependent round trip per workgroup, for a byte the tile does not need.
+      incl = wave_inclusive_scan(lane == 0 ? len : 0);
+      if ((threadIdx.x & (kWave - 1)) == kWave - 1) wave_tot[threadIdx.x / kWave] = incl;
+    }
     __syncthreads();
     if (LENS && from_lens && off == off0) {
       const int w = threadIdx.x / kWave;

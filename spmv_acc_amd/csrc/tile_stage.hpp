@@ -26,63 +26,95 @@ namespace dev {
 // x line of that non-zero outside the set of hot lines that fit an L2.  Cold gathers are issued non-temporal, so the lines they
 // bring do not displace the hot ones (skewed_gather_bench.hip: 66 -> 74-76 G gathers/s on R-MAT columns; non-temporal for ALL
 // gathers: 43).  The bits only steer the cache policy: stale or arbitrary bits cannot change a sum.
-// The branch-free step.  ALL: every step of this wavefront starts below `hi` (stage_products' wave-uniform test): the body then has no
-// branch on wave_has[k] either.  Across those branches hipcc's waitcnt pass takes the most conservative count: the first gathers waited at
+// The branch-free step of a wavefront whose steps ALL start below `hi` (stage_products' wave-uniform test): no branch at all between the
+// loads.  Across the per-step branches of the earlier form hipcc's waitcnt pass took the most conservative count: the first gathers waited at
 // vmcnt(2) -- the first step's values AND the second step's colindex back -- where vmcnt(5) is what they need (round 6, found on the 16-bit
 // column path, whose first decode waited at vmcnt(0)).
-template <int THREADS, int NPT, bool NTC, bool NTV, bool HINT, bool ALL>
-__device__ __forceinline__ void stage_products_fast(double *__restrict__ lds, int a0, int hi, const int *__restrict__ ci,
-                                                    const double *__restrict__ v, const double *__restrict__ x,
-                                                    const unsigned char *__restrict__ cold) {
+template <int THREADS, int NPT, bool NTC, bool NTV, bool HINT>
+__device__ __forceinline__ void stage_products_all(double *__restrict__ lds, int a0, int hi, const int *__restrict__ ci,
+                                                   const double *__restrict__ v, const double *__restrict__ x,
+                                                   const unsigned char *__restrict__ cold) {
   constexpr int K = NPT / 4;
   int4v c[K];
   double2v va[K], vb[K];
   unsigned nib[K]; // HINT: the cold bits of this lane's four non-zeros
-  bool wave_has[K]; // wave-uniform: does any lane of this wave have a group below hi in step k?
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const int wave_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + k * THREADS));
-    wave_has[k] = ALL || wave_j < hi;
-    if (wave_has[k]) {
-      const int j = a0 + 4 * (threadIdx.x + k * THREADS);
-      const int jc = (j < hi) ? j : a0; // lanes past hi in the boundary wave re-read the tile's first group (L1 hit)
-      c[k] = load_stream_i4<NTC>(ci + jc);
-      va[k] = load_stream_d2<NTV>(v + jc);
-      vb[k] = load_stream_d2<NTV>(v + jc + 2);
-      if (HINT) nib[k] = static_cast<unsigned>(cold[jc >> 3]) >> (jc & 4); // (jc is a multiple of 4; a wave reads 32 consecutive bytes)
-    }
+    const int j = a0 + 4 * (threadIdx.x + k * THREADS);
+    const int jc = (j < hi) ? j : a0; // lanes past hi in the boundary wave re-read the tile's first group (L1 hit)
+    c[k] = load_stream_i4<NTC>(ci + jc);
+    va[k] = load_stream_d2<NTV>(v + jc);
+    vb[k] = load_stream_d2<NTV>(v + jc + 2);
+    if (HINT) nib[k] = static_cast<unsigned>(cold[jc >> 3]) >> (jc & 4); // (jc is a multiple of 4; a wave reads 32 consecutive bytes)
   }
   double xg[K][4];
   const XGather xr = make_xgather(x, HINT);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (wave_has[k]) {
-      if (HINT) {
-        xg[k][0] = gather_hinted(xr, c[k].x, nib[k] & 1u);
-        xg[k][1] = gather_hinted(xr, c[k].y, nib[k] & 2u);
-        xg[k][2] = gather_hinted(xr, c[k].z, nib[k] & 4u);
-        xg[k][3] = gather_hinted(xr, c[k].w, nib[k] & 8u);
-      } else { // one VGPR and one shift per gather address (the caller vouches for 8 * n < 2^32: x32)
-        xg[k][0] = gather_u32(x, c[k].x);
-        xg[k][1] = gather_u32(x, c[k].y);
-        xg[k][2] = gather_u32(x, c[k].z);
-        xg[k][3] = gather_u32(x, c[k].w);
-      }
+    if (HINT) {
+      xg[k][0] = gather_hinted(xr, c[k].x, nib[k] & 1u);
+      xg[k][1] = gather_hinted(xr, c[k].y, nib[k] & 2u);
+      xg[k][2] = gather_hinted(xr, c[k].z, nib[k] & 4u);
+      xg[k][3] = gather_hinted(xr, c[k].w, nib[k] & 8u);
+    } else { // one VGPR and one shift per gather address (the caller vouches for 8 * n < 2^32: x32)
+      xg[k][0] = gather_u32(x, c[k].x);
+      xg[k][1] = gather_u32(x, c[k].y);
+      xg[k][2] = gather_u32(x, c[k].z);
+      xg[k][3] = gather_u32(x, c[k].w);
     }
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (wave_has[k]) {
-      const int g = threadIdx.x + k * THREADS;
-      double2v p0, p1;
-      p0.x = va[k].x * xg[k][0];
-      p0.y = va[k].y * xg[k][1];
-      p1.x = vb[k].x * xg[k][2];
-      p1.y = vb[k].y * xg[k][3];
-      double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
-      dst[0] = p0;
-      dst[1] = p1;
+    const int g = threadIdx.x + k * THREADS;
+    double2v p0, p1;
+    p0.x = va[k].x * xg[k][0];
+    p0.y = va[k].y * xg[k][1];
+    p1.x = vb[k].x * xg[k][2];
+    p1.y = vb[k].y * xg[k][3];
+    double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
+    dst[0] = p0;
+    dst[1] = p1;
+  }
+}
+
+// The wavefronts at a tile's end (their last step starts at or above `hi`; one in eight on a row-block grid): one step at a time, the loop NOT
+// unrolled -- with NPT = 8 such a wavefront has at most one step to do anyway, and a body that cannot set the kernel's register count (the
+// unrolled form with per-step branches cost up to 16 registers of undefined-value copies in some instances).
+template <int THREADS, int NPT, bool NTC, bool NTV, bool HINT>
+__device__ __forceinline__ void stage_products_tail(double *__restrict__ lds, int a0, int hi, const int *__restrict__ ci,
+                                                    const double *__restrict__ v, const double *__restrict__ x,
+                                                    const unsigned char *__restrict__ cold) {
+  const XGather xr = make_xgather(x, HINT);
+#pragma nounroll
+  for (int k = 0; k < NPT / 4 - 1; ++k) {
+    const int wave_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + k * THREADS));
+    if (wave_j >= hi) break; // wave-uniform
+    const int g = threadIdx.x + k * THREADS;
+    const int j = a0 + 4 * g;
+    const int jc = (j < hi) ? j : a0;
+    const int4v c = load_stream_i4<NTC>(ci + jc);
+    const double2v va = load_stream_d2<NTV>(v + jc), vb = load_stream_d2<NTV>(v + jc + 2);
+    double xg[4];
+    if (HINT) {
+      const unsigned nib = static_cast<unsigned>(cold[jc >> 3]) >> (jc & 4);
+      xg[0] = gather_hinted(xr, c.x, nib & 1u);
+      xg[1] = gather_hinted(xr, c.y, nib & 2u);
+      xg[2] = gather_hinted(xr, c.z, nib & 4u);
+      xg[3] = gather_hinted(xr, c.w, nib & 8u);
+    } else {
+      xg[0] = gather_u32(x, c.x);
+      xg[1] = gather_u32(x, c.y);
+      xg[2] = gather_u32(x, c.z);
+      xg[3] = gather_u32(x, c.w);
     }
+    double2v p0, p1;
+    p0.x = va.x * xg[0];
+    p0.y = va.y * xg[1];
+    p1.x = vb.x * xg[2];
+    p1.y = vb.y * xg[3];
+    double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
+    dst[0] = p0;
+    dst[1] = p1;
   }
 }
 
@@ -104,8 +136,8 @@ __device__ __forceinline__ void stage_products(double *__restrict__ lds, int a0,
   if (allow_fast && x32 && ((hi + 3) & ~3) <= nnz) {
     // the wavefront's LAST step starts below hi: so do all its steps (wave-uniform)
     const int last_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + (K - 1) * THREADS));
-    if (last_j < hi) stage_products_fast<THREADS, NPT, NTC, NTV, HINT, true>(lds, a0, hi, ci, v, x, cold);
-    else stage_products_fast<THREADS, NPT, NTC, NTV, HINT, false>(lds, a0, hi, ci, v, x, cold);
+    if (last_j < hi) stage_products_all<THREADS, NPT, NTC, NTV, HINT>(lds, a0, hi, ci, v, x, cold);
+    else stage_products_tail<THREADS, NPT, NTC, NTV, HINT>(lds, a0, hi, ci, v, x, cold);
     return;
   }
   // General form: the tile that holds the ragged end of the arrays (one in the grid), `stage_fast = 0` (tests), and x of 4 GB and more
@@ -217,88 +249,121 @@ __device__ __forceinline__ void stage_finish(double *__restrict__ lds, const Str
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 typedef uint2v uint2v_a2 __attribute__((aligned(2)));
 
-// ALL: every step of this wavefront starts below `hi` (the caller's wave-uniform test) -- the body then has no branch on has[k] at all.
-// With the per-step branches the waitcnt pass cannot count across them: it placed s_waitcnt vmcnt(0) in front of the first decode (ALL the
-// value loads back before the first gather leaves) where vmcnt(5) is what the decode needs (record + offsets).  seven of eight wavefront
-// steps of a row-block grid are ALL steps (tiles are filled to 1800 of 2048 products).
-template <int THREADS, int NPT, bool NTC, bool NTV, bool ALL>
-__device__ __forceinline__ void stage_products_c16_body(double *__restrict__ lds, int a0, int lo4, int hi, const Col16Dev &C,
-                                                        const double *__restrict__ v, const double *__restrict__ x) {
+// One step's decode: the four columns of this lane's group out of the record (held one entry per lane in rv) and the four codes dq.
+__device__ __forceinline__ void c16_decode(int (&c)[4], const uint2v d, int rv, int R, int lane, const int *__restrict__ ovf) {
+  const int bs = __builtin_amdgcn_readlane(rv, 0);
+  const int nesc = __builtin_amdgcn_readlane(rv, 1);
+  const int dq[4] = {static_cast<int>(d.x & 0xFFFFu), static_cast<int>(d.x >> 16), static_cast<int>(d.y & 0xFFFFu), static_cast<int>(d.y >> 16)};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) c[q] = bs + dq[q];
+  if (nesc > 0) { // wave-uniform
+    const int E = R - 4;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const bool e[4] = {dq[0] == 0xFFFF, dq[1] == 0xFFFF, dq[2] == 0xFFFF, dq[3] == 0xFFFF};
+    const unsigned long long slot[4] = {__ballot(e[0]), __ballot(e[1]), __ballot(e[2]), __ballot(e[3])};
+    // rank of this lane's first escape in the chunk: the escapes held by lower lanes (records list them in non-zero order)
+    int r = __popcll(slot[0] & lt) + __popcll(slot[1] & lt) + __popcll(slot[2] & lt) + __popcll(slot[3] & lt);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (slot[q]) { // wave-uniform: some lane's q-th entry is an escape
+        const int got = __shfl(rv, (4 + r) & (kWave - 1), kWave);
+        if (e[q]) c[q] = r < E ? got : ovf[__builtin_amdgcn_readlane(rv, 2) + r - E];
+      }
+      r += e[q] ? 1 : 0;
+    }
+  }
+}
+
+// A wavefront whose steps ALL start below `hi` (the caller's wave-uniform test): no branch between the loads.  With per-step branches the
+// waitcnt pass cannot count across them: it placed s_waitcnt vmcnt(0) in front of the first decode (ALL the value loads back before the first
+// gather leaves) where vmcnt(5) is what the decode needs (record + offsets) -- 2-5 % of these kernels' time on the FEM-class stand-ins
+// (profiles/r06_col16_counters.md section 5).  Seven of eight wavefronts of a row-block grid take this body (tiles are filled to 1800 of 2048).
+template <int THREADS, int NPT, bool NTC, bool NTV>
+__device__ __forceinline__ void stage_products_c16_all(double *__restrict__ lds, int a0, int lo4, int hi, const Col16Dev &C,
+                                                       const double *__restrict__ v, const double *__restrict__ x) {
   constexpr int K = NPT / 4;
   uint2v d[K];
   double2v va[K], vb[K];
   int rv[K];
-  bool has[K];
   const int lane = threadIdx.x & (kWave - 1);
   const int R = C.rec_ints;
   const int rl = lane < R ? lane : 0; // (lanes past the record re-read its first entry: no branch, no extra line)
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int wave_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + k * THREADS));
-    has[k] = ALL || wave_j < hi;
-    if (has[k]) rv[k] = C.rec[static_cast<long long>(wave_j >> 8) * R + rl];
+    rv[k] = C.rec[static_cast<long long>(wave_j >> 8) * R + rl];
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (has[k]) {
-      const int j = a0 + 4 * (threadIdx.x + k * THREADS);
-      const uint2v_a2 *p = reinterpret_cast<const uint2v_a2 *>(C.d16 + j); // (the offsets are padded to whole chunks)
-      d[k] = NTC ? __builtin_nontemporal_load(p) : *p;
-    }
+    const int j = a0 + 4 * (threadIdx.x + k * THREADS);
+    const uint2v_a2 *p = reinterpret_cast<const uint2v_a2 *>(C.d16 + j); // (the offsets are padded to whole chunks)
+    d[k] = NTC ? __builtin_nontemporal_load(p) : *p;
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (has[k]) {
-      const int j = a0 + 4 * (threadIdx.x + k * THREADS);
-      const int jv = (j >= lo4 && j < hi) ? j : lo4;
-      va[k] = load_stream_d2<NTV>(v + jv);
-      vb[k] = load_stream_d2<NTV>(v + jv + 2);
-    }
+    const int j = a0 + 4 * (threadIdx.x + k * THREADS);
+    const int jv = (j >= lo4 && j < hi) ? j : lo4;
+    va[k] = load_stream_d2<NTV>(v + jv);
+    vb[k] = load_stream_d2<NTV>(v + jv + 2);
   }
   double xg[K][4];
-  const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (has[k]) {
-      const int j = a0 + 4 * (threadIdx.x + k * THREADS);
-      const int bs = __builtin_amdgcn_readlane(rv[k], 0);
-      const int nesc = __builtin_amdgcn_readlane(rv[k], 1);
-      const int dq[4] = {static_cast<int>(d[k].x & 0xFFFFu), static_cast<int>(d[k].x >> 16), static_cast<int>(d[k].y & 0xFFFFu),
-                         static_cast<int>(d[k].y >> 16)};
-      int c[4] = {bs + dq[0], bs + dq[1], bs + dq[2], bs + dq[3]};
-      if (nesc > 0) { // wave-uniform
-        const int E = R - 4;
-        const bool e[4] = {dq[0] == 0xFFFF, dq[1] == 0xFFFF, dq[2] == 0xFFFF, dq[3] == 0xFFFF};
-        const unsigned long long slot[4] = {__ballot(e[0]), __ballot(e[1]), __ballot(e[2]), __ballot(e[3])};
-        // rank of this lane's first escape in the chunk: the escapes held by lower lanes (records list them in non-zero order)
-        int r = __popcll(slot[0] & lt) + __popcll(slot[1] & lt) + __popcll(slot[2] & lt) + __popcll(slot[3] & lt);
+    const int j = a0 + 4 * (threadIdx.x + k * THREADS);
+    int c[4];
+    c16_decode(c, d[k], rv[k], R, lane, C.ovf);
+    const bool mine = j >= lo4 && j < hi;
+    const int bs = __builtin_amdgcn_readlane(rv[k], 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (slot[q]) { // wave-uniform: some lane's q-th entry is an escape
-            const int got = __shfl(rv[k], (4 + r) & (kWave - 1), kWave);
-            if (e[q]) c[q] = r < E ? got : C.ovf[__builtin_amdgcn_readlane(rv[k], 2) + r - E];
-          }
-          r += e[q] ? 1 : 0;
-        }
-      }
-      const bool mine = j >= lo4 && j < hi;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) xg[k][q] = gather_u32(x, mine ? c[q] : bs);
-    }
+    for (int q = 0; q < 4; ++q) xg[k][q] = gather_u32(x, mine ? c[q] : bs);
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (has[k]) {
-      const int g = threadIdx.x + k * THREADS;
-      double2v p0, p1;
-      p0.x = va[k].x * xg[k][0];
-      p0.y = va[k].y * xg[k][1];
-      p1.x = vb[k].x * xg[k][2];
-      p1.y = vb[k].y * xg[k][3];
-      double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
-      dst[0] = p0;
-      dst[1] = p1;
-    }
+    const int g = threadIdx.x + k * THREADS;
+    double2v p0, p1;
+    p0.x = va[k].x * xg[k][0];
+    p0.y = va[k].y * xg[k][1];
+    p1.x = vb[k].x * xg[k][2];
+    p1.y = vb[k].y * xg[k][3];
+    double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
+    dst[0] = p0;
+    dst[1] = p1;
+  }
+}
+
+// The wavefronts at a tile's end: one step at a time, not unrolled (see stage_products_tail).
+template <int THREADS, int NPT, bool NTC, bool NTV>
+__device__ __forceinline__ void stage_products_c16_tail(double *__restrict__ lds, int a0, int lo4, int hi, const Col16Dev &C,
+                                                        const double *__restrict__ v, const double *__restrict__ x) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int R = C.rec_ints;
+  const int rl = lane < R ? lane : 0;
+#pragma nounroll
+  for (int k = 0; k < NPT / 4 - 1; ++k) {
+    const int wave_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + k * THREADS));
+    if (wave_j >= hi) break; // wave-uniform
+    const int g = threadIdx.x + k * THREADS;
+    const int j = a0 + 4 * g;
+    const int rv = C.rec[static_cast<long long>(wave_j >> 8) * R + rl];
+    const uint2v_a2 *p = reinterpret_cast<const uint2v_a2 *>(C.d16 + j);
+    const uint2v d = NTC ? __builtin_nontemporal_load(p) : *p;
+    const int jv = (j >= lo4 && j < hi) ? j : lo4;
+    const double2v va = load_stream_d2<NTV>(v + jv), vb = load_stream_d2<NTV>(v + jv + 2);
+    int c[4];
+    c16_decode(c, d, rv, R, lane, C.ovf);
+    const bool mine = j >= lo4 && j < hi;
+    const int bs = __builtin_amdgcn_readlane(rv, 0);
+    double xg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xg[q] = gather_u32(x, mine ? c[q] : bs);
+    double2v p0, p1;
+    p0.x = va.x * xg[0];
+    p0.y = va.y * xg[1];
+    p1.x = vb.x * xg[2];
+    p1.y = vb.y * xg[3];
+    double2v *dst = reinterpret_cast<double2v *>(lds + 4 * g);
+    dst[0] = p0;
+    dst[1] = p1;
   }
 }
 
@@ -307,8 +372,8 @@ __device__ __forceinline__ void stage_products_c16(double *__restrict__ lds, int
                                                    const double *__restrict__ v, const double *__restrict__ x) {
   // the wavefront's LAST step starts below hi: so do all its steps (wave-uniform)
   const int last_j = __builtin_amdgcn_readfirstlane(a0 + 4 * ((threadIdx.x & ~(kWave - 1)) + (NPT / 4 - 1) * THREADS));
-  if (last_j < hi) stage_products_c16_body<THREADS, NPT, NTC, NTV, true>(lds, a0, lo4, hi, C, v, x);
-  else stage_products_c16_body<THREADS, NPT, NTC, NTV, false>(lds, a0, lo4, hi, C, v, x);
+  if (last_j < hi) stage_products_c16_all<THREADS, NPT, NTC, NTV>(lds, a0, lo4, hi, C, v, x);
+  else stage_products_c16_tail<THREADS, NPT, NTC, NTV>(lds, a0, lo4, hi, C, v, x);
 }
 
 // Stale-plan guard of the kernels that read the encoding: they no longer read colindex, so an in-place edit of the column indices (same rowptr)
