@@ -422,7 +422,17 @@ __device__ __forceinline__ double tile_row_sum(const double *__restrict__ lds, S
       sh.hi[slot] = hi;
     }
   } else {
-    for (int j = lo + lane; j < hi; j += w) s += lds[j];
+    // four reads in flight, added in the loop's own order (bitwise the one-at-a-time sum): the loop as written is one LDS round trip per
+    // addition -- s_waitcnt lgkmcnt(0) between ds_read_b64 and v_add_f64, six to eight times for a row of 22-30 products on four lanes
+    int j = lo + lane;
+    for (; j + 3 * w < hi; j += 4 * w) {
+      const double a = lds[j], b = lds[j + w], c = lds[j + 2 * w], d = lds[j + 3 * w];
+      s += a;
+      s += b;
+      s += c;
+      s += d;
+    }
+    for (; j < hi; j += w) s += lds[j];
   }
   // the barrier itself tells every thread how many spans were posted (no shared variable to read after it, so a thread
   // that is late here cannot see a post from a later call)
