@@ -147,7 +147,11 @@ Tunable g_tunables[] = {
                                // size / staging order, the row-block-plus block size, gather hints -- follows a fixed rule on the
                                // matrix' shape instead (strategy_picker.cpp:19-65: the reference's choice is a pure function of its
                                // inputs), so two processes run the same kernels in the same configuration and y is bitwise equal
-                               // across processes and runs.  Costs the per-matrix optimum (a few per cent on most stand-ins)
+                               // across processes and runs.  Costs the per-matrix optimum (a few per cent on most stand-ins).
+                               // 0 (default, round 6): the rule serves UNTIL THE PLAN IS SETTLED -- the calls before that are answered by the plan's
+                               // rule twin while the timings advance beside them against a scratch y, so early iterations are bitwise equal to each
+                               // other; from the first settled call on the timed choices serve (dispatch.cpp run_spmv).  -1: the timed choices as
+                               // far as they have come serve from the first call (rounds 2-5: the last bits of y could change while a plan settled)
     {"col_slabs", -1, -1},     // column-slab blocking with a slab-major COPY of colindex and values (k_slab.hip): A = sum of S column-range slabs, an SpMV is S
                                // consecutive SpMVs of the named strategy, each gathering from 1/S of x (power-law columns: R-MAT scale 25 5.0 -> 4.4 ms
                                // with S = 8; a slab keeps only the rows that have non-zeros in it).  -1 (round 6) = automatic: a plan whose own timed

@@ -818,9 +818,100 @@ static int slab_copy_auto(Plan &p, int strategy, hipStream_t st, int n, const do
   return S;
 }
 
+namespace {
+thread_local bool t_early_clock = false; // run_spmv's rule-twin path: the tuning pass's budget clock started when the CALL began (twin's serve included)
+thread_local std::chrono::steady_clock::time_point t_early_began;
+
+void run_spmv_call(int strategy, int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
+                   const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx, double *dy,
+                   const double *dy_in);
+} // namespace
+
+// One SpMV call.  Round 6 (review item 7): while a matrix's per-matrix timings are open, its calls are SERVED BY RULE -- by the plan's rule twin,
+// a second plan of the same arrays that decides everything the way `deterministic = 1` does -- and the timings advance beside them against a scratch
+// y, under the same budget (first_call_budget / later_call_budget, the clock started when the call began, the twin's work included).  So the
+// iterations before a plan settles are bitwise equal to each other (rounds 2-5 served them with the choices as far as they had come: the result's
+// last bits could change from one call to the next while the plan settled), and from the first settled call on the timed choices serve, bitwise
+// equal among themselves.  One switch per (matrix, strategy, beta class), at a call the caller can see (spmv_acc_query_plan's `settled`).
+// Outside this: `deterministic = 1` (always the rule), `deterministic = -1` (the earlier behaviour), spmv_acc_prepare (settles before the first
+// call), stream captures (time nothing), the slabs of a slab-major copy (derived matrices of a settled parent).
 void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
               const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx, double *dy,
               const double *dy_in) {
+  apply_env_tunables();
+  // (a forced slab-major copy -- col_slabs >= 2 -- is pinned by the caller and holds the matrix a second time: no twin of that)
+  bool early = rule_until_settled() && !t_in_slab && !t_rule_twin && t_unbounded_tuning == 0 && m > 0 && d_rowptr && dy && strategy >= 0 &&
+               strategy < kStrategyCount && strategy < 32 && tun(kT_col_slabs) < 2;
+  bool capturing = false;
+  if (early) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    capturing = hipStreamIsCapturing(t_stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    (void)hipGetLastError();
+  }
+  if (early) early = !plan_settled_for(d_rowptr, d_colindex, d_value, m, n, strategy, beta != 0.0 ? 1 : 0);
+  if (!early) {
+    run_spmv_call(strategy, trans, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy, dy_in);
+    return;
+  }
+  if (capturing && !rule_twin_exists(d_rowptr, d_colindex, d_value, m, n)) {
+    // (a capture on a plan that spmv_acc_prepare settled for the other beta class, or that no eager call of this kind has met: no twin to record --
+    // the plan's own kernels with what it holds, as before round 6)
+    run_spmv_call(strategy, trans, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy, dy_in);
+    return;
+  }
+  if (capturing) {
+    // a capture of an unsettled plan records what serves such a plan: the twin's kernels (nothing is timed inside a capture) -- and the twin stays
+    // alive for the graph's sake when the plan settles later
+    struct TwinScope {
+      TwinScope() { t_rule_twin = true; }
+      ~TwinScope() { t_rule_twin = false; }
+    } twin;
+    run_spmv_call(strategy, trans, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy, dy_in);
+    return;
+  }
+  const auto began = std::chrono::steady_clock::now();
+  const int err_before = last_error_code_only();
+  // 1. the caller's y, by rule
+  int served_kernel = -1, served_c16 = 0;
+  {
+    struct TwinScope {
+      TwinScope() { t_rule_twin = true; }
+      ~TwinScope() { t_rule_twin = false; }
+    } twin;
+    run_spmv_call(strategy, trans, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, dy, dy_in);
+    if (const std::shared_ptr<Plan> tp = t_last_plan.lock()) {
+      served_kernel = tp->last_kernel;
+      served_c16 = tp->last_c16;
+    }
+  }
+  if (last_error_code_only() != err_before && last_error_code_only() != kOk && last_error_code_only() != kErrUnsupportedTrans) return; // (the call failed: nothing to tune)
+  // 2. the timings, one budget's worth, against a scratch y (tune_scratch: this thread's, released when the pass returns)
+  double *scratch = tune_scratch(static_cast<size_t>(m));
+  if (!scratch) {
+    clear_error(); // (no room for a scratch y: the plan stays open, the twin keeps serving)
+    return;
+  }
+  (void)hipMemsetAsync(scratch, 0, sizeof(double) * static_cast<size_t>(m), t_stream);
+  t_early_began = began;
+  t_early_clock = true;
+  run_spmv_call(strategy, 0, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, scratch, nullptr);
+  t_early_clock = false;
+  // 3. what the caller can ask about is the plan being settled, served so far by its twin's kernel
+  if (const std::shared_ptr<Plan> p = t_last_plan.lock()) {
+    std::lock_guard<std::mutex> plan_lock(p->mu);
+    if (p->tuning_open || p->calls == 0) {
+      p->last_kernel = served_kernel;
+      p->last_c16 = served_c16;
+    }
+  }
+  if (plan_settled_for(d_rowptr, d_colindex, d_value, m, n, strategy, beta != 0.0 ? 1 : 0)) drop_rule_twin(d_rowptr, d_colindex, d_value, m, n);
+}
+
+namespace {
+void run_spmv_call(int strategy, int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
+                   const int *d_rowptr, const int *d_colindex, const double *d_value, const double *dx, double *dy,
+                   const double *dy_in) {
+  const int strategy_named = strategy;
   if (trans != 0) {
     // the reference never reads `trans` (only operation_none is supported, api/spmv.h:13); it computes
     // the non-transposed product.  Same here, but the mismatch is reported out of band.
@@ -876,16 +967,20 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   struct BudgetScope {
     Plan &p;
     bool outer;
+    int strategy, cls;
     ~BudgetScope() {
       if (!outer) return;
       if (t_first_trial_ms > 0.f) p.trial_ms = t_first_trial_ms;
       p.tuning_open = t_tuning_deferred; // (a call that deferred nothing has settled everything on its path)
+      if (strategy >= 0 && strategy < 32) p.served[cls] |= 1u << strategy;
       t_budget_spmvs = 0.0;
       t_budget_ms = -1.0;
     }
-  } budget_scope{*p, !t_in_slab};
+  } budget_scope{*p, !t_in_slab, strategy_named, beta != 0.0 ? 1 : 0};
   if (!t_in_slab) {
-    t_call_began = std::chrono::steady_clock::now();
+    // (the rule-twin path: the FIRST call's budget covers the twin's build and serve too; a later call's two SpMV-equivalents start here, or a small
+    // matrix' twin launch alone would use them up and no phase would ever start)
+    t_call_began = (t_early_clock && p->calls == 0) ? t_early_began : std::chrono::steady_clock::now();
     t_tuning_deferred = false;
     t_first_trial_ms = 0.f;
     const int allowance = p->calls == 0 ? tun(kT_first_call_budget) : tun(kT_later_call_budget);
@@ -916,6 +1011,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   }
   p->last_stream = st;
   p->launched = true;
+  if (t_capturing) p->captured = true;
   // where this call's kernels read the old y (kernels.hpp CsrDev::yin); the plan's lock is held until the launches are enqueued
   struct YinScope {
     CsrDev &A;
@@ -1109,5 +1205,6 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   if (launch_err != hipSuccess && last_error_code_only() == kOk)
     set_error(kErrHip, std::string("kernel launch failed: ") + hipGetErrorString(launch_err));
 }
+} // namespace
 
 } // namespace spmv_acc

@@ -52,7 +52,17 @@ enum TunableId {
 };
 extern Tunable g_tunables[];
 void apply_env_tunables();
-inline int tun(TunableId id) { return g_tunables[id].val; } // apply_env_tunables() has run: run_spmv calls it first
+// A plan's RULE TWIN (round 6, dispatch.cpp run_spmv): while a matrix's per-matrix timings are still open its calls are served by a second plan of the
+// same arrays that decides everything by rule -- what `deterministic = 1` does for every call -- so that the iterations before the plan settles are
+// bitwise equal to each other whatever the timings have found so far.  This thread is serving from (or building) such a twin:
+extern thread_local bool t_rule_twin;
+// tunable `deterministic`: 1 = every call by rule; 0 (default) = by rule until the plan is settled, the timed choices from then on; -1 = the timed
+// choices as far as they have come serve from the first call (rounds 2-5).  tun(kT_deterministic) reads as a boolean everywhere: "is THIS call by rule?"
+inline int tun(TunableId id) { // apply_env_tunables() has run: run_spmv calls it first
+  if (id == kT_deterministic) return (t_rule_twin || g_tunables[id].val > 0) ? 1 : 0;
+  return g_tunables[id].val;
+}
+inline bool rule_until_settled() { return g_tunables[kT_deterministic].val == 0; }
 bool quarters_uneven(const RowptrSamples &s);
 int classic_vec(long long avg);
 int tile_vec(long long avg);
@@ -66,7 +76,7 @@ enum LastKernel { kKernelRowblock = 0, kKernelPlus = 1, kKernelFlatTile = 2, kKe
                   kKernelWaveRow = 6, kKernelLight = 7, kKernelBlockRow = 8, kKernelColSlabs = 9, kKernelScaleOnly = 10 };
 extern thread_local int t_strict_name; // the strategy the caller NAMED when tunable strict_strategy is on (else -1): run_flat / run_plus keep to the name's kernel
 
-typedef std::tuple<int, const void *, const void *, const void *, int, int> PlanKey;
+typedef std::tuple<int, const void *, const void *, const void *, int, int, int> PlanKey; // device, rowptr, colindex, value, m, n, 1 for a rule twin
 
 struct Plan {
   int device = 0;
@@ -82,6 +92,8 @@ struct Plan {
   int last_c16 = -1;               // the plan's latest SpMV read the 16-bit column encoding (its record ints) or colindex (0): spmv_acc_query_plan_col16
   int last_kernel = -1;            // which kernel the plan's latest SpMV ran (kKernel*, below): spmv_acc_query_plan_last_kernel, strict_strategy's test
   bool tuning_open = true;         // some per-matrix timing was deferred (or has not been reached yet): later calls may resume it
+  bool captured = false;           // a stream capture recorded kernels of this plan (a rule twin then outlives its plan's settling)
+  unsigned served[2] = {0, 0};     // bit s: strategy s has completed a call of this beta class on this plan (with tuning_open: is the plan settled FOR a call?)
   CsrDev A;
   int guard_slot = -1;
   bool have_samples = false;
@@ -261,6 +273,10 @@ extern std::map<PlanKey, std::shared_ptr<Plan>> g_plans; // a running call keeps
 extern thread_local std::weak_ptr<Plan> t_last_plan;     // the plan this thread's latest run_spmv used
 extern thread_local bool t_capturing;
 bool plan_work_allowed(const char *what);
+// is there a plan of these arrays whose timings are closed for calls of this strategy and beta class? (run_spmv's rule-twin decision; no plan is made)
+bool plan_settled_for(const int *rp, const int *ci, const double *v, int m, int n, int strategy, int cls);
+void drop_rule_twin(const int *rp, const int *ci, const double *v, int m, int n);
+bool rule_twin_exists(const int *rp, const int *ci, const double *v, int m, int n);
 const int *host_view(const int *h); // h if the pointer is host-readable, else null
 bool fetch_samples(Plan &p, const int *h_rowptr);
 std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const int *rp, const int *ci, const double *v);

@@ -318,6 +318,14 @@ void drain_deferred_locked() { // g_mu held
     dead.swap(g_deferred_rp);
   }
 }
+// a plan and its rule twin (PlanKey's last member) live and die together: a stale matrix, a changed nnz, the LRU bound and the release entries take both
+static void erase_with_sibling_locked(const PlanKey &k) { // g_mu held
+  PlanKey a = k, b = k;
+  std::get<6>(a) = 0;
+  std::get<6>(b) = 1;
+  g_plans.erase(a);
+  g_plans.erase(b);
+}
 thread_local std::weak_ptr<Plan> t_last_plan;     // the plan this thread's latest run_spmv used (last_error asks it, and only it)
 
 // Is the calling thread inside a stream capture (set by run_spmv)?  Plan work -- allocations, synchronisation, timings -- would
@@ -379,7 +387,7 @@ bool fetch_samples(Plan &p, const int *h_rowptr) {
 std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const int *rp, const int *ci, const double *v) {
   int dev = 0;
   if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
-  const PlanKey key(dev, rp, ci, v, m, n);
+  const PlanKey key(dev, rp, ci, v, m, n, t_rule_twin ? 1 : 0);
   std::lock_guard<std::mutex> lk(g_mu);
   drain_deferred_locked();
   auto it = g_plans.find(key);
@@ -389,7 +397,7 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
               "the matrix behind a cached plan changed (same pointers and shape, different rowptr) without "
               "spmv_acc_release_plans: the results of the EARLIER calls made on it since the change are invalid; the plan has "
               "been rebuilt, so the call that reports this ran on the matrix as it is now and its y is valid");
-    g_plans.erase(it);
+    erase_with_sibling_locked(key);
     it = g_plans.end();
   }
   if (it != g_plans.end()) {
@@ -399,14 +407,21 @@ std::shared_ptr<Plan> get_plan(int m, int n, int nnz, const int *h_rowptr, const
     }
     // same buffers, different nnz: the caller rebuilt the matrix in place
     if (!plan_work_allowed("rebuilding the plan of a matrix whose nnz changed")) return nullptr;
-    g_plans.erase(it);
+    erase_with_sibling_locked(key);
   }
   if (!plan_work_allowed("building the plan of a matrix seen for the first time")) return nullptr;
-  if (g_plans.size() >= kMaxPlans) {
-    auto oldest = g_plans.begin();
-    for (auto jt = g_plans.begin(); jt != g_plans.end(); ++jt)
-      if (jt->second->last_use < oldest->second->last_use) oldest = jt;
-    g_plans.erase(oldest);
+  if (!t_rule_twin && g_plans.size() >= kMaxPlans) { // (the bound counts matrices: a twin neither counts nor evicts)
+    size_t primaries = 0;
+    auto oldest = g_plans.end();
+    for (auto jt = g_plans.begin(); jt != g_plans.end(); ++jt) {
+      if (std::get<6>(jt->first) != 0) continue;
+      ++primaries;
+      if (oldest == g_plans.end() || jt->second->last_use < oldest->second->last_use) oldest = jt;
+    }
+    if (primaries >= kMaxPlans && oldest != g_plans.end()) {
+      const PlanKey gone = oldest->first;
+      erase_with_sibling_locked(gone);
+    }
   }
   if (nnz < 0) {
     if ((h_rowptr = host_view(h_rowptr)) != nullptr) {
@@ -480,7 +495,7 @@ bool report_stale_last_plan() {
   t_last_plan.reset();
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_plans.find(p->key);
-  if (it != g_plans.end() && it->second == p) g_plans.erase(it);
+  if (it != g_plans.end() && it->second == p) erase_with_sibling_locked(p->key);
   return true;
 }
 } // namespace detail
@@ -489,14 +504,17 @@ bool report_stale_last_plan() {
 // from several threads and want one check after a device-wide synchronisation; not on any hot path.
 int check_plans() {
   std::lock_guard<std::mutex> lk(g_mu);
-  int dropped = 0;
-  for (auto it = g_plans.begin(); it != g_plans.end();) {
-    if (it->second->is_stale()) {
-      it = g_plans.erase(it);
-      ++dropped;
-    } else {
-      ++it;
-    }
+  int dropped = 0; // (matrices: a plan and its rule twin count once)
+  std::vector<PlanKey> gone;
+  for (auto &kv : g_plans) {
+    if (!kv.second->is_stale()) continue;
+    PlanKey k = kv.first;
+    std::get<6>(k) = 0;
+    if (std::find(gone.begin(), gone.end(), k) == gone.end()) gone.push_back(k);
+  }
+  for (const PlanKey &k : gone) {
+    erase_with_sibling_locked(k);
+    ++dropped;
   }
   if (dropped) set_error(kErrBadArgument, kStaleText);
   return dropped;
@@ -520,7 +538,7 @@ void release_plans(const int *d_rowptr, int m_only) {
 bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto &kv : g_plans) {
-    if (std::get<1>(kv.first) == d_rowptr && std::get<4>(kv.first) == m) {
+    if (std::get<1>(kv.first) == d_rowptr && std::get<4>(kv.first) == m && std::get<6>(kv.first) == 0) { // (a rule twin is not what callers ask about)
       const Plan &p = *kv.second;
       out->nnz = p.A.nnz;
       out->adaptive_branch = p.have_samples ? adaptive_branch(m, p.samples) : 0;
@@ -549,9 +567,39 @@ bool query_plan(const int *d_rowptr, int m, PlanInfo *out) {
   return false;
 }
 
-int cached_plan_count() {
+int cached_plan_count() { // (the rule twins of unsettled plans are not counted: they come and go with their plans)
   std::lock_guard<std::mutex> lk(g_mu);
-  return static_cast<int>(g_plans.size());
+  int n = 0;
+  for (auto &kv : g_plans) n += std::get<6>(kv.first) == 0 ? 1 : 0;
+  return n;
 }
+
+namespace detail {
+bool plan_settled_for(const int *rp, const int *ci, const double *v, int m, int n, int strategy, int cls) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return true; // (the call itself will report it)
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_plans.find(PlanKey(dev, rp, ci, v, m, n, 0));
+  if (it == g_plans.end()) return false;
+  const Plan &p = *it->second;
+  return p.calls > 0 && !p.tuning_open && strategy >= 0 && strategy < 32 && ((p.served[cls & 1] >> strategy) & 1u);
+}
+
+bool rule_twin_exists(const int *rp, const int *ci, const double *v, int m, int n) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_plans.find(PlanKey(dev, rp, ci, v, m, n, 1)) != g_plans.end();
+}
+
+void drop_rule_twin(const int *rp, const int *ci, const double *v, int m, int n) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_plans.find(PlanKey(dev, rp, ci, v, m, n, 1));
+  // (a twin that a stream capture recorded stays: the graph's kernels read its tables until the caller releases the matrix' plans)
+  if (it != g_plans.end() && !it->second->captured) g_plans.erase(it);
+}
+} // namespace detail
 
 } // namespace spmv_acc

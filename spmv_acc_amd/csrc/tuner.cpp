@@ -243,6 +243,7 @@ thread_local std::chrono::steady_clock::time_point t_call_began;
 thread_local double t_budget_spmvs = 0.0;
 thread_local double t_budget_ms = -1.0;
 thread_local bool t_tuning_deferred = false;
+thread_local bool t_rule_twin = false;
 thread_local float t_first_trial_ms = 0.f;
 thread_local int t_unbounded_tuning = 0;
 thread_local bool t_coarse_tuning = false;

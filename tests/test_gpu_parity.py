@@ -403,8 +403,18 @@ def test_stream_and_hipgraph_capture(torch_dev, oracle, hiplib):
         hiplib.spmv_acc_set_stream(side.cuda_stream)
         for strat in ("adaptive", "flat", "line_enhance", "adaptive_plus"):
             dy = dy0.clone()
+            # (steady state: the calls before a plan settles are served by its rule twin, the ones after by the timed choices -- round 6 -- so the
+            # eager result the replays are compared with is taken once the plan has settled)
+            for _ in range(60):
+                dy = dy0.clone()
+                with torch.cuda.stream(side):
+                    spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat, h_rowptr=rowptr)  # builds the plan
+                side.synchronize()
+                if spmv_acc_amd.query_plan(drp, m)["settled"]:
+                    break
+            dy = dy0.clone()
             with torch.cuda.stream(side):
-                spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat, h_rowptr=rowptr)  # builds the plan
+                spmv_acc_amd.csr_spmv(1.0, 1.0, m, n, nnz, drp, dci, dv, dx, dy, strategy=strat, h_rowptr=rowptr)
             side.synchronize()
             eager = dy.cpu().numpy()
             assert oracle.scaled_error(eager, ref, 1.0, 1.0, rowptr, cols, vals, x, y0) <= SCALED_TOL, strat

@@ -561,3 +561,64 @@ def test_gather_hints_change_no_bit(torch_dev, oracle, hiplib):
     finally:
         hiplib.spmv_acc_reset_tunables()
         spmv_acc_amd.release_plans(drp)
+
+
+def test_calls_before_a_plan_settles_are_bitwise_equal(torch_dev, oracle, hiplib):
+    """Round 6 (review item 7): while a matrix's per-matrix timings are open its calls are served by the plan's RULE TWIN (what `deterministic = 1`
+    computes) and the timings advance beside them against a scratch y; from the first settled call on the timed choices serve.  So y changes its last
+    bits at most ONCE over the life of a plan, at a call the caller can see (`settled`), instead of whenever a timing phase finished (rounds 2-5).
+    Checked for two strategies and both beta classes on a matrix big enough that settling takes several calls; `deterministic = -1` keeps the old
+    behaviour and still matches the oracle."""
+    torch = torch_dev
+    m = n = 300_000
+    drp, dci, dv = synth.structured_csr_torch(m, n, 7_500_000, 0x5E77, device="cuda")
+    rowptr, cols, vals = (t.cpu().numpy() for t in (drp, dci, dv))
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(3)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    dx, dy0 = dev(torch, x), dev(torch, y0)
+
+    def call(strategy, alpha, beta):
+        y = dy0.clone()
+        spmv_acc_amd.csr_spmv(alpha, beta, m, n, nnz, drp, dci, dv, dx, y, strategy=strategy)
+        torch.cuda.synchronize()
+        assert hiplib.spmv_acc_last_error() == 0
+        return y, spmv_acc_amd.query_plan(drp, m)["settled"]
+
+    try:
+        for strategy in ("adaptive", "flat"):
+            for alpha, beta in ((0.5, -2.0), (1.25, 0.0)):
+                ref = oracle.host_spmv(alpha, beta, rowptr, cols, vals, x, y0)
+                # what the rule alone computes (a plan of its own: released before the run under test)
+                spmv_acc_amd.release_plans(drp)
+                assert hiplib.spmv_acc_set_tunable(b"deterministic", 1) == 0
+                by_rule, _ = call(strategy, alpha, beta)
+                assert hiplib.spmv_acc_set_tunable(b"deterministic", 0) == 0
+                spmv_acc_amd.release_plans(drp)
+                ys, settled = [], []
+                for _ in range(60):
+                    y, s = call(strategy, alpha, beta)
+                    ys.append(y)
+                    settled.append(s)
+                    if len(settled) >= 4 and all(settled[-3:]):
+                        break
+                assert settled[-1] == 1, (strategy, beta, settled)
+                first = settled.index(1)  # the call whose tuning pass closed the plan: itself still served by the twin
+                assert first >= 1, (strategy, beta, settled)  # (several calls: what the test is about)
+                for k in range(first + 1):
+                    assert torch.equal(ys[k], by_rule), (strategy, beta, k, settled)
+                for k in range(first + 1, len(ys)):
+                    assert torch.equal(ys[k], ys[first + 1]), (strategy, beta, k, settled)
+                    assert oracle.scaled_error(ys[k].cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL
+                assert oracle.scaled_error(by_rule.cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL
+                assert hiplib.spmv_acc_cached_plans() >= 1
+        # the earlier behaviour on request
+        spmv_acc_amd.release_plans(drp)
+        assert hiplib.spmv_acc_set_tunable(b"deterministic", -1) == 0
+        for _ in range(6):
+            y, _s = call("adaptive", 0.5, -2.0)
+            ref = oracle.host_spmv(0.5, -2.0, rowptr, cols, vals, x, y0)
+            assert oracle.scaled_error(y.cpu().numpy(), ref, 0.5, -2.0, rowptr, cols, vals, x, y0) <= SCALED_TOL
+    finally:
+        hiplib.spmv_acc_reset_tunables()
+        spmv_acc_amd.release_plans(drp)
