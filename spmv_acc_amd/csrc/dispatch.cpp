@@ -832,7 +832,8 @@ void run_spmv_call(int strategy, int trans, double alpha, double beta, int m, in
 // y, under the same budget (first_call_budget / later_call_budget, the clock started when the call began, the twin's work included).  So the
 // iterations before a plan settles are bitwise equal to each other (rounds 2-5 served them with the choices as far as they had come: the result's
 // last bits could change from one call to the next while the plan settled), and from the first settled call on the timed choices serve, bitwise
-// equal among themselves.  One switch per (matrix, strategy, beta class), at a call the caller can see (spmv_acc_query_plan's `settled`).
+// equal among themselves.  One switch per (matrix, strategy, beta class) -- Plan::settled_for, never taken back: what another strategy or the other
+// beta class still has open does not send a settled kind of call back to the twin -- at a call the caller can see (spmv_acc_query_plan's `settled`).
 // Outside this: `deterministic = 1` (always the rule), `deterministic = -1` (the earlier behaviour), spmv_acc_prepare (settles before the first
 // call), stream captures (time nothing), the slabs of a slab-major copy (derived matrices of a settled parent).
 void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, int nnz, const int *h_rowptr,
@@ -899,7 +900,8 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   // 3. what the caller can ask about is the plan being settled, served so far by its twin's kernel
   if (const std::shared_ptr<Plan> p = t_last_plan.lock()) {
     std::lock_guard<std::mutex> plan_lock(p->mu);
-    if (p->tuning_open || p->calls == 0) {
+    const int cls = beta != 0.0 ? 1 : 0;
+    if (!((p->settled_for[cls] >> strategy) & 1u)) {
       p->last_kernel = served_kernel;
       p->last_c16 = served_c16;
     }
@@ -972,7 +974,7 @@ void run_spmv_call(int strategy, int trans, double alpha, double beta, int m, in
       if (!outer) return;
       if (t_first_trial_ms > 0.f) p.trial_ms = t_first_trial_ms;
       p.tuning_open = t_tuning_deferred; // (a call that deferred nothing has settled everything on its path)
-      if (strategy >= 0 && strategy < 32) p.served[cls] |= 1u << strategy;
+      if (!t_tuning_deferred && strategy >= 0 && strategy < 32) p.settled_for[cls] |= 1u << strategy;
       t_budget_spmvs = 0.0;
       t_budget_ms = -1.0;
     }

@@ -93,7 +93,8 @@ struct Plan {
   int last_kernel = -1;            // which kernel the plan's latest SpMV ran (kKernel*, below): spmv_acc_query_plan_last_kernel, strict_strategy's test
   bool tuning_open = true;         // some per-matrix timing was deferred (or has not been reached yet): later calls may resume it
   bool captured = false;           // a stream capture recorded kernels of this plan (a rule twin then outlives its plan's settling)
-  unsigned served[2] = {0, 0};     // bit s: strategy s has completed a call of this beta class on this plan (with tuning_open: is the plan settled FOR a call?)
+  unsigned settled_for[2] = {0, 0}; // bit s: a call of strategy s and this beta class has run on this plan with nothing left open on its path -- such calls time
+                                   // nothing from then on, whatever other strategies / the other beta class still have open (run_spmv's rule-twin decision)
   CsrDev A;
   int guard_slot = -1;
   bool have_samples = false;

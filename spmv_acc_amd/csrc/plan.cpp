@@ -582,7 +582,7 @@ bool plan_settled_for(const int *rp, const int *ci, const double *v, int m, int 
   auto it = g_plans.find(PlanKey(dev, rp, ci, v, m, n, 0));
   if (it == g_plans.end()) return false;
   const Plan &p = *it->second;
-  return p.calls > 0 && !p.tuning_open && strategy >= 0 && strategy < 32 && ((p.served[cls & 1] >> strategy) & 1u);
+  return strategy >= 0 && strategy < 32 && ((p.settled_for[cls & 1] >> strategy) & 1u);
 }
 
 bool rule_twin_exists(const int *rp, const int *ci, const double *v, int m, int n) {

@@ -612,6 +612,19 @@ def test_calls_before_a_plan_settles_are_bitwise_equal(torch_dev, oracle, hiplib
                     assert oracle.scaled_error(ys[k].cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL
                 assert oracle.scaled_error(by_rule.cpu().numpy(), ref, alpha, beta, rowptr, cols, vals, x, y0) <= SCALED_TOL
                 assert hiplib.spmv_acc_cached_plans() >= 1
+        # a settled kind of call stays with the timed choices while ANOTHER kind (the other beta class, another strategy) is still being timed
+        spmv_acc_amd.release_plans(drp)
+        ys = []
+        for _ in range(60):
+            y, s = call("adaptive", 0.5, -2.0)
+            if s:
+                break
+        settled_y, _ = call("adaptive", 0.5, -2.0)
+        for other in (("adaptive", 1.25, 0.0), ("line_enhance", 0.5, -2.0)):
+            for _ in range(3):  # (unsettled calls of the other kind: served by the twin, their timings advancing)
+                call(*other)
+                again, _ = call("adaptive", 0.5, -2.0)
+                assert torch.equal(again, settled_y), other
         # the earlier behaviour on request
         spmv_acc_amd.release_plans(drp)
         assert hiplib.spmv_acc_set_tunable(b"deterministic", -1) == 0
