@@ -226,7 +226,11 @@ int spmv_acc_prepare_beta(int strategy, double beta, int m, int n, int nnz, cons
  *     matrix, keyed by a digest of (library version, device name, m, n, nnz, 64 rowptr samples); a later process that meets the
  *     same matrix on the same device adopts them and only runs the structural passes (NULL or "" switches it off);
  *   tunable "deterministic" = 1 / environment SPMV_ACC_DETERMINISTIC=1: nothing is timed at all, every choice follows a fixed
- *     rule on the matrix' shape -- y is then bitwise equal across processes and runs (the kernels never use atomics). */
+ *     rule on the matrix' shape -- y is then bitwise equal across processes and runs (the kernels never use atomics).
+ * Round 6: with the default ("deterministic" = 0) the calls made BEFORE a plan is settled are answered by that same rule (the plan's rule twin)
+ * while the timings advance beside them against a scratch y; from the first settled call on the timed choices serve.  y changes its last bits at
+ * most once per (matrix, strategy, beta class), at a call spmv_acc_query_plan_settled shows.  "deterministic" = -1: as rounds 2-5 (the timed
+ * choices as far as they have come serve from the first call on). */
 void spmv_acc_set_tune_cache(const char *path);
 
 /* ---- values changed in place, with the opt-in column slabs in use (new) ---------------------------------------------------------
@@ -280,7 +284,8 @@ int spmv_acc_query_plan_beta0(const int *d_rowptr, int m);
  * strategy (strategy_picker.cpp:19-65). */
 int spmv_acc_query_plan_slab_passes(const int *d_rowptr, int m);
 /* 1: the latest call on this plan left none of its per-matrix timings open -- the plan is settled, calls are launches only and bitwise stable;
- * 0: the first-call budget (tunable first_call_budget) deferred some, the next calls resume them (or call spmv_acc_prepare); -2 = no such plan.
+ * 0: the first-call budget (tunable first_call_budget) deferred some, the next calls resume them (or call spmv_acc_prepare); that call was answered
+ * by the plan's rule twin (round 6), as the following ones are until one returns 1 here; -2 = no such plan.
  * No reference counterpart (the reference times nothing). */
 int spmv_acc_query_plan_settled(const int *d_rowptr, int m);
 /* Did the plan's LATEST SpMV read the plan's 16-bit column encoding instead of colindex (round 6; tunable col16, default: timed per matrix and
