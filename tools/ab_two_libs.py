@@ -46,6 +46,10 @@ for name in names:
         for key, lib in libs.items():
             for k, val in knobs:
                 assert lib.spmv_acc_set_tunable(k.encode(), int(val)) == 0
+            if key == "exp":  # AB_EXP_KNOBS=k=v,...: tunables for the experimental build only (a build whose constants ask for other settings)
+                for kv in filter(None, os.environ.get("AB_EXP_KNOBS", "").split(",")):
+                    k, val = kv.split("=")
+                    assert lib.spmv_acc_set_tunable(k.encode(), int(val)) == 0
             args = (m, n, nnz, None, rp.data_ptr(), ci.data_ptr(), v.data_ptr(), x.data_ptr(), y.data_ptr())
             for _ in range(5):
                 lib.spmv_acc_csr_spmv_strategy(sid, 0, 1.0, 1.0, *args)
