@@ -886,6 +886,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
     }
   }
   if (last_error_code_only() != err_before && last_error_code_only() != kOk && last_error_code_only() != kErrUnsupportedTrans) return; // (the call failed: nothing to tune)
+  const double twin_prepare_us = t_last_prepare_us; // (spmv_acc_last_prepare_us reports the call's whole preparation: the twin's and the plan's)
   // 2. the timings, one budget's worth, against a scratch y (tune_scratch: this thread's, released when the pass returns)
   double *scratch = tune_scratch(static_cast<size_t>(m));
   if (!scratch) {
@@ -897,6 +898,7 @@ void run_spmv(int strategy, int trans, double alpha, double beta, int m, int n, 
   t_early_clock = true;
   run_spmv_call(strategy, 0, alpha, beta, m, n, nnz, h_rowptr, d_rowptr, d_colindex, d_value, dx, scratch, nullptr);
   t_early_clock = false;
+  t_last_prepare_us += twin_prepare_us;
   // 3. what the caller can ask about is the plan being settled, served so far by its twin's kernel
   if (const std::shared_ptr<Plan> p = t_last_plan.lock()) {
     std::lock_guard<std::mutex> plan_lock(p->mu);
