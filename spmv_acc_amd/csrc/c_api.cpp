@@ -151,7 +151,7 @@ constexpr int kNcclFloat64 = 8; // ncclDataType_t ncclFloat64 / ncclDouble (rccl
 
 extern "C" {
 
-const char *spmv_acc_version(void) { return "spmv_acc_amd 0.5 (gfx950)"; }
+const char *spmv_acc_version(void) { return "spmv_acc_amd 0.6 (gfx950)"; }
 
 int spmv_acc_set_strategy(const char *name) {
   const int s = parse_strategy(name);
